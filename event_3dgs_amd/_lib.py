@@ -1,0 +1,81 @@
+"""Loader of the C-ABI HIP library (include/e3dgs_hip.h) -- ctypes, no torch types cross it.
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
+ABI_VERSION = 1
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_fp, _ip, _vp, _cp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.e3dgs_abi_version.restype = C.c_int
+    if L.e3dgs_abi_version() != ABI_VERSION:
+        raise HipLibraryError("libe3dgs_hip.so ABI version mismatch; rebuild")
+    L.e3dgs_last_error.restype = C.c_char_p
+    L.e3dgs_rasterize_forward.restype = C.c_int
+    L.e3dgs_rasterize_forward.argtypes = (
+        [ALLOC_FN, _vp] * 3 + [C.c_int] * 3 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5
+        + [C.c_float, C.c_float, C.c_int, _fp, _ip, C.c_int, C.POINTER(C.c_int), _vp])
+    L.e3dgs_rasterize_backward.restype = C.c_int
+    L.e3dgs_rasterize_backward.argtypes = (
+        [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
+        + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, _vp])
+    L.e3dgs_state_offsets.restype = None
+    L.e3dgs_state_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)]
+    L.e3dgs_mark_visible.restype = C.c_int
+    L.e3dgs_mark_visible.argtypes = [C.c_int, _fp, _fp, _fp, _vp, _vp]
+    L.e3dgs_knn_scratch_bytes.restype = C.c_size_t
+    L.e3dgs_knn_scratch_bytes.argtypes = [C.c_int]
+    L.e3dgs_dist_knn3.restype = C.c_int
+    L.e3dgs_dist_knn3.argtypes = [C.c_int, _fp, _fp, _cp, _vp]
+    L.e3dgs_event_loss_scratch_bytes.restype = C.c_size_t
+    L.e3dgs_event_loss_scratch_bytes.argtypes = [C.c_int, C.c_int]
+    L.e3dgs_event_loss.restype = C.c_int
+    L.e3dgs_event_loss.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 4 + [_cp, _vp]
+    L.e3dgs_adam_step.restype = C.c_int
+    L.e3dgs_adam_step.argtypes = [C.c_size_t] + [_fp] * 4 + [C.c_float] * 4 + [C.c_int, _vp]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().e3dgs_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+EXPORTED_SYMBOLS = [
+    "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_backward",
+    "e3dgs_state_offsets", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
+    "e3dgs_event_loss", "e3dgs_adam_step",
+]

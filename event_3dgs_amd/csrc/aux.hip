@@ -1,0 +1,351 @@
+// aux.hip -- small kernels around the rasteriser: distCUDA2, event loss, Adam.
+#include "common.h"
+
+int e3_fail(hipError_t e, const char* what);
+
+// ------------------------------------------------------------------------------------ distCUDA2
+// Exact mean squared distance to the 3 nearest other points (scene/gaussian_model.py:134,
+// SURVEY Appendix C).  Uniform-grid search: points are binned into cubic cells (radix sort by
+// cell id with the same sort kernels as the rasteriser), then each point scans cell shells of
+// growing Chebyshev radius until the shell's lower distance bound exceeds its current 3rd best.
+struct KnnGrid {
+    float minx, miny, minz, inv_h, h;
+    int nx, ny, nz;
+};
+
+__global__ __launch_bounds__(256) void knn_bbox_kernel(int P, const float* __restrict__ pts, float* __restrict__ bbox) {
+    // bbox: [minx,miny,minz,maxx,maxy,maxz] as ordered-int atomics
+    __shared__ float smin[3][4], smax[3][4];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = pts[3 * (size_t)i + a];
+            mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { smin[a][wave] = mn[a]; smax[a][wave] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int a = threadIdx.x;
+        float lo = fminf(fminf(smin[a][0], smin[a][1]), fminf(smin[a][2], smin[a][3]));
+        float hi = fmaxf(fmaxf(smax[a][0], smax[a][1]), fmaxf(smax[a][2], smax[a][3]));
+        // monotone float->int mapping for atomicMin/Max
+        auto enc = [](float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; };
+        atomicMin(reinterpret_cast<int*>(bbox) + a, enc(lo));
+        atomicMax(reinterpret_cast<int*>(bbox) + 3 + a, enc(hi));
+    }
+}
+
+__device__ __forceinline__ float knn_dec(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__device__ __forceinline__ KnnGrid knn_grid(const float* bbox, int P) {
+    const int* b = reinterpret_cast<const int*>(bbox);
+    KnnGrid g;
+    g.minx = knn_dec(b[0]); g.miny = knn_dec(b[1]); g.minz = knn_dec(b[2]);
+    float ex = knn_dec(b[3]) - g.minx, ey = knn_dec(b[4]) - g.miny, ez = knn_dec(b[5]) - g.minz;
+    float ext = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-20f));
+    // aim at ~4 points per cell, at most 128 cells per axis (21 bits of cell id)
+    float cells = fminf(128.0f, fmaxf(1.0f, cbrtf((float)P / 4.0f)));
+    g.h = ext / cells * 1.0001f;
+    g.inv_h = 1.0f / g.h;
+    g.nx = min(128, (int)(ex * g.inv_h) + 1);
+    g.ny = min(128, (int)(ey * g.inv_h) + 1);
+    g.nz = min(128, (int)(ez * g.inv_h) + 1);
+    return g;
+}
+
+__device__ __forceinline__ void knn_cell_of(const KnnGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+    cx = min(g.nx - 1, max(0, (int)((x - g.minx) * g.inv_h)));
+    cy = min(g.ny - 1, max(0, (int)((y - g.miny) * g.inv_h)));
+    cz = min(g.nz - 1, max(0, (int)((z - g.minz) * g.inv_h)));
+}
+
+__global__ __launch_bounds__(256) void knn_cellid_kernel(int P, const float* __restrict__ pts,
+                                                         const float* __restrict__ bbox, uint32_t* __restrict__ cell,
+                                                         uint32_t* __restrict__ idx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    KnnGrid g = knn_grid(bbox, P);
+    int cx, cy, cz;
+    knn_cell_of(g, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], cx, cy, cz);
+    cell[i] = (uint32_t)((cz * g.ny + cy) * g.nx + cx);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void knn_cell_ranges_kernel(int P, const uint32_t* __restrict__ cell_sorted,
+                                                              const uint32_t* __restrict__ idx_sorted,
+                                                              const float* __restrict__ pts,
+                                                              uint32_t* __restrict__ cstart, uint32_t* __restrict__ cend,
+                                                              float4* __restrict__ pts_sorted) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    uint32_t c = cell_sorted[i];
+    if (i == 0 || cell_sorted[i - 1] != c) cstart[c] = (uint32_t)i;
+    if (i == P - 1 || cell_sorted[i + 1] != c) cend[c] = (uint32_t)i + 1;
+    uint32_t j = idx_sorted[i];
+    pts_sorted[i] = make_float4(pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2], __uint_as_float(j));
+}
+
+__global__ __launch_bounds__(256) void knn_search_kernel(int P, const float4* __restrict__ pts_sorted,
+                                                         const float* __restrict__ bbox,
+                                                         const uint32_t* __restrict__ cstart,
+                                                         const uint32_t* __restrict__ cend, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    KnnGrid g = knn_grid(bbox, P);
+    float4 p = pts_sorted[i];
+    int cx, cy, cz;
+    knn_cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+    float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+    const int maxr = max(g.nx, max(g.ny, g.nz));
+    // distance from p to the faces of its own cell -> lower bound for shell r is (r-1)*h + that margin
+    float fx = (p.x - g.minx) - cx * g.h, fy = (p.y - g.miny) - cy * g.h, fz = (p.z - g.minz) - cz * g.h;
+    float margin = fminf(fminf(fminf(fx, g.h - fx), fminf(fy, g.h - fy)), fminf(fz, g.h - fz));
+    margin = fmaxf(margin, 0.0f);
+    for (int r = 0; r <= maxr; ++r) {
+        if (r > 0) {
+            float lb = (float)(r - 1) * g.h + margin;
+            if (lb * lb > b2) break;
+        }
+        for (int dz = -r; dz <= r; ++dz) {
+            int z = cz + dz;
+            if (z < 0 || z >= g.nz) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                int y = cy + dy;
+                if (y < 0 || y >= g.ny) continue;
+                const bool face = (abs(dz) == r) || (abs(dy) == r);
+                const int step = face ? 1 : 2 * r;   // interior rows: only the two x extremes belong to the shell
+                for (int dx = -r; dx <= r; dx += (step > 0 ? step : 1)) {
+                    int x = cx + dx;
+                    if (x < 0 || x >= g.nx) continue;
+                    uint32_t c = (uint32_t)((z * g.ny + y) * g.nx + x);
+                    uint32_t s = cstart[c], e = cend[c];
+                    for (uint32_t k = s; k < e; ++k) {
+                        if ((int)k == i) continue;
+                        float4 q = pts_sorted[k];
+                        float ddx = q.x - p.x, ddy = q.y - p.y, ddz = q.z - p.z;
+                        float d = ddx * ddx + ddy * ddy + ddz * ddz;
+                        if (d < b2) {
+                            if (d < b1) {
+                                b2 = b1;
+                                if (d < b0) { b1 = b0; b0 = d; } else b1 = d;
+                            } else b2 = d;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float s = 0.0f; int n = 0;
+    if (b0 != INFINITY) { s += b0; ++n; }
+    if (b1 != INFINITY) { s += b1; ++n; }
+    if (b2 != INFINITY) { s += b2; ++n; }
+    float r = n == 3 ? s / 3.0f : (n ? s / (float)n : 0.0f);
+    out[__float_as_uint(p.w)] = r;
+}
+
+constexpr size_t KNN_MAX_CELLS = 128ull * 128ull * 128ull;
+
+size_t e3_knn_scratch_bytes(int P) {
+    size_t n = P > 0 ? (size_t)P : 1;
+    char* p = nullptr;
+    carve<float>(p, 64);
+    carve<uint32_t>(p, n); carve<uint32_t>(p, n); carve<uint32_t>(p, n); carve<uint32_t>(p, n);
+    carve<uint32_t>(p, sort_scratch_words(n));
+    carve<uint32_t>(p, KNN_MAX_CELLS); carve<uint32_t>(p, KNN_MAX_CELLS);
+    carve<float4>(p, n);
+    return (size_t)p + 256;
+}
+
+int e3_knn_impl(int P, const float* pts, float* out, char* scratch, hipStream_t s) {
+    if (P <= 0) return 0;
+    size_t n = (size_t)P;
+    char* p = scratch;
+    float* bbox = carve<float>(p, 64);
+    uint32_t* c0 = carve<uint32_t>(p, n); uint32_t* c1 = carve<uint32_t>(p, n);
+    uint32_t* i0 = carve<uint32_t>(p, n); uint32_t* i1 = carve<uint32_t>(p, n);
+    uint32_t* sscr = carve<uint32_t>(p, sort_scratch_words(n));
+    uint32_t* cstart = carve<uint32_t>(p, KNN_MAX_CELLS); uint32_t* cend = carve<uint32_t>(p, KNN_MAX_CELLS);
+    float4* ps = carve<float4>(p, n);
+    // init bbox: min slots = +inf encoding, max slots = -inf encoding
+    int init[6] = {0x7F800000, 0x7F800000, 0x7F800000, (int)0xFF800000 ^ 0x7FFFFFFF, (int)0xFF800000 ^ 0x7FFFFFFF,
+                   (int)0xFF800000 ^ 0x7FFFFFFF};
+    hipError_t e = hipMemcpyAsync(bbox, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e3_fail(e, "knn bbox init");
+    e = hipStreamSynchronize(s);   // `init` is a stack buffer
+    if (e != hipSuccess) return e3_fail(e, "knn bbox init sync");
+    unsigned pb = (unsigned)((P + 255) / 256);
+    knn_bbox_kernel<<<dim3(pb < 1024 ? pb : 1024), dim3(256), 0, s>>>(P, pts, bbox);
+    knn_cellid_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, pts, bbox, c0, i0);
+    uint32_t *cs, *is;
+    launch_radix_sort_pairs(c0, c1, i0, i1, n, 21, sscr, &cs, &is, s);
+    e = hipMemsetAsync(cstart, 0, KNN_MAX_CELLS * 4, s);
+    if (e != hipSuccess) return e3_fail(e, "knn memset");
+    e = hipMemsetAsync(cend, 0, KNN_MAX_CELLS * 4, s);
+    if (e != hipSuccess) return e3_fail(e, "knn memset");
+    knn_cell_ranges_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, cs, is, pts, cstart, cend, ps);
+    knn_search_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, ps, bbox, cstart, cend, out);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "knn kernels");
+}
+
+// ------------------------------------------------------------------------------------ event loss
+// train.py:165-203 fused into a reduction pass and a gradient pass.
+constexpr int EV_THREADS = 256;
+constexpr int EV_NSUM = 5;   // sum|D-D*|, count(D*!=0), sum sign*D, sum|image-gt_int|, sum|image-gt_blur|
+
+__device__ __forceinline__ float lum3(const float* __restrict__ img, size_t HW, size_t p) {
+    return FMA(0.1804f, img[2 * HW + p], FMA(0.35758f, img[HW + p], 0.4124f * img[p]));
+}
+
+__global__ __launch_bounds__(EV_THREADS) void event_reduce_kernel(
+    size_t HW, const float* __restrict__ image, const float* __restrict__ now, const float* __restrict__ next,
+    const float* __restrict__ gt_int, const float* __restrict__ gt_now, const float* __restrict__ gt_next,
+    const float* __restrict__ gt_blur, const float* __restrict__ c_ptr, float gt_c, double* __restrict__ partials) {
+    __shared__ double sred[EV_NSUM][EV_THREADS / WAVE];
+    const float c = c_ptr[0];
+    double acc[EV_NSUM] = {0, 0, 0, 0, 0};
+    for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
+        float D = (__logf(lum3(next, HW, p) + 1e-8f) - __logf(lum3(now, HW, p) + 1e-8f)) / c;
+        float Dg = (__logf(lum3(gt_next, HW, p) + 1e-8f) - __logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
+        float e = D - Dg;
+        acc[0] += fabsf(e);
+        acc[1] += (Dg != 0.0f) ? 1.0 : 0.0;
+        acc[2] += (double)((e > 0.0f) - (e < 0.0f)) * (double)D;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = image[ch * HW + p];
+            acc[3] += fabsf(v - gt_int[ch * HW + p]);
+            if (gt_blur) acc[4] += fabsf(v - gt_blur[ch * HW + p]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EV_NSUM; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        if ((threadIdx.x & 63) == 0) sred[k][threadIdx.x >> 6] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < EV_NSUM) {
+        double s = 0;
+        for (int w = 0; w < EV_THREADS / WAVE; ++w) s += sred[threadIdx.x][w];
+        partials[(size_t)blockIdx.x * EV_NSUM + threadIdx.x] = s;
+    }
+}
+
+// scalars (float[8]): 0 loss, 1 dL/dc, 2 rho, 3 L1 event, 4 L1 intensity, 5 L1 blur, 6 kE, 7 kI
+__global__ __launch_bounds__(WAVE) void event_finalize_kernel(int nblocks, size_t HW, const double* __restrict__ partials,
+                                                              const float* __restrict__ c_ptr, int has_blur,
+                                                              float* __restrict__ scalars) {
+    double acc[EV_NSUM] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += WAVE)
+#pragma unroll
+        for (int k = 0; k < EV_NSUM; ++k) acc[k] += partials[(size_t)b * EV_NSUM + k];
+#pragma unroll
+    for (int k = 0; k < EV_NSUM; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    if (threadIdx.x == 0) {
+        const double n = (double)HW, c = (double)c_ptr[0];
+        double L1E = acc[0] / n, rho = acc[1] / n, L1I = acc[3] / (3.0 * n), L1B = acc[4] / (3.0 * n);
+        double loss = 0.9 * L1E * rho + 0.1 * L1I * (1.0 - rho);
+        double outer = 1.0;
+        if (has_blur) { loss = 0.5 * loss + 0.5 * L1B; outer = 0.5; }
+        scalars[0] = (float)loss;
+        scalars[1] = (float)(-outer * 0.9 * rho * (acc[2] / n) / c);
+        scalars[2] = (float)rho; scalars[3] = (float)L1E; scalars[4] = (float)L1I; scalars[5] = (float)L1B;
+        scalars[6] = (float)(outer * 0.9 * rho / n);
+        scalars[7] = (float)(outer * 0.1 * (1.0 - rho) / (3.0 * n));
+    }
+}
+
+__global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
+    size_t HW, const float* __restrict__ image, const float* __restrict__ now, const float* __restrict__ next,
+    const float* __restrict__ gt_int, const float* __restrict__ gt_now, const float* __restrict__ gt_next,
+    const float* __restrict__ gt_blur, const float* __restrict__ c_ptr, float gt_c,
+    const float* __restrict__ scalars, float* __restrict__ d_image, float* __restrict__ d_now,
+    float* __restrict__ d_next) {
+    const float c = c_ptr[0];
+    const float kE = scalars[6], kI = scalars[7];
+    const float kB = 0.5f / (3.0f * (float)HW);
+    const float wch[3] = {0.4124f, 0.35758f, 0.1804f};
+    for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
+        float yn = lum3(next, HW, p) + 1e-8f, yo = lum3(now, HW, p) + 1e-8f;
+        float D = (__logf(yn) - __logf(yo)) / c;
+        float Dg = (__logf(lum3(gt_next, HW, p) + 1e-8f) - __logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
+        float e = D - Dg;
+        float k = kE * (float)((e > 0.0f) - (e < 0.0f)) / c;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            d_next[ch * HW + p] = k * wch[ch] / yn;
+            d_now[ch * HW + p] = -(k * wch[ch]) / yo;
+            float v = image[ch * HW + p];
+            float ei = v - gt_int[ch * HW + p];
+            float g = kI * (float)((ei > 0.0f) - (ei < 0.0f));
+            if (gt_blur) {
+                float eb = v - gt_blur[ch * HW + p];
+                g += kB * (float)((eb > 0.0f) - (eb < 0.0f));
+            }
+            d_image[ch * HW + p] = g;
+        }
+    }
+}
+
+static inline int ev_blocks(size_t HW) {
+    size_t b = (HW + EV_THREADS - 1) / EV_THREADS;
+    return (int)(b < 2048 ? b : 2048);
+}
+size_t e3_event_scratch_bytes(int W, int H) { return (size_t)ev_blocks((size_t)W * H) * EV_NSUM * sizeof(double) + 256; }
+
+int e3_event_loss_impl(int W, int H, const float* image, const float* now, const float* next, const float* gt_int,
+                       const float* gt_now, const float* gt_next, const float* gt_blur, const float* c, float gt_c,
+                       float* d_image, float* d_now, float* d_next, float* scalars, char* scratch, hipStream_t s) {
+    size_t HW = (size_t)W * H;
+    if (HW == 0) return 0;
+    int nb = ev_blocks(HW);
+    double* partials = reinterpret_cast<double*>(scratch);
+    event_reduce_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
+                                                              gt_c, partials);
+    event_finalize_kernel<<<dim3(1), dim3(WAVE), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars);
+    event_grad_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
+                                                            gt_c, scalars, d_image, d_now, d_next);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "event loss kernels");
+}
+
+// ------------------------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float step_size,
+                                                   float b1, float b2, float bc2_sqrt, float eps) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gi = g[i];
+        float mi = m[i] + (1.0f - b1) * (gi - m[i]);
+        float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                 int step, hipStream_t s) {
+    if (n == 0) return 0;
+    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    size_t nb = (n + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    adam_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, (float)(lr / bc1), b1, b2, (float)sqrt(bc2), eps);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "adam_kernel");
+}

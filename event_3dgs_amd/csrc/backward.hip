@@ -1,0 +1,391 @@
+// backward.hip -- gradient kernels (SURVEY 8a rows a19-a21, Appendix B [UPSTREAM]).
+//
+//   render_bwd_kernel  a19  one wave per tile, 4 pixels per lane, back-to-front walk over the same
+//                           sorted list; per list entry the 9 partial sums (mean2D 2, conic 3,
+//                           opacity 1, colour 3) are reduced across the wave with DPP adds and
+//                           committed with ONE atomic per value per (tile, Gaussian) -- instead of
+//                           the reference's one atomic per pixel per value.
+//   geom_bwd_kernel    a20+a21 fused: conic -> Sigma2 -> Sigma3 and view-space mean, NDC mean through
+//                           the projection, SH backward, Sigma3 -> scale / quaternion.
+#include "common.h"
+
+constexpr int BWD_WAVES = 4;
+
+__global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
+    int ntiles, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ recA, const float4* __restrict__ recB, const float* __restrict__ recC,
+    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D /*P,3*/, float* __restrict__ dL_dconic /*P,4*/,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor /*P,3*/) {
+    __shared__ float4 sA[BWD_WAVES][WAVE];
+    __shared__ float4 sB[BWD_WAVES][WAVE];
+    __shared__ float sC[BWD_WAVES][WAVE];
+    __shared__ uint32_t sId[BWD_WAVES][WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * BWD_WAVES + wave;
+    if (tile >= ntiles) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * E3_TILE + (lane & 15);
+    const int py0 = ty * E3_TILE + (lane >> 4);
+    const float pfx = (float)px;
+    const size_t HW = (size_t)H * W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    float pfy[4], T[4], Tfin[4], dp0[4], dp1[4], dp2[4], bgdot[4];
+    float acc0[4], acc1[4], acc2[4], lc0[4], lc1[4], lc2[4], last_alpha[4];
+    uint32_t last[4];
+    uint32_t maxc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int py = py0 + 4 * k;
+        pfy[k] = (float)py;
+        bool inside = (px < W) && (py < H);
+        size_t pix = (size_t)py * W + px;
+        Tfin[k] = inside ? final_T[pix] : 0.0f;
+        T[k] = Tfin[k];
+        last[k] = inside ? n_contrib[pix] : 0u;
+        dp0[k] = inside ? dL_dpix[pix] : 0.0f;
+        dp1[k] = inside ? dL_dpix[HW + pix] : 0.0f;
+        dp2[k] = inside ? dL_dpix[2 * HW + pix] : 0.0f;
+        bgdot[k] = FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
+        acc0[k] = acc1[k] = acc2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = 0.0f;
+        maxc = last[k] > maxc ? last[k] : maxc;
+    }
+    maxc = wave_max_u32(maxc);
+    const uint2 range = ranges[tile];
+    const int n = (int)maxc;   // entries [0, n) of the tile list can contribute
+
+    // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
+    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
+    float rc = 0.0f;
+    uint32_t rid = 0;
+    if (lane < n) {
+        rid = point_list[range.x + (uint32_t)(n - 1 - lane)];
+        ra = recA[rid]; rb = recB[rid]; rc = recC[rid];
+    }
+    for (int base = 0; base < n; base += WAVE) {
+        const int cnt = min(WAVE, n - base);
+        sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = rid;
+        wave_sync();
+        if (base + WAVE + lane < n) {
+            rid = point_list[range.x + (uint32_t)(n - 1 - (base + WAVE + lane))];
+            ra = recA[rid]; rb = recB[rid]; rc = recC[rid];
+        }
+        for (int j = 0; j < cnt; ++j) {
+            const float4 a = sA[wave][j];
+            const float4 b = sB[wave][j];
+            const float cb = sC[wave][j];
+            const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
+            const float dx = a.x - pfx;
+            const float cxdx = a.z * dx;
+            const float qx = cxdx * dx;
+            const float cydx = a.w * dx;
+            float g_mx = 0.0f, g_my = 0.0f, g_A = 0.0f, g_B = 0.0f, g_C = 0.0f, g_o = 0.0f, g_c0 = 0.0f, g_c1 = 0.0f,
+                  g_c2 = 0.0f;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = a.y - pfy[k];
+                const float q = FMA(b.x * dy, dy, qx);
+                const float power = FMA(-0.5f, q, -(cydx * dy));
+                const float G = exp_det(power);
+                const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
+                const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
+                if (valid) {
+                    any = true;
+                    const float one_m = 1.0f - alpha;
+                    T[k] = T[k] / one_m;
+                    const float dch = alpha * T[k];
+                    acc0[k] = FMA(last_alpha[k], lc0[k], (1.0f - last_alpha[k]) * acc0[k]);
+                    acc1[k] = FMA(last_alpha[k], lc1[k], (1.0f - last_alpha[k]) * acc1[k]);
+                    acc2[k] = FMA(last_alpha[k], lc2[k], (1.0f - last_alpha[k]) * acc2[k]);
+                    lc0[k] = b.z; lc1[k] = b.w; lc2[k] = cb;
+                    float dL_dalpha = (b.z - acc0[k]) * dp0[k];
+                    dL_dalpha = FMA(b.w - acc1[k], dp1[k], dL_dalpha);
+                    dL_dalpha = FMA(cb - acc2[k], dp2[k], dL_dalpha);
+                    g_c0 = FMA(dch, dp0[k], g_c0);
+                    g_c1 = FMA(dch, dp1[k], g_c1);
+                    g_c2 = FMA(dch, dp2[k], g_c2);
+                    dL_dalpha = dL_dalpha * T[k];
+                    last_alpha[k] = alpha;
+                    dL_dalpha = FMA(-Tfin[k] / one_m, bgdot[k], dL_dalpha);
+                    const float dL_dG = b.y * dL_dalpha;     // straight-through min(0.99, .)
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = FMA(-gdx, a.z, -(gdy * a.w));
+                    const float dG_ddely = FMA(-gdy, b.x, -(gdx * a.w));
+                    g_mx = FMA(dL_dG * dG_ddelx, ddelx_dx, g_mx);
+                    g_my = FMA(dL_dG * dG_ddely, ddely_dy, g_my);
+                    g_A = FMA(-0.5f * gdx * dx, dL_dG, g_A);
+                    g_B = FMA(-(gdx * dy), dL_dG, g_B);
+                    g_C = FMA(-0.5f * gdy * dy, dL_dG, g_C);
+                    g_o = FMA(G, dL_dalpha, g_o);
+                }
+            }
+            if (__any(any)) {
+                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
+                g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
+                g_o = wave_sum_to_lane63(g_o);
+                g_c0 = wave_sum_to_lane63(g_c0); g_c1 = wave_sum_to_lane63(g_c1); g_c2 = wave_sum_to_lane63(g_c2);
+                if (lane == 63) {
+                    const uint32_t id = sId[wave][j];
+                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], g_mx);
+                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], g_my);
+                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], g_A);
+                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], g_B);
+                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 2], g_C);
+                    unsafeAtomicAdd(&dL_dopacity[id], g_o);
+                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 0], g_c0);
+                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 1], g_c1);
+                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 2], g_c2);
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------ per-Gaussian backward
+__device__ __forceinline__ void sh_backward(int D, int M, const float* __restrict__ sh, float* __restrict__ dsh,
+                                            float mx, float my, float mz, const float* __restrict__ campos,
+                                            uint32_t clamped, const float gin[3], float gmean[3]) {
+    const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                         0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    float ox = mx - campos[0], oy = my - campos[1], oz = mz - campos[2];
+    float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+    float x = ox / len, y = oy / len, z = oz / len;
+    float g[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) g[ch] = ((clamped >> ch) & 1u) ? 0.0f : gin[ch];
+    float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
+    auto term = [&](int k, float Y, float Yx, float Yy, float Yz) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            dsh[k * 3 + ch] = Y * g[ch];
+            float s = sh[k * 3 + ch] * g[ch];
+            ddx = FMA(Yx, s, ddx); ddy = FMA(Yy, s, ddy); ddz = FMA(Yz, s, ddz);
+        }
+    };
+    term(0, SH_C0, 0.0f, 0.0f, 0.0f);
+    if (D > 0) {
+        term(1, -SH_C1 * y, 0.0f, -SH_C1, 0.0f);
+        term(2, SH_C1 * z, 0.0f, 0.0f, SH_C1);
+        term(3, -SH_C1 * x, -SH_C1, 0.0f, 0.0f);
+        if (D > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            term(4, C2[0] * xy, C2[0] * y, C2[0] * x, 0.0f);
+            term(5, C2[1] * yz, 0.0f, C2[1] * z, C2[1] * y);
+            term(6, C2[2] * (2.0f * zz - xx - yy), C2[2] * -2.0f * x, C2[2] * -2.0f * y, C2[2] * 4.0f * z);
+            term(7, C2[3] * xz, C2[3] * z, 0.0f, C2[3] * x);
+            term(8, C2[4] * (xx - yy), C2[4] * 2.0f * x, C2[4] * -2.0f * y, 0.0f);
+            if (D > 2) {
+                term(9, C3[0] * y * (3.0f * xx - yy), C3[0] * 6.0f * xy, C3[0] * (3.0f * xx - 3.0f * yy), 0.0f);
+                term(10, C3[1] * xy * z, C3[1] * yz, C3[1] * xz, C3[1] * xy);
+                term(11, C3[2] * y * (4.0f * zz - xx - yy), C3[2] * -2.0f * xy, C3[2] * (4.0f * zz - xx - 3.0f * yy),
+                     C3[2] * 8.0f * yz);
+                term(12, C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), C3[3] * -6.0f * xz, C3[3] * -6.0f * yz,
+                     C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+                term(13, C3[4] * x * (4.0f * zz - xx - yy), C3[4] * (4.0f * zz - 3.0f * xx - yy), C3[4] * -2.0f * xy,
+                     C3[4] * 8.0f * xz);
+                term(14, C3[5] * z * (xx - yy), C3[5] * 2.0f * xz, C3[5] * -2.0f * yz, C3[5] * (xx - yy));
+                term(15, C3[6] * x * (xx - 3.0f * yy), C3[6] * (3.0f * xx - 3.0f * yy), C3[6] * -6.0f * xy, 0.0f);
+            }
+        }
+    }
+    for (int k = (D + 1) * (D + 1); k < M; ++k) { dsh[k * 3] = 0.0f; dsh[k * 3 + 1] = 0.0f; dsh[k * 3 + 2] = 0.0f; }
+    float dot = x * ddx + y * ddy + z * ddz;
+    gmean[0] += (ddx - x * dot) / len;
+    gmean[1] += (ddy - y * dot) / len;
+    gmean[2] += (ddz - z * dot) / len;
+}
+
+__global__ __launch_bounds__(256) void geom_bwd_kernel(
+    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov_pre,
+    ViewParams vp, const int* __restrict__ radii, const uint32_t* __restrict__ clamped,
+    const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolor,
+    float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (radii[i] <= 0) return;   // all outputs pre-zeroed by the caller
+    const float* V = vp.view;
+    const float* Pm = vp.proj;
+    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float S[6];
+    if (cov_pre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
+    }
+    float qr = 0, qx = 0, qy = 0, qz = 0, s0 = 0, s1 = 0, s2 = 0;
+    float R[3][3];
+    if (!cov_pre) {
+        const float* q = rots + 4 * (size_t)i;
+        const float* s3 = scales + 3 * (size_t)i;
+        qr = q[0]; qx = q[1]; qy = q[2]; qz = q[3];
+        s0 = vp.scale_modifier * s3[0]; s1 = vp.scale_modifier * s3[1]; s2 = vp.scale_modifier * s3[2];
+        R[0][0] = 1.0f - 2.0f * FMA(qy, qy, qz * qz); R[0][1] = 2.0f * FMA(qx, qy, -(qr * qz)); R[0][2] = 2.0f * FMA(qx, qz, qr * qy);
+        R[1][0] = 2.0f * FMA(qx, qy, qr * qz); R[1][1] = 1.0f - 2.0f * FMA(qx, qx, qz * qz); R[1][2] = 2.0f * FMA(qy, qz, -(qr * qx));
+        R[2][0] = 2.0f * FMA(qx, qz, -(qr * qy)); R[2][1] = 2.0f * FMA(qy, qz, qr * qx); R[2][2] = 1.0f - 2.0f * FMA(qx, qx, qy * qy);
+        float L[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { L[a][0] = R[a][0] * s0; L[a][1] = R[a][1] * s1; L[a][2] = R[a][2] * s2; }
+        S[0] = FMA(L[0][0], L[0][0], FMA(L[0][1], L[0][1], L[0][2] * L[0][2]));
+        S[1] = FMA(L[0][0], L[1][0], FMA(L[0][1], L[1][1], L[0][2] * L[1][2]));
+        S[2] = FMA(L[0][0], L[2][0], FMA(L[0][1], L[2][1], L[0][2] * L[2][2]));
+        S[3] = FMA(L[1][0], L[1][0], FMA(L[1][1], L[1][1], L[1][2] * L[1][2]));
+        S[4] = FMA(L[1][0], L[2][0], FMA(L[1][1], L[2][1], L[1][2] * L[2][2]));
+        S[5] = FMA(L[2][0], L[2][0], FMA(L[2][1], L[2][1], L[2][2] * L[2][2]));
+    }
+    // ---- recompute the EWA intermediates
+    float vx = XFORM(V, 0, mx, my, mz), vy = XFORM(V, 1, mx, my, mz), vz = XFORM(V, 2, mx, my, mz);
+    float limx = E3_GUARD_BAND * vp.tanfovx, limy = E3_GUARD_BAND * vp.tanfovy;
+    float txtz = vx / vz, tytz = vy / vz;
+    float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+    float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+    float tz = vz;
+    float xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    float ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    float J00 = vp.focal_x / tz, J02 = -(vp.focal_x * tx) / (tz * tz);
+    float J11 = vp.focal_y / tz, J12 = -(vp.focal_y * ty) / (tz * tz);
+    float T00 = FMA(J00, V[0], J02 * V[2]), T01 = FMA(J00, V[4], J02 * V[6]), T02 = FMA(J00, V[8], J02 * V[10]);
+    float T10 = FMA(J11, V[1], J12 * V[2]), T11 = FMA(J11, V[5], J12 * V[6]), T12 = FMA(J11, V[9], J12 * V[10]);
+    float u0 = FMA(S[0], T00, FMA(S[1], T01, S[2] * T02));
+    float u1 = FMA(S[1], T00, FMA(S[3], T01, S[4] * T02));
+    float u2 = FMA(S[2], T00, FMA(S[4], T01, S[5] * T02));
+    float w0 = FMA(S[0], T10, FMA(S[1], T11, S[2] * T12));
+    float w1 = FMA(S[1], T10, FMA(S[3], T11, S[4] * T12));
+    float w2 = FMA(S[2], T10, FMA(S[4], T11, S[5] * T12));
+    float a = FMA(T00, u0, FMA(T01, u1, T02 * u2)) + E3_DILATION;
+    float b = FMA(T10, u0, FMA(T11, u1, T12 * u2));
+    float c = FMA(T10, w0, FMA(T11, w1, T12 * w2)) + E3_DILATION;
+    // ---- conic -> (a,b,c)
+    float gA = dL_dconic[4 * (size_t)i], gB = dL_dconic[4 * (size_t)i + 1], gC = dL_dconic[4 * (size_t)i + 2];
+    float det = a * c - b * b;
+    float d2inv = 1.0f / (det * det + E3_DET2_EPS);
+    float g_a = 0.0f, g_b = 0.0f, g_c = 0.0f;
+    if (det != 0.0f) {
+        g_a = d2inv * (-c * c * gA + b * c * gB - b * b * gC);
+        g_c = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
+        g_b = d2inv * (2.0f * b * c * gA - (a * c + b * b) * gB + 2.0f * a * b * gC);
+    }
+    float gcov[6];
+    gcov[0] = T00 * T00 * g_a + T00 * T10 * g_b + T10 * T10 * g_c;
+    gcov[3] = T01 * T01 * g_a + T01 * T11 * g_b + T11 * T11 * g_c;
+    gcov[5] = T02 * T02 * g_a + T02 * T12 * g_b + T12 * T12 * g_c;
+    gcov[1] = 2.0f * T00 * T01 * g_a + (T00 * T11 + T01 * T10) * g_b + 2.0f * T10 * T11 * g_c;
+    gcov[2] = 2.0f * T00 * T02 * g_a + (T00 * T12 + T02 * T10) * g_b + 2.0f * T10 * T12 * g_c;
+    gcov[4] = 2.0f * T02 * T01 * g_a + (T01 * T12 + T02 * T11) * g_b + 2.0f * T11 * T12 * g_c;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = gcov[k];
+    float gT00 = 2.0f * g_a * u0 + g_b * w0, gT01 = 2.0f * g_a * u1 + g_b * w1, gT02 = 2.0f * g_a * u2 + g_b * w2;
+    float gT10 = 2.0f * g_c * w0 + g_b * u0, gT11 = 2.0f * g_c * w1 + g_b * u1, gT12 = 2.0f * g_c * w2 + g_b * u2;
+    float gJ00 = V[0] * gT00 + V[4] * gT01 + V[8] * gT02;
+    float gJ02 = V[2] * gT00 + V[6] * gT01 + V[10] * gT02;
+    float gJ11 = V[1] * gT10 + V[5] * gT11 + V[9] * gT12;
+    float gJ12 = V[2] * gT10 + V[6] * gT11 + V[10] * gT12;
+    float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    float gtx = xmul * (-vp.focal_x * itz2 * gJ02);
+    float gty = ymul * (-vp.focal_y * itz2 * gJ12);
+    float gtz = -vp.focal_x * itz2 * gJ00 - vp.focal_y * itz2 * gJ11 + (2.0f * vp.focal_x * tx) * itz3 * gJ02 +
+                (2.0f * vp.focal_y * ty) * itz3 * gJ12;
+    float gmean[3];
+    gmean[0] = V[0] * gtx + V[1] * gty + V[2] * gtz;
+    gmean[1] = V[4] * gtx + V[5] * gty + V[6] * gtz;
+    gmean[2] = V[8] * gtx + V[9] * gty + V[10] * gtz;
+    // ---- NDC mean gradient through the projection
+    float gm2x = dL_dmean2D[3 * (size_t)i], gm2y = dL_dmean2D[3 * (size_t)i + 1];
+    float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
+    float pw = 1.0f / (hw + E3_W_EPS);
+    float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
+    gmean[0] += (Pm[0] * pw - Pm[3] * mul1) * gm2x + (Pm[1] * pw - Pm[3] * mul2) * gm2y;
+    gmean[1] += (Pm[4] * pw - Pm[7] * mul1) * gm2x + (Pm[5] * pw - Pm[7] * mul2) * gm2y;
+    gmean[2] += (Pm[8] * pw - Pm[11] * mul1) * gm2x + (Pm[9] * pw - Pm[11] * mul2) * gm2y;
+    if (shs) {
+        float gcol[3] = {dL_dcolor[3 * (size_t)i], dL_dcolor[3 * (size_t)i + 1], dL_dcolor[3 * (size_t)i + 2]};
+        sh_backward(D, M, shs + (size_t)i * M * 3, dL_dsh + (size_t)i * M * 3, mx, my, mz, vp.campos, clamped[i], gcol,
+                    gmean);
+    }
+    dL_dmean3D[3 * (size_t)i] = gmean[0];
+    dL_dmean3D[3 * (size_t)i + 1] = gmean[1];
+    dL_dmean3D[3 * (size_t)i + 2] = gmean[2];
+    // ---- Sigma3 = (R diag s)(R diag s)^T
+    if (!cov_pre) {
+        const float s[3] = {s0, s1, s2};
+        const float Gs[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                                {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                                {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+        float dR[3][3];
+        float ds[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float dl = 2.0f * (Gs[r][0] * (R[0][j] * s[j]) + Gs[r][1] * (R[1][j] * s[j]) + Gs[r][2] * (R[2][j] * s[j]));
+                t += R[r][j] * dl;
+                dR[r][j] = s[j] * dl;
+            }
+            ds[j] = vp.scale_modifier * t;
+        }
+        dL_dscale[3 * (size_t)i] = ds[0]; dL_dscale[3 * (size_t)i + 1] = ds[1]; dL_dscale[3 * (size_t)i + 2] = ds[2];
+        dL_drot[4 * (size_t)i + 0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        dL_drot[4 * (size_t)i + 1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - qr * dR[1][2] + qz * dR[2][0] + qr * dR[2][1] - 2.0f * qx * dR[2][2]);
+        dL_drot[4 * (size_t)i + 2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - qr * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
+        dL_drot[4 * (size_t)i + 3] = 2.0f * (-2.0f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ host driver
+int e3_fail(hipError_t e, const char* what);
+#define KERNEL_OK(name)                                       \
+    do {                                                      \
+        hipError_t _e = hipGetLastError();                    \
+        if (_e != hipSuccess) return e3_fail(_e, name);       \
+        if (debug) {                                          \
+            _e = hipStreamSynchronize(s);                     \
+            if (_e != hipSuccess) return e3_fail(_e, name);   \
+        }                                                     \
+    } while (0)
+
+int e3_backward_impl(int P, int D, int M, int num_rendered, const float* background, int W, int H,
+                     const float* means3D, const float* shs, const float* colors, const float* scales,
+                     float scale_modifier, const float* rots, const float* cov_pre, const float* view,
+                     const float* proj, const float* campos, float tanfovx, float tanfovy, const int* radii,
+                     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                     const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                     hipStream_t s) {
+    (void)colors;
+    if (P <= 0) return 0;
+    ViewParams vp;
+    vp.view = view; vp.proj = proj; vp.campos = campos;
+    vp.tanfovx = tanfovx; vp.tanfovy = tanfovy;
+    vp.focal_x = (float)W / (2.0f * tanfovx);
+    vp.focal_y = (float)H / (2.0f * tanfovy);
+    vp.scale_modifier = scale_modifier;
+    vp.W = W; vp.H = H;
+    vp.gx = (W + E3_TILE - 1) / E3_TILE;
+    vp.gy = (H + E3_TILE - 1) / E3_TILE;
+    const int ntiles = vp.gx * vp.gy;
+    char* gp = const_cast<char*>(geom_buffer);
+    char* bp = const_cast<char*>(binning_buffer);
+    char* ip = const_cast<char*>(image_buffer);
+    GeomState geom = GeomState::from(gp, P);
+    BinningState bin = BinningState::from(bp, (size_t)num_rendered);
+    ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
+    if (num_rendered > 0) {
+        render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+            ntiles, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
+            img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+        KERNEL_OK("render_bwd_kernel");
+    }
+    geom_bwd_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, D, M, means3D, shs, scales, rots, cov_pre, vp, radii,
+                                                               geom.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
+                                                               dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    KERNEL_OK("geom_bwd_kernel");
+    return 0;
+}

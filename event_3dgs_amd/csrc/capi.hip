@@ -1,0 +1,121 @@
+// capi.hip -- the extern "C" boundary declared in include/e3dgs_hip.h.
+#include "common.h"
+#include "../../include/e3dgs_hip.h"
+#include <stdio.h>
+#include <string.h>
+
+thread_local char g_err[512] = "";
+
+int e3_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof g_err, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+    return e == hipSuccess ? -1 : (int)e;
+}
+
+int e3_forward_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*,
+                    int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
+                    const float*, float, const float*, const float*, const float*, const float*, const float*, float,
+                    float, int, float*, int*, int, int*, hipStream_t);
+int e3_backward_impl(int, int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
+                     float, const float*, const float*, const float*, const float*, const float*, float, float,
+                     const int*, const char*, const char*, const char*, const float*, float*, float*, float*, float*,
+                     float*, float*, float*, float*, float*, int, hipStream_t);
+int e3_mark_visible_impl(int, const float*, const float*, uint8_t*, hipStream_t);
+size_t e3_knn_scratch_bytes(int);
+int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
+size_t e3_event_scratch_bytes(int, int);
+int e3_event_loss_impl(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
+                       const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
+int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, hipStream_t);
+
+extern "C" {
+
+int e3dgs_abi_version(void) { return 1; }
+const char* e3dgs_last_error(void) { return g_err; }
+
+int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
+                            void* binning_user, e3dgs_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                            float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                            int* num_rendered_host, void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || width <= 0 || height <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
+    if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
+        return e3_fail(hipErrorInvalidValue, "provide exactly one of shs / colors_precomp");
+    if (((scales == nullptr || rotations == nullptr) == (cov3D_precomp == nullptr)) && P > 0)
+        return e3_fail(hipErrorInvalidValue, "provide exactly one of scales+rotations / cov3D_precomp");
+    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1)))
+        return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
+    if ((width + 15) / 16 > 65535 || (height + 15) / 16 > 65535)
+        return e3_fail(hipErrorInvalidValue, "image too large for 16-bit tile coordinates");
+    return e3_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
+                           background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                           rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                           out_color, radii, debug, num_rendered_host, (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
+                             const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                             float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                             const char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                             float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                             float* dL_dscale, float* dL_drot, int debug, void* stream) {
+    g_err[0] = 0;
+    if (shs && !dL_dsh) return e3_fail(hipErrorInvalidValue, "dL_dsh required when shs is given");
+    if (!cov3D_precomp && (!dL_dscale || !dL_drot))
+        return e3_fail(hipErrorInvalidValue, "dL_dscale/dL_drot required when scales+rotations are given");
+    return e3_backward_impl(P, D, M, num_rendered, background, width, height, means3D, shs, colors_precomp, scales,
+                            scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                            tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
+                            (hipStream_t)stream);
+}
+
+void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9) {
+    char* p = nullptr;
+    GeomState g = GeomState::from(p, (size_t)(P > 0 ? P : 0));
+    out9[0] = (size_t)g.recA; out9[1] = (size_t)g.recB; out9[2] = (size_t)g.recC; out9[3] = (size_t)g.clamped;
+    out9[4] = (size_t)g.rect;
+    p = nullptr;
+    BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
+    out9[5] = (size_t)b.point_list;
+    p = nullptr;
+    int gx = (width + E3_TILE - 1) / E3_TILE, gy = (height + E3_TILE - 1) / E3_TILE;
+    ImageState im = ImageState::from(p, (size_t)width * height, (size_t)gx * gy);
+    out9[6] = (size_t)im.ranges; out9[7] = (size_t)im.final_T; out9[8] = (size_t)im.n_contrib;
+}
+
+int e3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                       void* stream) {
+    (void)projmatrix;
+    g_err[0] = 0;
+    return e3_mark_visible_impl(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+size_t e3dgs_knn_scratch_bytes(int P) { return e3_knn_scratch_bytes(P); }
+int e3dgs_dist_knn3(int P, const float* points, float* out, char* scratch, void* stream) {
+    g_err[0] = 0;
+    return e3_knn_impl(P, points, out, scratch, (hipStream_t)stream);
+}
+
+size_t e3dgs_event_loss_scratch_bytes(int width, int height) { return e3_event_scratch_bytes(width, height); }
+int e3dgs_event_loss(int width, int height, const float* image, const float* img_now, const float* img_next,
+                     const float* gt_int, const float* gt_now, const float* gt_next, const float* gt_blur,
+                     const float* c, float gt_c, float* d_image, float* d_now, float* d_next, float* scalars_out,
+                     char* scratch, void* stream) {
+    g_err[0] = 0;
+    return e3_event_loss_impl(width, height, image, img_now, img_next, gt_int, gt_now, gt_next, gt_blur, c, gt_c,
+                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream);
+}
+
+int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                    float beta1, float beta2, float eps, int step, void* stream) {
+    g_err[0] = 0;
+    return e3_adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// common.h -- shared device helpers and scratch-buffer layouts (gfx950 / wave64 only).
+//
+// Arithmetic contract: this library is compiled with -ffp-contract=off; every fused
+// multiply-add is an explicit FMA().  The forward kernels follow the operation order
+// documented in DESIGN.md ("Arithmetic contract") so that integer outputs (radii, tile
+// rectangles, sorted lists, n_contrib) and the fp32 image are reproducible bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define E3_TILE 16
+#define E3_NEAR_CULL_Z 0.2f
+#define E3_GUARD_BAND 1.3f
+#define E3_DILATION 0.3f
+#define E3_EIGEN_FLOOR 0.1f
+#define E3_ALPHA_CLAMP 0.99f
+#define E3_ALPHA_SKIP (1.0f / 255.0f)
+#define E3_T_STOP 0.0001f
+#define E3_W_EPS 0.0000001f
+#define E3_DET2_EPS 0.0000001f
+
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define WAVE 64
+
+__device__ __forceinline__ float exp_det(float x) {
+    // 2^(x*log2e), degree-5 polynomial on the fractional part; v_rndne + v_ldexp.
+    float t = fmaxf(x * 1.4426950408889634f, -126.0f);
+    float n = __builtin_rintf(t);
+    float f = t - n;
+    float p = 0.0013218672247603536f;
+    p = FMA(p, f, 0.009671698324382305f);
+    p = FMA(p, f, 0.05550893023610115f);
+    p = FMA(p, f, 0.24022237956523895f);
+    p = FMA(p, f, 0.6931468844413757f);
+    p = FMA(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+// flat[4*c + r]: row r of the column-vector matrix applied to (x,y,z,1)
+#define XFORM(M, r, x, y, z) FMA((M)[(r)], (x), FMA((M)[4 + (r)], (y), FMA((M)[8 + (r)], (z), (M)[12 + (r)])))
+
+// Sum over the 64 lanes of a wave with DPP adds; the total lands in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false);  v += __int_as_float(x);  // quad_perm [1,0,3,2]
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false);  v += __int_as_float(x);  // quad_perm [2,3,0,1]
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false); v += __int_as_float(x);  // row_half_mirror
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false); v += __int_as_float(x);  // row_mirror
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false); v += __int_as_float(x);  // row_bcast:15 -> rows 1,3
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false); v += __int_as_float(x);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_xor(v, o, 64);
+        v = v > t ? v : t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void wave_sync() {
+    // Same-wave LDS hand-off: lanes run in lockstep and DS ops retire in order, so only
+    // the compiler has to be kept from reordering across this point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static inline T* carve(char*& p, size_t count) {
+    T* r = reinterpret_cast<T*>(p);
+    p += align_up(count * sizeof(T), 256);
+    return r;
+}
+
+// ---------------------------------------------------------------- radix sort / scan
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;                       // keys per thread
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+static inline size_t sort_blocks(size_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+static inline size_t scan_blocks(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+// scratch (in uint32) needed to sort n pairs: per-block digit histograms + scan block sums
+static inline size_t sort_scratch_words(size_t n) {
+    size_t h = sort_blocks(n) * 256;
+    return h + scan_blocks(h) + 64;
+}
+
+// ---------------------------------------------------------------- scratch layouts
+// geometry state: everything sized by P.  The first five members are what backward reads.
+struct GeomState {
+    float4* recA;      // (x, y, conic.x, conic.y)
+    float4* recB;      // (conic.z, opacity, r, g)
+    float* recC;       // b
+    uint32_t* clamped; // SH clamp bitmask (bit ch)
+    uint2* rect;       // packed tile rectangle: .x = xmin | ymin<<16, .y = xmax | ymax<<16
+    uint32_t* key0;    // depth keys (ping)
+    uint32_t* key1;    // (pong)
+    uint32_t* ord0;    // Gaussian ids (ping)
+    uint32_t* ord1;    // (pong)
+    uint32_t* tiles;   // tiles touched, in depth-sorted order
+    uint32_t* offsets; // inclusive scan of `tiles`
+    uint32_t* scratch; // sort/scan scratch
+    uint32_t* total;   // [1] instance count (device copy)
+    static size_t required(size_t P) {
+        char* p = nullptr;
+        from(p, P);
+        return (size_t)p + 256;
+    }
+    static GeomState from(char*& p, size_t P) {
+        GeomState g;
+        size_t n = P ? P : 1;
+        g.recA = carve<float4>(p, n);
+        g.recB = carve<float4>(p, n);
+        g.recC = carve<float>(p, n);
+        g.clamped = carve<uint32_t>(p, n);
+        g.rect = carve<uint2>(p, n);
+        g.key0 = carve<uint32_t>(p, n);
+        g.key1 = carve<uint32_t>(p, n);
+        g.ord0 = carve<uint32_t>(p, n);
+        g.ord1 = carve<uint32_t>(p, n);
+        g.tiles = carve<uint32_t>(p, n);
+        g.offsets = carve<uint32_t>(p, n);
+        g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_blocks(n) + 64);
+        g.total = carve<uint32_t>(p, 64);
+        return g;
+    }
+};
+
+// binning state: everything sized by the instance count I.  point_list is first (backward reads it).
+struct BinningState {
+    uint32_t* point_list; // final sorted Gaussian ids
+    uint32_t* vals_alt;
+    uint32_t* keys;       // tile ids
+    uint32_t* keys_alt;
+    uint32_t* scratch;
+    static size_t required(size_t I) {
+        char* p = nullptr;
+        from(p, I);
+        return (size_t)p + 256;
+    }
+    static BinningState from(char*& p, size_t I) {
+        BinningState b;
+        size_t n = I ? I : 1;
+        b.point_list = carve<uint32_t>(p, n);
+        b.vals_alt = carve<uint32_t>(p, n);
+        b.keys = carve<uint32_t>(p, n);
+        b.keys_alt = carve<uint32_t>(p, n);
+        b.scratch = carve<uint32_t>(p, sort_scratch_words(n));
+        return b;
+    }
+};
+
+struct ImageState {
+    uint2* ranges;       // per tile [start, end) into point_list
+    float* final_T;      // per pixel
+    uint32_t* n_contrib; // per pixel
+    static size_t required(size_t npix, size_t ntiles) {
+        char* p = nullptr;
+        from(p, npix, ntiles);
+        return (size_t)p + 256;
+    }
+    static ImageState from(char*& p, size_t npix, size_t ntiles) {
+        ImageState s;
+        s.ranges = carve<uint2>(p, ntiles ? ntiles : 1);
+        s.final_T = carve<float>(p, npix ? npix : 1);
+        s.n_contrib = carve<uint32_t>(p, npix ? npix : 1);
+        return s;
+    }
+};
+
+// per-view constants: matrices stay on the device (they arrive as torch tensors), scalars by value
+struct ViewParams {
+    const float* view;   // 16, row-vector layout
+    const float* proj;   // 16
+    const float* campos; // 3
+    float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+    int W, H, gx, gy;
+};
+
+// launchers implemented in scan_sort.hip
+void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
+                               hipStream_t s);
+// Stable LSD radix sort of (key,val) u32 pairs on bits [0,nbits).  Result is returned in
+// (*keys_out,*vals_out) which are one of the two provided buffer pairs.
+void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
+                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
+static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }

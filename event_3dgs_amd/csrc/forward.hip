@@ -1,0 +1,426 @@
+// forward.hip -- forward rasterisation kernels (preprocess, binning, compositing).
+//
+// Re-creates, MI355X-first, the forward half of the reference's absent CUDA op
+// (SURVEY 2.1 / 8a rows a13-a18 [UPSTREAM]; call site gaussian_renderer/__init__.py:89-97):
+//
+//   preprocess_kernel     a13   cull, project, Sigma3, EWA Sigma2, conic, radius, tile rect, colour
+//   (radix sort A)        ---   visible Gaussians by fp32 depth bits (stable -> ties keep index order)
+//   gather_tiles_kernel   a14   tiles touched in depth order (then inclusive scan -> offsets, I)
+//   emit_kernel           a15   (tile id, Gaussian id) instances, already depth-ordered
+//   (radix sort B)        a16   stable sort by tile id only (ceil(log2 T) bits, 2 passes at 1080p)
+//   tile_ranges_kernel    a17   [start,end) of each tile
+//   render_fwd_kernel     a18   ONE WAVE PER 16x16 TILE, 4 pixels per lane, no workgroup barriers
+//
+// The two-level sort (depth on P Gaussians, then tile on I instances) yields exactly the order
+// of the reference's single 64-bit (tile<<32 | depth) stable sort with 6x less sort traffic.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ SH colour
+__device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, float mx, float my, float mz,
+                                          const float* __restrict__ campos, float rgb[3], uint32_t& clamped) {
+    const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+    const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
+                C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+    const float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f,
+                C33 = 0.3731763325901154f, C34 = -0.4570457994644658f, C35 = 1.445305721320277f,
+                C36 = -0.5900435899266435f;
+    float dx = mx - campos[0], dy = my - campos[1], dz = mz - campos[2];
+    float len = __builtin_sqrtf(FMA(dx, dx, FMA(dy, dy, dz * dz)));
+    float x = dx / len, y = dy / len, z = dz / len;
+    clamped = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float r = SH_C0 * sh[0 * 3 + ch];
+        if (D > 0) {
+            r = FMA(-(SH_C1 * y), sh[1 * 3 + ch], r);
+            r = FMA(SH_C1 * z, sh[2 * 3 + ch], r);
+            r = FMA(-(SH_C1 * x), sh[3 * 3 + ch], r);
+            if (D > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = FMA(C20 * xy, sh[4 * 3 + ch], r);
+                r = FMA(C21 * yz, sh[5 * 3 + ch], r);
+                r = FMA(C22 * (FMA(2.0f, zz, -xx) - yy), sh[6 * 3 + ch], r);
+                r = FMA(C23 * xz, sh[7 * 3 + ch], r);
+                r = FMA(C24 * (xx - yy), sh[8 * 3 + ch], r);
+                if (D > 2) {
+                    r = FMA(C30 * y * FMA(3.0f, xx, -yy), sh[9 * 3 + ch], r);
+                    r = FMA(C31 * xy * z, sh[10 * 3 + ch], r);
+                    r = FMA(C32 * y * (FMA(4.0f, zz, -xx) - yy), sh[11 * 3 + ch], r);
+                    r = FMA(C33 * z * (FMA(2.0f, zz, -(3.0f * xx)) - 3.0f * yy), sh[12 * 3 + ch], r);
+                    r = FMA(C34 * x * (FMA(4.0f, zz, -xx) - yy), sh[13 * 3 + ch], r);
+                    r = FMA(C35 * z * (xx - yy), sh[14 * 3 + ch], r);
+                    r = FMA(C36 * x * FMA(-3.0f, yy, xx), sh[15 * 3 + ch], r);
+                }
+            }
+        }
+        r = r + 0.5f;
+        if (r < 0.0f) clamped |= (1u << ch);
+        rgb[ch] = fmaxf(r, 0.0f);
+    }
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s3, float mod,
+                                                     const float* __restrict__ q, float cov[6]) {
+    float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    float R00 = 1.0f - 2.0f * FMA(y, y, z * z), R01 = 2.0f * FMA(x, y, -(r * z)), R02 = 2.0f * FMA(x, z, r * y);
+    float R10 = 2.0f * FMA(x, y, r * z), R11 = 1.0f - 2.0f * FMA(x, x, z * z), R12 = 2.0f * FMA(y, z, -(r * x));
+    float R20 = 2.0f * FMA(x, z, -(r * y)), R21 = 2.0f * FMA(y, z, r * x), R22 = 1.0f - 2.0f * FMA(x, x, y * y);
+    float L00 = R00 * sx, L01 = R01 * sy, L02 = R02 * sz;
+    float L10 = R10 * sx, L11 = R11 * sy, L12 = R12 * sz;
+    float L20 = R20 * sx, L21 = R21 * sy, L22 = R22 * sz;
+    cov[0] = FMA(L00, L00, FMA(L01, L01, L02 * L02));
+    cov[1] = FMA(L00, L10, FMA(L01, L11, L02 * L12));
+    cov[2] = FMA(L00, L20, FMA(L01, L21, L02 * L22));
+    cov[3] = FMA(L10, L10, FMA(L11, L11, L12 * L12));
+    cov[4] = FMA(L10, L20, FMA(L11, L21, L12 * L22));
+    cov[5] = FMA(L20, L20, FMA(L21, L21, L22 * L22));
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ------------------------------------------------------------------------------------ preprocess
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
+    const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
+    const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewParams vp, int* __restrict__ radii,
+    float4* __restrict__ recA, float4* __restrict__ recB, float* __restrict__ recC, uint32_t* __restrict__ clamped,
+    uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* V = vp.view;
+    const float* Pm = vp.proj;
+    int radius_out = 0;
+    uint2 rect_out = make_uint2(0u, 0u);
+    uint32_t key_out = 0xFFFFFFFFu;
+    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float vx = XFORM(V, 0, mx, my, mz), vy = XFORM(V, 1, mx, my, mz), vz = XFORM(V, 2, mx, my, mz);
+    if (vz > E3_NEAR_CULL_Z) {
+        float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
+        float pw = 1.0f / (hw + E3_W_EPS);
+        float ndcx = hx * pw, ndcy = hy * pw;
+        float S[6];
+        if (cov_pre) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
+        } else {
+            cov3d_from_scale_rot(scales + 3 * (size_t)i, vp.scale_modifier, rots + 4 * (size_t)i, S);
+        }
+        // EWA: T = J * Wr, Sigma2 = T Sigma3 T^T
+        float limx = E3_GUARD_BAND * vp.tanfovx, limy = E3_GUARD_BAND * vp.tanfovy;
+        float txtz = vx / vz, tytz = vy / vz;
+        float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        float tz = vz;
+        float J00 = vp.focal_x / tz, J02 = -(vp.focal_x * tx) / (tz * tz);
+        float J11 = vp.focal_y / tz, J12 = -(vp.focal_y * ty) / (tz * tz);
+        float T00 = FMA(J00, V[0], J02 * V[2]), T01 = FMA(J00, V[4], J02 * V[6]), T02 = FMA(J00, V[8], J02 * V[10]);
+        float T10 = FMA(J11, V[1], J12 * V[2]), T11 = FMA(J11, V[5], J12 * V[6]), T12 = FMA(J11, V[9], J12 * V[10]);
+        float u0 = FMA(S[0], T00, FMA(S[1], T01, S[2] * T02));
+        float u1 = FMA(S[1], T00, FMA(S[3], T01, S[4] * T02));
+        float u2 = FMA(S[2], T00, FMA(S[4], T01, S[5] * T02));
+        float w0 = FMA(S[0], T10, FMA(S[1], T11, S[2] * T12));
+        float w1 = FMA(S[1], T10, FMA(S[3], T11, S[4] * T12));
+        float w2 = FMA(S[2], T10, FMA(S[4], T11, S[5] * T12));
+        float a = FMA(T00, u0, FMA(T01, u1, T02 * u2));
+        float b = FMA(T10, u0, FMA(T11, u1, T12 * u2));
+        float c = FMA(T10, w0, FMA(T11, w1, T12 * w2));
+        a = a + E3_DILATION;
+        c = c + E3_DILATION;
+        float det = FMA(a, c, -(b * b));
+        if (det != 0.0f) {
+            float det_inv = 1.0f / det;
+            float conx = c * det_inv, cony = -b * det_inv, conz = a * det_inv;
+            float mid = 0.5f * (a + c);
+            float disc = __builtin_sqrtf(fmaxf(E3_EIGEN_FLOOR, FMA(mid, mid, -det)));
+            float lam1 = mid + disc, lam2 = mid - disc;
+            int radius = (int)__builtin_ceilf(3.0f * __builtin_sqrtf(fmaxf(lam1, lam2)));
+            // ndc2Pix in double, single final rounding (gaussian_renderer/__init__.py:238-241)
+            float px = (float)((((double)ndcx + 1.0) * (double)vp.W - 1.0) * 0.5);
+            float py = (float)((((double)ndcy + 1.0) * (double)vp.H - 1.0) * 0.5);
+            float fr = (float)radius;
+            int xmin = clampi((int)((px - fr) / (float)E3_TILE), 0, vp.gx);
+            int ymin = clampi((int)((py - fr) / (float)E3_TILE), 0, vp.gy);
+            int xmax = clampi((int)((((px + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gx);
+            int ymax = clampi((int)((((py + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gy);
+            if ((xmax - xmin) * (ymax - ymin) != 0) {
+                float rgb[3];
+                uint32_t cl = 0;
+                if (shs) {
+                    sh_to_rgb(D, shs + (size_t)i * M * 3, mx, my, mz, vp.campos, rgb, cl);
+                } else {
+                    rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
+                }
+                recA[i] = make_float4(px, py, conx, cony);
+                recB[i] = make_float4(conz, opac[i], rgb[0], rgb[1]);
+                recC[i] = rgb[2];
+                clamped[i] = cl;
+                radius_out = radius;
+                rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
+                key_out = __float_as_uint(vz);
+            }
+        }
+    }
+    radii[i] = radius_out;
+    rect[i] = rect_out;
+    key[i] = key_out;
+    ord[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ uint32_t rect_area(uint2 r) {
+    uint32_t w = (r.y & 0xFFFFu) - (r.x & 0xFFFFu), h = (r.y >> 16) - (r.x >> 16);
+    return w * h;
+}
+
+__global__ __launch_bounds__(256) void gather_tiles_kernel(int P, const uint32_t* __restrict__ order,
+                                                           const uint2* __restrict__ rect,
+                                                           uint32_t* __restrict__ tiles) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P) return;
+    tiles[s] = rect_area(rect[order[s]]);
+}
+
+// one thread per depth-sorted Gaussian; row-major over its tile rectangle (y outer, x inner)
+__global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __restrict__ order,
+                                                   const uint2* __restrict__ rect,
+                                                   const uint32_t* __restrict__ offsets, int gx,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P) return;
+    uint32_t g = order[s];
+    uint2 r = rect[g];
+    uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu, ymax = r.y >> 16;
+    if (xmax == xmin || ymax == ymin) return;
+    uint32_t off = s == 0 ? 0u : offsets[s - 1];
+    for (uint32_t y = ymin; y < ymax; ++y)
+        for (uint32_t x = xmin; x < xmax; ++x) {
+            keys[off] = y * (uint32_t)gx + x;
+            vals[off] = g;
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint32_t* __restrict__ keys,
+                                                          uint2* __restrict__ ranges) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    uint32_t t = keys[i];
+    if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
+    if (i == I - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
+}
+
+// ------------------------------------------------------------------------------------ compositing
+// One wave per 16x16 tile.  Lane l owns column (l & 15) and rows (l >> 4) + 4k, k = 0..3, so the
+// x-dependent half of the quadratic form is shared by its four pixels.  Each round the wave
+// gathers 64 list entries (one per lane) into its private LDS slice and every lane then walks
+// them with broadcast ds_read_b128; the next round's gathers are in flight meanwhile.
+constexpr int RENDER_WAVES = 4;
+
+__global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
+    int ntiles, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ recA, const float4* __restrict__ recB, const float* __restrict__ recC,
+    const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 sA[RENDER_WAVES][WAVE];
+    __shared__ float4 sB[RENDER_WAVES][WAVE];
+    __shared__ float sC[RENDER_WAVES][WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * RENDER_WAVES + wave;
+    if (tile >= ntiles) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * E3_TILE + (lane & 15);
+    const int py0 = ty * E3_TILE + (lane >> 4);
+    const float pfx = (float)px;
+    float pfy[4], T[4], C0[4], C1[4], C2[4];
+    uint32_t last[4];
+    bool done[4], inside[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int py = py0 + 4 * k;
+        pfy[k] = (float)py;
+        inside[k] = (px < W) && (py < H);
+        done[k] = !inside[k];
+        T[k] = 1.0f; C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
+    }
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
+    float rc = 0.0f;
+    if (lane < n) {
+        uint32_t id = point_list[range.x + lane];
+        ra = recA[id]; rb = recB[id]; rc = recC[id];
+    }
+    for (int base = 0; base < n; base += WAVE) {
+        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        const int cnt = min(WAVE, n - base);
+        sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
+        wave_sync();
+        if (base + WAVE + lane < n) {
+            uint32_t id = point_list[range.x + base + WAVE + lane];
+            ra = recA[id]; rb = recB[id]; rc = recC[id];
+        }
+        for (int j = 0; j < cnt; ++j) {
+            const float4 a = sA[wave][j];
+            const float4 b = sB[wave][j];
+            const float cb = sC[wave][j];
+            const uint32_t contributor = (uint32_t)(base + j + 1);
+            const float dx = a.x - pfx;
+            const float cxdx = a.z * dx;
+            const float qx = cxdx * dx;
+            const float cydx = a.w * dx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = a.y - pfy[k];
+                const float q = FMA(b.x * dy, dy, qx);
+                const float power = FMA(-0.5f, q, -(cydx * dy));
+                const float G = exp_det(power);
+                const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
+                const bool valid = !done[k] && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
+                const float test_T = T[k] * (1.0f - alpha);
+                const bool stop = valid && (test_T < E3_T_STOP);
+                const bool apply = valid && !stop;
+                const float w = alpha * T[k];
+                C0[k] = apply ? FMA(b.z, w, C0[k]) : C0[k];
+                C1[k] = apply ? FMA(b.w, w, C1[k]) : C1[k];
+                C2[k] = apply ? FMA(cb, w, C2[k]) : C2[k];
+                T[k] = apply ? test_T : T[k];
+                last[k] = apply ? contributor : last[k];
+                done[k] = done[k] || stop;
+            }
+        }
+        wave_sync();
+    }
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (inside[k]) {
+            size_t pix = (size_t)(py0 + 4 * k) * W + px;
+            final_T[pix] = T[k];
+            n_contrib[pix] = last[k];
+            out[pix] = FMA(T[k], bg0, C0[k]);
+            out[HW + pix] = FMA(T[k], bg1, C1[k]);
+            out[2 * HW + pix] = FMA(T[k], bg2, C2[k]);
+        }
+    }
+}
+
+// background fill for P == 0 or empty scenes is handled by the same kernel (ranges are zero).
+
+// ------------------------------------------------------------------------------------ mark_visible
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means,
+                                                           const float* __restrict__ view,
+                                                           uint8_t* __restrict__ present) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float vz = XFORM(view, 2, mx, my, mz);
+    present[i] = vz > E3_NEAR_CULL_Z ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------ host driver
+extern thread_local char g_err[512];
+int e3_fail(hipError_t e, const char* what);
+#define HIP_OK(expr)                                          \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return e3_fail(_e, #expr);      \
+    } while (0)
+#define KERNEL_OK(name)                                       \
+    do {                                                      \
+        hipError_t _e = hipGetLastError();                    \
+        if (_e != hipSuccess) return e3_fail(_e, name);       \
+        if (debug) {                                          \
+            _e = hipStreamSynchronize(s);                     \
+            if (_e != hipSuccess) return e3_fail(_e, name);   \
+        }                                                     \
+    } while (0)
+
+static int ceil_log2(uint32_t v) {
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (*bin_alloc)(void*, size_t),
+                    void* bin_user, char* (*img_alloc)(void*, size_t), void* img_user, int P, int D, int M,
+                    const float* background, int W, int H, const float* means3D, const float* shs,
+                    const float* colors, const float* opac, const float* scales, float scale_modifier,
+                    const float* rots, const float* cov_pre, const float* view, const float* proj,
+                    const float* campos, float tanfovx, float tanfovy, int prefiltered, float* out_color, int* radii,
+                    int debug, int* num_rendered_host, hipStream_t s) {
+    (void)prefiltered;
+    ViewParams vp;
+    vp.view = view; vp.proj = proj; vp.campos = campos;
+    vp.tanfovx = tanfovx; vp.tanfovy = tanfovy;
+    vp.focal_x = (float)W / (2.0f * tanfovx);
+    vp.focal_y = (float)H / (2.0f * tanfovy);
+    vp.scale_modifier = scale_modifier;
+    vp.W = W; vp.H = H;
+    vp.gx = (W + E3_TILE - 1) / E3_TILE;
+    vp.gy = (H + E3_TILE - 1) / E3_TILE;
+    const int ntiles = vp.gx * vp.gy;
+    const size_t npix = (size_t)W * H;
+
+    char* gp = geom_alloc(geom_user, GeomState::required(P));
+    char* ip = img_alloc(img_user, ImageState::required(npix, ntiles));
+    if (!gp || !ip) return e3_fail(hipErrorOutOfMemory, "scratch allocation callback returned NULL");
+    GeomState geom = GeomState::from(gp, P);
+    ImageState img = ImageState::from(ip, npix, ntiles);
+    HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * sizeof(uint2), s));
+
+    uint32_t I = 0;
+    uint32_t* order = geom.ord0;
+    if (P > 0) {
+        const unsigned pb = (unsigned)((P + 255) / 256);
+        preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
+                                                         vp, radii, geom.recA, geom.recB, geom.recC, geom.clamped,
+                                                         geom.rect, geom.key0, geom.ord0);
+        KERNEL_OK("preprocess_kernel");
+        uint32_t* keys_sorted;
+        launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, (size_t)P, 32, geom.scratch, &keys_sorted,
+                                &order, s);
+        KERNEL_OK("radix sort (depth)");
+        gather_tiles_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, order, geom.rect, geom.tiles);
+        KERNEL_OK("gather_tiles_kernel");
+        launch_exclusive_scan_u32(geom.tiles, geom.offsets, (size_t)P, geom.scratch, true, s);
+        KERNEL_OK("scan");
+        // the single device->host synchronisation of the op: the instance count sizes the binning buffers
+        HIP_OK(hipMemcpyAsync(&I, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    *num_rendered_host = (int)I;
+
+    char* bp = bin_alloc(bin_user, BinningState::required(I));
+    if (!bp) return e3_fail(hipErrorOutOfMemory, "binning allocation callback returned NULL");
+    BinningState bin = BinningState::from(bp, I);
+    if (I > 0) {
+        const int tile_bits = ceil_log2((uint32_t)ntiles);
+        const int passes = radix_passes(tile_bits);
+        // choose the emit target so that the final sorted values land in bin.point_list
+        uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.point_list, *v1 = bin.vals_alt;
+        if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
+        const unsigned pb = (unsigned)((P + 255) / 256);
+        emit_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, order, geom.rect, geom.offsets, vp.gx, k0, v0);
+        KERNEL_OK("emit_kernel");
+        uint32_t *ks, *vs;
+        launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s);
+        KERNEL_OK("radix sort (tile)");
+        if (vs != bin.point_list) return e3_fail(hipErrorUnknown, "internal: sorted list not in point_list");
+        tile_ranges_kernel<<<dim3((I + 255) / 256), dim3(256), 0, s>>>(I, ks, img.ranges);
+        KERNEL_OK("tile_ranges_kernel");
+    }
+    render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
+        ntiles, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
+        img.final_T, img.n_contrib);
+    KERNEL_OK("render_fwd_kernel");
+    return 0;
+}
+
+int e3_mark_visible_impl(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+    if (P <= 0) return 0;
+    mark_visible_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, view, present);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "mark_visible_kernel");
+}

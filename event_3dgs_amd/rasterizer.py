@@ -1,0 +1,212 @@
+"""Host-side mirror of the reference's rasteriser operator API, bound to the HIP C ABI.
+
+Mirrors the Python surface of the un-vendored `diff_gaussian_rasterization` package that the
+reference imports at gaussian_renderer/__init__.py:15 and drives at :38-53,89-97:
+
+    GaussianRasterizationSettings  12-field NamedTuple (same keyword set as :38-51)
+    GaussianRasterizer             nn.Module; forward(means3D, means2D, opacities, shs=None,
+                                   colors_precomp=None, scales=None, rotations=None,
+                                   cov3D_precomp=None) -> (color (3,H,W), radii (P,) int32)
+    rasterize_gaussians / _RasterizeGaussians   autograd.Function keeping the three scratch
+                                   buffers alive between forward and backward.
+
+Gradient tuple order: means3D, means2D, sh, colors_precomp, opacities,
+scales, rotations, cov3D_precomp, raster_settings(None).
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _prep(t, name, device=None):
+    """fp32, contiguous, on the GPU.  Inputs may arrive strided (scene/cameras.py:54-57)."""
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor (this op has no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _Scratch:
+    """One growable uint8 torch tensor handed to the C ABI through an allocation callback."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _lib.ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    """One call of e3dgs_rasterize_forward.  Returns a dict with the outputs, the prepared
+    (contiguous) inputs and the three scratch tensors that backward needs."""
+    import ctypes as C
+    L = _lib.lib()
+    rs = raster_settings
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D_c = _prep(means3D, "means3D")
+    sh_c = _prep(sh, "shs")
+    colors_c = _prep(colors_precomp, "colors_precomp")
+    opac_c = _prep(opacities, "opacities")
+    scales_c = _prep(scales, "scales")
+    rots_c = _prep(rotations, "rotations")
+    cov_c = _prep(cov3Ds_precomp, "cov3D_precomp")
+    bg = _prep(rs.bg, "bg"); view = _prep(rs.viewmatrix, "viewmatrix")
+    proj = _prep(rs.projmatrix, "projmatrix"); campos = _prep(rs.campos, "campos")
+    M = 0 if sh_c is None else sh_c.shape[1]
+    if P:
+        if opac_c is None or opac_c.numel() != P:
+            raise RuntimeError("opacities must have P elements")
+        if (sh_c is None) == (colors_c is None):
+            raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales_c is None or rots_c is None) == (cov_c is None)):
+            raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    num_rendered = C.c_int(0)
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_rasterize_forward(
+            geom.cb, None, binning.cb, None, img.cb, None, P, int(rs.sh_degree), M, _lib.ptr(bg), W, H,
+            _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(scales_c),
+            float(rs.scale_modifier), _lib.ptr(rots_c), _lib.ptr(cov_c), _lib.ptr(view), _lib.ptr(proj),
+            _lib.ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
+            _lib.ptr(out_color), _lib.ptr(radii), int(bool(rs.debug)), C.byref(num_rendered),
+            _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_forward")
+    return dict(color=out_color, radii=radii, num_rendered=num_rendered.value, M=M,
+                inputs=(means3D_c, sh_c, colors_c, scales_c, rots_c, cov_c), consts=(bg, view, proj, campos),
+                geom=geom.tensor, binning=binning.tensor, image=img.tensor)
+
+
+def state_views(raw, P, W, H):
+    """Typed views into the scratch buffers of a forward_raw() result (tests / tools)."""
+    import ctypes as C
+    offs = (C.c_size_t * 9)()
+    I = raw["num_rendered"]
+    _lib.lib().e3dgs_state_offsets(P, I, W, H, offs)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    def view(buf, off, dtype, count, shape):
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        return buf[off:off + nbytes].view(dtype).reshape(shape)
+    g, b, im = raw["geom"], raw["binning"], raw["image"]
+    return dict(
+        recA=view(g, offs[0], torch.float32, 4 * P, (P, 4)), recB=view(g, offs[1], torch.float32, 4 * P, (P, 4)),
+        recC=view(g, offs[2], torch.float32, P, (P,)), clamped=view(g, offs[3], torch.int32, P, (P,)),
+        rect=view(g, offs[4], torch.int32, 2 * P, (P, 2)),
+        point_list=view(b, offs[5], torch.int32, I, (I,)),
+        ranges=view(im, offs[6], torch.int32, 2 * gx * gy, (gx * gy, 2)),
+        final_T=view(im, offs[7], torch.float32, W * H, (H, W)),
+        n_contrib=view(im, offs[8], torch.int32, W * H, (H, W)))
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        raw = forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = raw["num_rendered"]
+        ctx.consts = raw["consts"]
+        ctx.M = raw["M"]
+        ctx.save_for_backward(*raw["inputs"], raw["radii"], raw["geom"], raw["binning"], raw["image"])
+        ctx.mark_non_differentiable(raw["radii"])
+        return raw["color"], raw["radii"]
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        L = _lib.lib()
+        rs = ctx.raster_settings
+        means3D, sh, colors, scales, rots, cov, radii, geomB, binB, imgB = ctx.saved_tensors
+        bg, view, proj, campos = ctx.consts
+        dev = means3D.device
+        P, M = means3D.shape[0], ctx.M
+        H, W = int(rs.image_height), int(rs.image_width)
+        g = grad_out_color
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = g.contiguous()
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        dL_dmeans2D, dL_dconic, dL_dopacity = z(P, 3), z(P, 4), z(P, 1)
+        dL_dcolors, dL_dmeans3D, dL_dcov3D = z(P, 3), z(P, 3), z(P, 6)
+        dL_dsh = z(P, M, 3) if sh is not None else None
+        dL_dscales = z(P, 3) if cov is None else None
+        dL_drots = z(P, 4) if cov is None else None
+        if P:
+            with torch.cuda.device(dev):
+                rc = L.e3dgs_rasterize_backward(
+                    P, int(rs.sh_degree), M, ctx.num_rendered, _lib.ptr(bg), W, H, _lib.ptr(means3D), _lib.ptr(sh),
+                    _lib.ptr(colors), _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots), _lib.ptr(cov),
+                    _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
+                    _lib.ptr(radii), _lib.ptr(geomB), _lib.ptr(binB), _lib.ptr(imgB), _lib.ptr(g),
+                    _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dconic), _lib.ptr(dL_dopacity), _lib.ptr(dL_dcolors),
+                    _lib.ptr(dL_dmeans3D), _lib.ptr(dL_dcov3D), _lib.ptr(dL_dsh), _lib.ptr(dL_dscales),
+                    _lib.ptr(dL_drots), int(bool(rs.debug)), _lib.current_stream())
+            _lib.check(rc, "e3dgs_rasterize_backward")
+        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if colors is not None else None, dL_dopacity,
+                dL_dscales, dL_drots, dL_dcov3D if cov is not None else None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            pos = _prep(positions, "positions")
+            P = 0 if pos is None else pos.shape[0]
+            present = torch.zeros(P, dtype=torch.uint8, device=positions.device)
+            if P:
+                rc = _lib.lib().e3dgs_mark_visible(P, _lib.ptr(pos), _lib.ptr(_prep(rs.viewmatrix, "viewmatrix")),
+                                                   _lib.ptr(_prep(rs.projmatrix, "projmatrix")), _lib.ptr(present),
+                                                   _lib.current_stream())
+                _lib.check(rc, "e3dgs_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

@@ -1,0 +1,189 @@
+/*
+ * e3dgs_hip.h -- C ABI of the MI355X (gfx950) Gaussian-splat hot path.
+ *
+ * This is the drop-in boundary of the repo: a plain C interface (raw device
+ * pointers, sizes, a hipStream_t passed as void*) with no torch types.  Each
+ * entry point replaces one function of the reference's un-vendored CUDA
+ * submodules; the reference-side call sites are cited per function.
+ *
+ *   reference import  gaussian_renderer/__init__.py:15
+ *       from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+ *   reference import  scene/gaussian_model.py:20
+ *       from simple_knn._C import distCUDA2
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - matrices are 16 floats in the reference's row-vector layout
+ *     (scene/cameras.py:54-56): flat[4*c + r] = row r, column c of the
+ *     textbook column-vector matrix;
+ *   - every function enqueues on `stream` and returns 0 (hipSuccess) or a
+ *     non-zero hipError_t value; e3dgs_last_error() gives the text;
+ *   - nothing here allocates device memory: scratch comes from the caller
+ *     through e3dgs_alloc_fn (the reference op grows three torch uint8 tensors
+ *     the same way and keeps them alive in the autograd ctx).
+ */
+#ifndef E3DGS_HIP_H
+#define E3DGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Returns a device pointer to at least `bytes` bytes (256-B aligned), owned by the caller. */
+typedef char* (*e3dgs_alloc_fn)(void* user, size_t bytes);
+
+/* ABI version; bumped on any signature change. */
+int e3dgs_abi_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* e3dgs_last_error(void);
+
+/*
+ * Forward rasterisation of P Gaussians into a (3,H,W) planar fp32 image.
+ * Replaces: diff_gaussian_rasterization._C.rasterize_gaussians, called by
+ * GaussianRasterizer.forward at gaussian_renderer/__init__.py:89-97 (and the
+ * duplicates at :174-182, :342-350) with the settings built at :38-51.
+ *
+ *   D = active SH degree, M = SH coefficients per channel in `shs` (P,M,3).
+ *   Exactly one of {shs, colors_precomp} and exactly one of
+ *   {scales+rotations, cov3D_precomp} is non-NULL.
+ *   out_color (3,H,W) and radii (P) are written in full (radii 0 = culled).
+ *   geom/binning/image scratch is requested through the three allocators and
+ *   must stay alive, unmodified, until the matching backward has run.
+ *   Contains exactly one device->host synchronisation (the instance count).
+ *   *num_rendered_host receives the number of (tile, Gaussian) instances.
+ */
+int e3dgs_rasterize_forward(
+    e3dgs_alloc_fn geom_alloc, void* geom_user,
+    e3dgs_alloc_fn binning_alloc, void* binning_user,
+    e3dgs_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,          /* (3) */
+    int width, int height,
+    const float* means3D,             /* (P,3) */
+    const float* shs,                 /* (P,M,3) or NULL */
+    const float* colors_precomp,      /* (P,3) or NULL */
+    const float* opacities,           /* (P) */
+    const float* scales,              /* (P,3) or NULL */
+    float scale_modifier,
+    const float* rotations,           /* (P,4) (r,x,y,z) or NULL */
+    const float* cov3D_precomp,       /* (P,6) or NULL */
+    const float* viewmatrix,          /* (16) */
+    const float* projmatrix,          /* (16) */
+    const float* cam_pos,             /* (3) */
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    float* out_color,                 /* (3,H,W) */
+    int* radii,                       /* (P) */
+    int debug,
+    int* num_rendered_host,
+    void* stream);
+
+/*
+ * Backward of the above.  Replaces:
+ * diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
+ * loss.backward() at train.py:211 through _RasterizeGaussians.backward.
+ *
+ * All dL_d* outputs must be zero-filled by the caller.  dL_dmean2D is (P,3)
+ * with the third component left 0 and the first two in NDC units
+ * (consumed by scene/gaussian_model.py:405-407).  dL_dcov3D (P,6) is always
+ * written (it is the returned gradient when cov3D_precomp was given, scratch
+ * otherwise).
+ */
+int e3dgs_rasterize_backward(
+    int P, int D, int M, int num_rendered,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    const float* dL_dpix,             /* (3,H,W) */
+    float* dL_dmean2D,                /* (P,3) */
+    float* dL_dconic,                 /* (P,4) scratch */
+    float* dL_dopacity,               /* (P) */
+    float* dL_dcolor,                 /* (P,3) */
+    float* dL_dmean3D,                /* (P,3) */
+    float* dL_dcov3D,                 /* (P,6) */
+    float* dL_dsh,                    /* (P,M,3) or NULL */
+    float* dL_dscale,                 /* (P,3) or NULL */
+    float* dL_drot,                   /* (P,4) or NULL */
+    int debug,
+    void* stream);
+
+/*
+ * Byte offsets of the members of the three scratch buffers, for tests and tools that want to
+ * inspect intermediate state (sorted lists, tile ranges, per-pixel n_contrib).
+ *   out[0..4]  geom:    recA (float4: x,y,conic.x,conic.y), recB (float4: conic.z,opacity,r,g),
+ *                       recC (float: b), clamped (u32), rect (uint2 packed 16-bit xmin|ymin, xmax|ymax)
+ *   out[5]     binning: point_list (u32 Gaussian ids, tile-major, depth order)
+ *   out[6..8]  image:   ranges (uint2 per tile), final_T (float per pixel), n_contrib (u32 per pixel)
+ */
+void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9);
+
+/*
+ * present[i] = 1 iff Gaussian i passes the near-plane test of the forward.
+ * Replaces: diff_gaussian_rasterization._C.mark_visible
+ * (GaussianRasterizer.markVisible; not called by this reference, kept for API
+ * completeness).
+ */
+int e3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                       const float* projmatrix, uint8_t* present, void* stream);
+
+/*
+ * out[i] = mean squared distance from point i to its 3 nearest other points.
+ * Replaces: simple_knn._C.distCUDA2 (scene/gaussian_model.py:134).
+ * `scratch` must hold e3dgs_knn_scratch_bytes(P) bytes.
+ */
+size_t e3dgs_knn_scratch_bytes(int P);
+int e3dgs_dist_knn3(int P, const float* points /* (P,3) */, float* out /* (P) */,
+                    char* scratch, void* stream);
+
+/*
+ * Fused event iteration loss of train.py:165-203 (forward value and the
+ * gradients w.r.t. the three rendered images and the contrast threshold c).
+ *
+ *   D  = (ln(Y(next)+1e-8) - ln(Y(now)+1e-8)) / c        utils/loss_utils.py:234-249
+ *   D* = same on the ground-truth pair with c = 0.17      train.py:170
+ *   loss = 0.9*mean|D-D*|*rho + 0.1*mean|image-gt_int|*(1-rho),  rho = mean(D* != 0)
+ *   deblur (gt_blur != NULL): loss = 0.5*loss + 0.5*mean|image-gt_blur|   train.py:197-203
+ *
+ * Two launches: a reduction pass (partials -> scalars[8] on device) and a
+ * gradient pass.  scalars_out[0]=loss, [1]=dL/dc, [2]=rho, [3]=L1 event,
+ * [4]=L1 intensity, [5]=L1 blur.  `scratch` needs e3dgs_event_loss_scratch_bytes(W,H).
+ */
+size_t e3dgs_event_loss_scratch_bytes(int width, int height);
+int e3dgs_event_loss(
+    int width, int height,
+    const float* image,     /* (3,H,W) intensity render */
+    const float* img_now,   /* (3,H,W) */
+    const float* img_next,  /* (3,H,W) */
+    const float* gt_int,    /* (3,H,W) */
+    const float* gt_now,    /* (3,H,W) */
+    const float* gt_next,   /* (3,H,W) */
+    const float* gt_blur,   /* (3,H,W) or NULL */
+    const float* c,         /* (1) device scalar, learnable threshold */
+    float gt_c,             /* 0.17 in the reference */
+    float* d_image, float* d_now, float* d_next, /* (3,H,W) grads, overwritten */
+    float* scalars_out,     /* (8) device */
+    char* scratch,
+    void* stream);
+
+/*
+ * Fused Adam step over one flat parameter tensor (train.py:330-332; groups
+ * scene/gaussian_model.py:154-163; eps 1e-15).  Matches torch.optim.Adam
+ * (no amsgrad, no weight decay): bias-corrected with step count `step`.
+ */
+int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg,
+                    float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                    int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E3DGS_HIP_H */

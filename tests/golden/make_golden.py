@@ -1,0 +1,180 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference's own Python (this container only).
+
+Run:  python tests/golden/make_golden.py          (needs /root/reference; never runs on the GPU box)
+
+Only arrays (inputs + the reference's outputs) are written; no reference source
+travels.  Recipe = SURVEY.md Appendix E: stub the modules the imported functions
+never touch, and map device "cuda" to CPU.
+
+Vectors:
+  G1 sh.npz          utils/sh_utils.py eval_sh deg 0..3 + clamp of gaussian_renderer/__init__.py:81, with autograd grads
+  G2 cov3d.npz       scene/gaussian_model.py:27-31 build_covariance_from_scaling_rotation + grads
+  G3 cameras.npz     scene/cameras.py Camera matrices for 4 seeded poses (one 1920x1080)
+  G4 event_loss.npz  utils/loss_utils.py differentialable_event_simu / l1_loss + the train.py:165-203 composition, grads
+  G5 image_metrics.npz  ssim, ssim_gray, l1_loss_gray, psnr values
+  G7 lr.npz          utils/general_utils.py get_expon_lr_func at steps {0,1,100,7000,30000}
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    for n in ["torchvision", "torchgeometry", "lpips", "plyfile", "simple_knn", "simple_knn._C",
+              "diff_gaussian_rasterization"]:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    sys.modules["diff_gaussian_rasterization"].GaussianRasterizationSettings = None
+    sys.modules["diff_gaussian_rasterization"].GaussianRasterizer = None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    def _wrap(fn):
+        def inner(*a, **k):
+            if k.get("device") is not None and "cuda" in str(k["device"]):
+                k["device"] = "cpu"
+            return fn(*a, **k)
+        return inner
+    for name in ["zeros", "ones", "tensor", "empty", "rand", "zeros_like", "ones_like", "full"]:
+        setattr(torch, name, _wrap(getattr(torch, name)))
+
+
+def main():
+    _import_reference()
+    from utils.sh_utils import eval_sh, RGB2SH
+    from utils.general_utils import build_scaling_rotation, strip_symmetric, get_expon_lr_func
+    from utils.loss_utils import (differentialable_event_simu, l1_loss, l1_loss_gray, ssim, ssim_gray)
+    from utils.image_utils import psnr
+    from scene.cameras import Camera
+
+    g = torch.Generator().manual_seed(1234)
+
+    # ---- G1: SH colours as render() computes them (gaussian_renderer/__init__.py:74-81) ----
+    out = {}
+    N = 64
+    feats = torch.randn(N, 16, 3, generator=g) * 0.4          # (N,16,3) like pc.get_features
+    xyz = torch.randn(N, 3, generator=g)
+    campos = torch.tensor([0.3, -0.2, 2.5])
+    out["features"], out["xyz"], out["campos"] = feats.numpy(), xyz.numpy(), campos.numpy()
+    gcol = torch.randn(N, 3, generator=g)
+    out["grad_colors"] = gcol.numpy()
+    for deg in range(4):
+        f = feats.clone().requires_grad_(True)
+        p = xyz.clone().requires_grad_(True)
+        shs_view = f.transpose(1, 2).view(-1, 3, 16)
+        dir_pp = p - campos.repeat(N, 1)
+        dirn = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        col = torch.clamp_min(eval_sh(deg, shs_view, dirn) + 0.5, 0.0)
+        (col * gcol).sum().backward()
+        out[f"colors_deg{deg}"] = col.detach().numpy()
+        out[f"dfeatures_deg{deg}"] = f.grad.numpy()
+        out[f"dxyz_deg{deg}"] = p.grad.numpy() if p.grad is not None else np.zeros((N, 3), np.float32)
+    out["rgb2sh_of_half"] = RGB2SH(torch.tensor([0.5, 0.0, 1.0])).numpy()
+    np.savez(os.path.join(OUT, "sh.npz"), **out)
+
+    # ---- G2: covariance twin (scene/gaussian_model.py:27-31) ----
+    s = torch.exp(torch.randn(N, 3, generator=g) * 0.7 - 2).requires_grad_(True)
+    q = torch.randn(N, 4, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True)).requires_grad_(True)
+    gc = torch.randn(N, 6, generator=g)
+    for mod in (1.0, 0.7):
+        s.grad = q.grad = None
+        L = build_scaling_rotation(mod * s, q)
+        cov = strip_symmetric(L @ L.transpose(1, 2))
+        (cov * gc).sum().backward()
+        tag = "" if mod == 1.0 else "_mod07"
+        np.savez(os.path.join(OUT, f"cov3d{tag}.npz"), scales=s.detach().numpy(), rotations=q.detach().numpy(),
+                 cov=cov.detach().numpy(), grad_cov=gc.numpy(), dscales=s.grad.numpy(), drotations=q.grad.numpy(),
+                 mod=np.float32(mod))
+
+    # ---- G3: cameras ----
+    cams = {}
+    rs = np.random.RandomState(7)
+    sizes = [(48, 32), (800, 800), (1920, 1080), (333, 217)]
+    for k, (w, h) in enumerate(sizes):
+        A = rs.randn(3, 3)
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        T = rs.randn(3) * 2
+        fovx = 0.6911112070083618 if k != 3 else 1.1
+        fovy = 2 * np.arctan(np.tan(fovx / 2) * h / w)
+        cam = Camera(colmap_id=k, R=Q, T=T, FoVx=fovx, FoVy=fovy, image=torch.zeros(3, h, w), gt_alpha_mask=None,
+                     image_name=str(k), uid=k, data_device="cpu")
+        cams[f"R{k}"], cams[f"T{k}"] = Q, T
+        cams[f"fov{k}"] = np.array([fovx, fovy]); cams[f"size{k}"] = np.array([w, h])
+        cams[f"view{k}"] = cam.world_view_transform.contiguous().numpy()
+        cams[f"viewstride{k}"] = np.array(cam.world_view_transform.stride())
+        cams[f"proj{k}"] = cam.full_proj_transform.contiguous().numpy()
+        cams[f"center{k}"] = cam.camera_center.contiguous().numpy()
+        cams[f"P{k}"] = cam.projection_matrix.contiguous().numpy()
+    np.savez(os.path.join(OUT, "cameras.npz"), **cams)
+
+    # ---- G4: event loss pieces + the train.py:165-203 composition ----
+    H, W = 32, 48
+    ev = {}
+    img = (torch.rand(3, H, W, generator=g))
+    now = torch.rand(3, H, W, generator=g)
+    nxt = (now + 0.1 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    now[:, :4, :] = 0.0                                        # black background region: Y = 0 -> ln(1e-8)
+    nxt[:, :2, :] = 0.0
+    gt_int = torch.rand(3, H, W, generator=g)
+    q8 = lambda t: torch.round(t * 255) / 255                  # 8-bit GT like PIL images
+    gt_now = q8(torch.rand(3, H, W, generator=g))
+    gt_next = gt_now.clone()
+    chg = torch.rand(H, W, generator=g) < 0.35                 # 35 % of pixels change -> rho ~ 0.35
+    gt_next[:, chg] = q8(torch.rand(3, int(chg.sum()), generator=g))
+    gt_blur = torch.rand(3, H, W, generator=g)
+    for name, t in dict(image=img, now=now, next=nxt, gt_int=gt_int, gt_now=gt_now, gt_next=gt_next, gt_blur=gt_blur).items():
+        ev[name] = t.numpy()
+    for deblur in (False, True):
+        c = torch.nn.Parameter(torch.tensor(0.17 if not deblur else 0.23))
+        a, b_, d = img.clone().requires_grad_(True), now.clone().requires_grad_(True), nxt.clone().requires_grad_(True)
+        img_diff = differentialable_event_simu(b_, d, False, c)
+        gt_image = differentialable_event_simu(gt_now, gt_next, False, 0.17)
+        Ll1 = l1_loss(img_diff, gt_image)
+        lambda_dssim = 0
+        loss1 = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim_gray(img_diff, gt_image))
+        Ll1b = l1_loss(a, gt_int)
+        loss2 = (1.0 - lambda_dssim) * Ll1b
+        mask = (gt_image != 0).float()
+        loss = 0.9 * (loss1 * mask).sum() + (1 - 0.9) * (loss2 * (1 - mask)).sum()
+        loss /= (mask.sum() + (1 - mask).sum())
+        if deblur:
+            loss = (1.0 - 0.5) * loss + 0.5 * l1_loss(a, gt_blur)
+        loss.backward()
+        t = "_deblur" if deblur else ""
+        ev["c" + t] = c.detach().numpy(); ev["loss" + t] = loss.detach().numpy()
+        ev["d_image" + t], ev["d_now" + t], ev["d_next" + t] = a.grad.numpy(), b_.grad.numpy(), d.grad.numpy()
+        ev["d_c" + t] = c.grad.numpy()
+        ev["img_diff" + t] = img_diff.detach().numpy(); ev["gt_diff"] = gt_image.numpy()
+        ev["rho"] = mask.mean().numpy()
+    np.savez(os.path.join(OUT, "event_loss.npz"), **ev)
+
+    # ---- G5: image metrics ----
+    a = torch.rand(3, 40, 56, generator=g); b2 = (a + 0.1 * torch.randn(3, 40, 56, generator=g)).clamp(0, 1)
+    a.requires_grad_(True)
+    sv = ssim(a, b2); sg = ssim_gray(a, b2); lg = l1_loss_gray(a, b2)
+    loss_gray = 0.8 * lg + 0.2 * (1.0 - sg)                    # train.py:213-223 with default lambda_dssim
+    loss_gray.backward()
+    np.savez(os.path.join(OUT, "image_metrics.npz"), a=a.detach().numpy(), b=b2.numpy(), ssim=sv.detach().numpy(),
+             ssim_gray=sg.detach().numpy(), l1_gray=lg.detach().numpy(), psnr=psnr(a.detach(), b2).numpy(),
+             gray_loss=loss_gray.detach().numpy(), d_a_gray_loss=a.grad.numpy())
+
+    # ---- G7: LR schedule (arguments/__init__.py:77-81 defaults, scene extent 1) ----
+    fn = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=30000)
+    steps = np.array([0, 1, 100, 7000, 30000])
+    np.savez(os.path.join(OUT, "lr.npz"), steps=steps, lr=np.array([fn(int(s)) for s in steps], np.float64))
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
