@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: train iters/s of the reference's `--event` iteration
+(train.py:97-332: three renders fwd+bwd, event + intensity loss, Adam) on synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  Workload at N=1 is BASELINE.json configs[2]:
+1M Gaussians, 1920x1080, event iteration, "trained-like" synthetic scene of SURVEY 8(d).
+With N>1 every rank renders its own camera triplet of the same replicated model and the
+59 floats/Gaussian of gradient are all-reduced over RCCL (view-parallel DP, weak scaling:
+value = camera triplets (= reference iterations) processed per second by the whole job).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (N gaussians, W, H, deblur)
+    "cfg2_200k_800px": (200_000, 800, 800, False),
+    "cfg3_1M_1080p_event": (1_000_000, 1920, 1080, False),
+    "cfg4_1M_1080p_deblur": (1_000_000, 1920, 1080, True),
+    "cfg5_2M_1080p_event": (2_000_000, 1920, 1080, False),
+    "tiny": (20_000, 320, 240, False),
+}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(slot, N, I, T, npx):
+    """SURVEY 8(d) per-render algorithmic bytes of each profiled stage."""
+    tile_bits = max(1, math.ceil(math.log2(max(T, 2))))
+    return {
+        "preprocess": 132 * N,
+        "sort_depth": 16 * N * 4,                       # 4 passes x (8 B read + 8 B write) on P pairs
+        "scan_emit": 8 * N + 20 * N + 8 * I,            # gather+scan, emit (u32 tile id + u32 Gaussian id)
+        "sort_tile": 16 * I * math.ceil(tile_bits / 8),
+        "tile_ranges": 4 * I + 8 * T,
+        "render_fwd": 40 * I + 20 * npx + 12,
+        "render_bwd": 40 * I + 20 * npx + 36 * I,
+        "geom_bwd": 160 * N,
+    }[slot]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=3, help="tile rows composited by the CPU baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from event_3dgs_amd import _lib, synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer, FLOATS_PER_GAUSSIAN
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg_name = args.config or "cfg3_1M_1080p_event"
+    N, W, H, deblur = CONFIGS[cfg_name]
+    L = _lib.lib()
+
+    # ---- scene, cameras, ground truth (render of the jittered scene) -- all resident in HBM
+    params = synth.make_scene(N, "trained", seed=0, device=dev)
+    K = 64
+    k0 = 3 * rank                                            # every rank its own triplet
+    cam_int = orbit_camera(k0, K, W, H, device=dev)
+    cam_now = orbit_camera(k0, K, W, H, device=dev, daz=0.005)
+    cam_next = orbit_camera(k0, K, W, H, device=dev, daz=0.015)
+    bg = torch.zeros(3, device=dev)
+    gt_params = dict(params)
+    gt_params["xyz"] = params["xyz"] + 0.01 * torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    gt_tr = EventTrainer(gt_params, dev)
+    with torch.no_grad():
+        gt_tr._activations()
+        gts = [gt_tr.render(c, bg)["render"].clone() for c in (cam_int, cam_now, cam_next)]
+    gt_blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
+    del gt_tr
+    trainer = EventTrainer(params, dev)
+
+    def one_step():
+        return trainer.step(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+
+    for _ in range(args.warmup):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.e3dgs_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # ---- per-kernel durations from the HIP events recorded on the launch stream during the timed region
+    import ctypes as C
+    kern = {}
+    for slot in range(8):
+        ms, n = C.c_double(0), C.c_int(0)
+        L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
+        name = L.e3dgs_profile_slot_name(slot).decode()
+        kern[name] = (ms.value, n.value)
+    L.e3dgs_profile_enable(0)
+    loss_val = float(loss.item())
+
+    # workload statistics of the last intensity render
+    with torch.no_grad():
+        vis = int((trainer.last_render["radii"] > 0).sum())
+    from event_3dgs_amd import rasterizer
+    trainer._activations()
+    with torch.no_grad():
+        v = trainer.views
+        rs = rasterizer.GaussianRasterizationSettings(H, W, math.tan(cam_int.FoVx * 0.5), math.tan(cam_int.FoVy * 0.5),
+                                                      bg, 1.0, cam_int.world_view_transform,
+                                                      cam_int.full_proj_transform, 3, cam_int.camera_center, False,
+                                                      False)
+        raw = rasterizer.forward_raw(v["xyz"], v["features"], None, trainer._opac, trainer._scales, trainer._rots,
+                                     None, rs)
+    I = raw["num_rendered"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    npx = W * H
+
+    stages = {}
+    for name, (ms, n) in kern.items():
+        if n:
+            avg = ms / n
+            b = algorithmic_bytes(name, N, I, T, npx)
+            stages[name] = {"avg_ms": round(avg, 4), "launch_groups": n, "alg_GB": round(b / 1e9, 4),
+                            "alg_GBps": round(b / 1e9 / (avg / 1e3), 1)}
+    dominant = max(stages, key=lambda k: stages[k]["avg_ms"] * stages[k]["launch_groups"]) if stages else None
+    roofline = None
+    if dominant:
+        s = stages[dominant]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant + "_kernel", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": dominant + "_kernel", "bound": "hbm", "achieved": s["alg_GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(s["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_ms": s["avg_ms"], "alg_bytes_per_launch": int(s["alg_GB"] * 1e9),
+                    "note": "compositing is VALU/exp/atomic-bound, not HBM-bound (SURVEY 8d): alpha evaluations/s = "
+                            + f"{256.0 * I / (s['avg_ms'] / 1e3) / 1e9:.1f} G/s"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows)
+
+    if rank == 0:
+        iters_per_s = args.steps * world / dt
+        out = {
+            "metric": "train iters/s fwd+bwd @1M Gaussians 1080p; PSNR vs ref; HBM GB/s %peak",
+            "value": round(iters_per_s, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg_name, "gaussians": N, "width": W, "height": H, "visible": vis,
+                       "tile_instances": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
+                       "parallelism": f"view-dp{world}", "grad_allreduce_bytes": 4 * FLOATS_PER_GAUSSIAN * N if world > 1 else 0,
+                       "loss": round(loss_val, 6)},
+            "roofline": roofline, "stages": stages, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(trainer, cams, bg, W, H, rows):
+    """C oracle (single thread) on a bounded sample of the same workload: full preprocess + binning of
+    all Gaussians for the three views, compositing fwd+bwd restricted to `rows` tile rows around the image
+    centre, extrapolated linearly in tile instances to the whole image."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle
+    v = {k: t.detach().cpu() for k, t in trainer.views.items()}
+    means = v["xyz"].numpy()
+    scales = torch.exp(v["scaling"]).numpy()
+    rots = torch.nn.functional.normalize(v["rotation"]).numpy()
+    opac = torch.sigmoid(v["opacity"]).numpy()
+    shs = v["features"].numpy()
+    gy = (H + 15) // 16
+    r0 = max(0, gy // 2 - rows // 2)
+    total = 0.0
+    detail = []
+    for cam in cams:
+        t0 = time.perf_counter()
+        f = c_oracle.Forward(means3D=means, opacities=opac, viewmatrix=cam.world_view_transform.contiguous().cpu().numpy(),
+                             projmatrix=cam.full_proj_transform.cpu().numpy(),
+                             campos=cam.camera_center.contiguous().cpu().numpy(), bg=bg.cpu().numpy(), width=W,
+                             height=H, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), shs=shs,
+                             sh_degree=3, scales=scales, rotations=rots, tile_rows=(r0, r0 + rows))
+        t1 = time.perf_counter()
+        gw = np.ones((3, H, W), np.float32)
+        f.backward(gw)
+        t2 = time.perf_counter()
+        tm = f.timings            # preprocess, binning, composite seconds
+        ranges = f.ranges.reshape(gy, -1, 2)
+        inst_rows = int((ranges[r0:r0 + rows, :, 1] - ranges[r0:r0 + rows, :, 0]).sum())
+        scale = f.num_rendered / max(inst_rows, 1)
+        est = tm[0] + tm[1] + (tm[2] + (t2 - t1)) * scale
+        total += est
+        detail.append({"pre_s": round(tm[0], 3), "bin_s": round(tm[1], 3), "comp_fwd_s": round(tm[2], 3),
+                       "bwd_s": round(t2 - t1, 3), "row_instances": inst_rows, "extrap": round(scale, 2)})
+        f.close()
+    return {"value": round(1.0 / total, 5), "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"C oracle (oracle/gs_oracle.c, 1 thread): 3 views, full preprocess+sort of all Gaussians, "
+                      f"compositing fwd+bwd on {rows} of {gy} tile rows extrapolated by tile instances; loss/Adam excluded",
+            "host_cpus": os.cpu_count(), "detail": detail}
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,9 @@ def lib():
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; import it FIRST so that our library binds to the same
+    # HIP runtime instance (two runtimes in one process -> "no ROCm-capable device", hipError 100).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.e3dgs_abi_version.restype = C.c_int
     if L.e3dgs_abi_version() != ABI_VERSION:
@@ -53,7 +56,13 @@ def lib():
     L.e3dgs_event_loss.restype = C.c_int
     L.e3dgs_event_loss.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 4 + [_cp, _vp]
     L.e3dgs_adam_step.restype = C.c_int
-    L.e3dgs_adam_step.argtypes = [C.c_size_t] + [_fp] * 4 + [C.c_float] * 4 + [C.c_int, _vp]
+    L.e3dgs_adam_step.argtypes = [C.c_size_t] + [_fp] * 4 + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_int, C.c_int, _vp]
+    L.e3dgs_profile_enable.restype = None
+    L.e3dgs_profile_enable.argtypes = [C.c_int]
+    L.e3dgs_profile_query.restype = C.c_int
+    L.e3dgs_profile_query.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.e3dgs_profile_slot_name.restype = C.c_char_p
+    L.e3dgs_profile_slot_name.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -77,5 +86,5 @@ def current_stream():
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_backward",
     "e3dgs_state_offsets", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
-    "e3dgs_event_loss", "e3dgs_adam_step",
+    "e3dgs_event_loss", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

@@ -326,10 +326,13 @@ int e3_event_loss_impl(int W, int H, const float* image, const float* now, const
 // ------------------------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float step_size,
-                                                   float b1, float b2, float bc2_sqrt, float eps) {
+                                                   float b1, float b2, float bc2_sqrt, float eps, float step_size_b,
+                                                   int period, int split) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float step_a = step_size;
     for (; i < n; i += stride) {
+        if (period > 0) step_size = ((int)(i % (size_t)period) < split) ? step_a : step_size_b;
         float gi = g[i];
         float mi = m[i] + (1.0f - b1) * (gi - m[i]);
         float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
@@ -340,12 +343,13 @@ __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__
 }
 
 int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
-                 int step, hipStream_t s) {
+                 int step, float lr_b, int period, int split, hipStream_t s) {
     if (n == 0) return 0;
     double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     size_t nb = (n + 255) / 256;
     if (nb > 8192) nb = 8192;
-    adam_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, (float)(lr / bc1), b1, b2, (float)sqrt(bc2), eps);
+    adam_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, (float)(lr / bc1), b1, b2, (float)sqrt(bc2), eps,
+                                                         (float)(lr_b / bc1), period, split);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "adam_kernel");
 }

@@ -378,14 +378,18 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     BinningState bin = BinningState::from(bp, (size_t)num_rendered);
     ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
     if (num_rendered > 0) {
+        ProfScope ps(PS_RENDER_BWD, s);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
             ntiles, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
             img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
-        KERNEL_OK("render_bwd_kernel");
     }
+    KERNEL_OK("render_bwd_kernel");
+    {
+    ProfScope ps(PS_GEOM_BWD, s);
     geom_bwd_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, D, M, means3D, shs, scales, rots, cov_pre, vp, radii,
                                                                geom.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
                                                                dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    }
     KERNEL_OK("geom_bwd_kernel");
     return 0;
 }

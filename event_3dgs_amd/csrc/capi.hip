@@ -11,6 +11,34 @@ int e3_fail(hipError_t e, const char* what) {
     return e == hipSuccess ? -1 : (int)e;
 }
 
+// ---- event profiler
+bool g_prof_on = false;
+namespace {
+struct ProfPair { hipEvent_t a, b; };
+constexpr int PROF_MAX = 4096;
+ProfPair g_pairs[PS_COUNT][PROF_MAX];
+int g_created[PS_COUNT] = {0}, g_used[PS_COUNT] = {0};
+bool g_open[PS_COUNT] = {false};
+const char* g_names[PS_COUNT] = {"preprocess", "sort_depth", "scan_emit", "sort_tile", "tile_ranges", "render_fwd",
+                                 "render_bwd", "geom_bwd"};
+}  // namespace
+void prof_begin(int slot, hipStream_t s) {
+    int k = g_used[slot];
+    if (k >= PROF_MAX) return;
+    if (k >= g_created[slot]) {
+        if (hipEventCreate(&g_pairs[slot][k].a) != hipSuccess || hipEventCreate(&g_pairs[slot][k].b) != hipSuccess) return;
+        g_created[slot] = k + 1;
+    }
+    (void)hipEventRecord(g_pairs[slot][k].a, s);
+    g_open[slot] = true;
+}
+void prof_end(int slot, hipStream_t s) {
+    if (!g_open[slot]) return;
+    (void)hipEventRecord(g_pairs[slot][g_used[slot]].b, s);
+    g_used[slot]++;
+    g_open[slot] = false;
+}
+
 int e3_forward_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*,
                     int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
                     const float*, float, const float*, const float*, const float*, const float*, const float*, float,
@@ -25,7 +53,8 @@ int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
 size_t e3_event_scratch_bytes(int, int);
 int e3_event_loss_impl(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
                        const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
-int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, hipStream_t);
+int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, float, int, int,
+                 hipStream_t);
 
 extern "C" {
 
@@ -113,9 +142,31 @@ int e3dgs_event_loss(int width, int height, const float* image, const float* img
 }
 
 int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                    float beta1, float beta2, float eps, int step, void* stream) {
+                    float beta1, float beta2, float eps, int step, float lr_b, int period, int split, void* stream) {
     g_err[0] = 0;
-    return e3_adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+    return e3_adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, lr_b, period, split,
+                        (hipStream_t)stream);
 }
+
+void e3dgs_profile_enable(int on) {
+    g_prof_on = on != 0;
+    for (int i = 0; i < PS_COUNT; ++i) { g_used[i] = 0; g_open[i] = false; }
+}
+int e3dgs_profile_query(int slot, double* total_ms, int* launches) {
+    if (slot < 0 || slot >= PS_COUNT) return -1;
+    double t = 0.0;
+    for (int k = 0; k < g_used[slot]; ++k) {
+        hipError_t e = hipEventSynchronize(g_pairs[slot][k].b);
+        if (e != hipSuccess) return e3_fail(e, "profile event sync");
+        float ms = 0.0f;
+        e = hipEventElapsedTime(&ms, g_pairs[slot][k].a, g_pairs[slot][k].b);
+        if (e != hipSuccess) return e3_fail(e, "profile elapsed");
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = g_used[slot];
+    return 0;
+}
+const char* e3dgs_profile_slot_name(int slot) { return (slot >= 0 && slot < PS_COUNT) ? g_names[slot] : ""; }
 
 }  // extern "C"

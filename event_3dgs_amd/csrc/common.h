@@ -193,3 +193,15 @@ void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                              uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
 static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
+
+// ---------------------------------------------------------------- optional event profiler (capi.hip)
+enum ProfSlot { PS_PREPROCESS = 0, PS_SORT_DEPTH, PS_SCAN_EMIT, PS_SORT_TILE, PS_RANGES, PS_RENDER_FWD, PS_RENDER_BWD,
+                PS_GEOM_BWD, PS_COUNT };
+extern bool g_prof_on;
+void prof_begin(int slot, hipStream_t s);
+void prof_end(int slot, hipStream_t s);
+struct ProfScope {
+    int slot; hipStream_t s;
+    ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_) { if (g_prof_on) prof_begin(slot, s); }
+    ~ProfScope() { if (g_prof_on) prof_end(slot, s); }
+};

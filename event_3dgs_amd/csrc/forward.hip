@@ -374,17 +374,25 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
     uint32_t* order = geom.ord0;
     if (P > 0) {
         const unsigned pb = (unsigned)((P + 255) / 256);
+        {
+        ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
                                                          vp, radii, geom.recA, geom.recB, geom.recC, geom.clamped,
                                                          geom.rect, geom.key0, geom.ord0);
+        }
         KERNEL_OK("preprocess_kernel");
         uint32_t* keys_sorted;
+        {
+        ProfScope ps(PS_SORT_DEPTH, s);
         launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, (size_t)P, 32, geom.scratch, &keys_sorted,
                                 &order, s);
+        }
         KERNEL_OK("radix sort (depth)");
+        {
+        ProfScope ps(PS_SCAN_EMIT, s);
         gather_tiles_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, order, geom.rect, geom.tiles);
-        KERNEL_OK("gather_tiles_kernel");
         launch_exclusive_scan_u32(geom.tiles, geom.offsets, (size_t)P, geom.scratch, true, s);
+        }
         KERNEL_OK("scan");
         // the single device->host synchronisation of the op: the instance count sizes the binning buffers
         HIP_OK(hipMemcpyAsync(&I, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -402,15 +410,25 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.point_list, *v1 = bin.vals_alt;
         if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
         const unsigned pb = (unsigned)((P + 255) / 256);
+        {
+        ProfScope ps(PS_SCAN_EMIT, s);
         emit_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, order, geom.rect, geom.offsets, vp.gx, k0, v0);
+        }
         KERNEL_OK("emit_kernel");
         uint32_t *ks, *vs;
+        {
+        ProfScope ps(PS_SORT_TILE, s);
         launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s);
+        }
         KERNEL_OK("radix sort (tile)");
         if (vs != bin.point_list) return e3_fail(hipErrorUnknown, "internal: sorted list not in point_list");
+        {
+        ProfScope ps(PS_RANGES, s);
         tile_ranges_kernel<<<dim3((I + 255) / 256), dim3(256), 0, s>>>(I, ks, img.ranges);
+        }
         KERNEL_OK("tile_ranges_kernel");
     }
+    ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
         ntiles, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
         img.final_T, img.n_contrib);

@@ -1,0 +1,60 @@
+"""Event iteration loss, fused on the GPU through the C ABI.
+
+event_iteration_loss mirrors the loss block of train.py:165-203 built from
+utils/loss_utils.py:differentialable_event_simu (:234-249), rgb_to_LUVscale (:24-28) and
+l1_loss (:270-271); lambda_dssim is forced to 0 there (train.py:177) so the SSIM term vanishes.
+"""
+import torch
+
+from . import _lib
+
+
+class _EventLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur, gt_c):
+        L = _lib.lib()
+        dev = image.device
+        _, H, W = image.shape
+        prep = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        image_c, now_c, next_c = prep(image), prep(img_now), prep(img_next)
+        gi, gn, gx, gb = prep(gt_int), prep(gt_now), prep(gt_next), prep(gt_blur)
+        c_dev = c.detach().to(torch.float32).reshape(1).contiguous()
+        d_image, d_now, d_next = (torch.empty_like(image_c) for _ in range(3))
+        scalars = torch.empty(8, dtype=torch.float32, device=dev)
+        scratch = torch.empty(L.e3dgs_event_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.e3dgs_event_loss(W, H, _lib.ptr(image_c), _lib.ptr(now_c), _lib.ptr(next_c), _lib.ptr(gi),
+                                    _lib.ptr(gn), _lib.ptr(gx), _lib.ptr(gb), _lib.ptr(c_dev), float(gt_c),
+                                    _lib.ptr(d_image), _lib.ptr(d_now), _lib.ptr(d_next), _lib.ptr(scalars),
+                                    _lib.ptr(scratch), _lib.current_stream())
+        _lib.check(rc, "e3dgs_event_loss")
+        ctx.save_for_backward(d_image, d_now, d_next, scalars)
+        ctx.c_shape = c.shape
+        ctx.stats = scalars
+        return scalars[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        d_image, d_now, d_next, scalars = ctx.saved_tensors
+        return (d_image * g, d_now * g, d_next * g, (scalars[1] * g).reshape(ctx.c_shape), None, None, None, None,
+                None)
+
+
+def event_iteration_loss(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17):
+    """loss of train.py:165-203; `c` is the learnable contrast threshold (train.py:71-73)."""
+    if not image.is_cuda:
+        raise RuntimeError("event_iteration_loss runs on the GPU only (no CPU path)")
+    return _EventLoss.apply(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur, gt_c)
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-15, lr_b=0.0, period=0,
+               split=0):
+    """In-place fused Adam on one flat fp32 tensor (train.py:330-332; eps of gaussian_model.py:163)."""
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("adam_step_ needs contiguous fp32 GPU tensors")
+    with torch.cuda.device(param.device):
+        rc = _lib.lib().e3dgs_adam_step(param.numel(), _lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg),
+                                        _lib.ptr(exp_avg_sq), float(lr), beta1, beta2, eps, int(step), float(lr_b),
+                                        int(period), int(split), _lib.current_stream())
+    _lib.check(rc, "e3dgs_adam_step")

@@ -181,7 +181,20 @@ int e3dgs_event_loss(
  */
 int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg,
                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
-                    int step, void* stream);
+                    int step,
+                    float lr_b, int period, int split, /* period > 0: element i uses lr if (i % period) < split else lr_b
+                                                          (f_dc / f_rest groups interleaved in one (P,16,3) tensor) */
+                    void* stream);
+
+/*
+ * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
+ * Slots: 0 preprocess, 1 sort_depth, 2 scan_emit, 3 sort_tile, 4 tile_ranges, 5 render_fwd,
+ *        6 render_bwd, 7 geom_bwd.  enable(1) resets the counters; query() synchronises the
+ * recorded events and returns the accumulated milliseconds and the number of launches.
+ */
+void e3dgs_profile_enable(int on);
+int e3dgs_profile_query(int slot, double* total_ms, int* launches);
+const char* e3dgs_profile_slot_name(int slot);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,8 @@ def lib():
         f.restype = vp
         f.argtypes = [vp]
     L.gso_free.argtypes = [vp]
+    L.gso_set_tile_rows.argtypes = [C.c_int, C.c_int]
+    L.gso_timings.argtypes = [vp, C.POINTER(C.c_double)]
     L.gso_backward.argtypes = [vp, fp] + [fp] * 9
     L.gso_exp_det.restype = C.c_float
     L.gso_exp_det.argtypes = [C.c_float]
@@ -88,8 +90,10 @@ class Forward:
 
     def __init__(self, *, means3D, opacities, viewmatrix, projmatrix, campos, bg, width, height, tanfovx, tanfovy,
                  colors_precomp=None, shs=None, sh_degree=0, scales=None, rotations=None, cov3D_precomp=None,
-                 scale_modifier=1.0):
+                 scale_modifier=1.0, tile_rows=None):
         L = lib()
+        if tile_rows is not None:
+            L.gso_set_tile_rows(int(tile_rows[0]), int(tile_rows[1]))
         self._keep = []
         def f(a):
             arr, p = _f(a)
@@ -113,6 +117,9 @@ class Forward:
             float(tanfovx), float(tanfovy), self.out_color.ctypes.data_as(C.POINTER(C.c_float)),
             self.radii.ctypes.data_as(C.POINTER(C.c_int)))
         self.num_rendered = int(L.gso_num_rendered(self._ctx))
+        tm = (C.c_double * 3)()
+        L.gso_timings(self._ctx, tm)
+        self.timings = tuple(tm)
 
     def _get(self, name, dtype, shape):
         return _view(getattr(lib(), "gso_" + name)(self._ctx), dtype, shape)

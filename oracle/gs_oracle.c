@@ -33,6 +33,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---- named constants of the algorithm ---- */
 #define TILE_X 16
@@ -95,7 +96,14 @@ typedef struct {
     uint32_t *ranges; /* 2 per tile */
     float *final_T;
     uint32_t *n_contrib;
+    int row0, row1;      /* tile-row window composited (bench cpu_baseline sample); default all */
+    double t_pre, t_bin, t_comp;
 } GsoCtx;
+
+/* Optional tile-row window for the NEXT gso_forward (bench.py bounded CPU sample). */
+static int g_row0 = 0, g_row1 = 1 << 30;
+void gso_set_tile_rows(int r0, int r1) { g_row0 = r0; g_row1 = r1; }
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 /* ---------- SH colour (only when `shs` is given; render() never does) ---------- */
 static void sh_to_rgb(const GsoCtx *c, int idx, float *rgb, uint8_t *clamped) {
@@ -295,7 +303,7 @@ static void binning(GsoCtx *c) {
 
 static void composite(GsoCtx *c, float *out) {
     const int W = c->W, H = c->H;
-    for (int ty = 0; ty < c->gy; ++ty)
+    for (int ty = (c->row0 > 0 ? c->row0 : 0); ty < c->gy && ty < c->row1; ++ty)
         for (int tx = 0; tx < c->gx; ++tx) {
             uint32_t lo = c->ranges[2 * (ty * c->gx + tx)], hi = c->ranges[2 * (ty * c->gx + tx) + 1];
             for (int py = ty * TILE_Y; py < (ty + 1) * TILE_Y && py < H; ++py)
@@ -354,14 +362,21 @@ GsoCtx *gso_forward(int P, int D, int M, const float *bg, int W, int H, const fl
     c->ranges = (uint32_t *)calloc((size_t)c->T, 8);
     c->final_T = (float *)calloc((size_t)W * H, 4);
     c->n_contrib = (uint32_t *)calloc((size_t)W * H, 4);
+    c->row0 = g_row0; c->row1 = g_row1;
+    g_row0 = 0; g_row1 = 1 << 30;
+    double t0 = now_s();
     preprocess(c);
+    double t1 = now_s();
     binning(c);
+    double t2 = now_s();
     composite(c, out_color);
+    c->t_pre = t1 - t0; c->t_bin = t2 - t1; c->t_comp = now_s() - t2;
     if (radii) memcpy(radii, c->radii, (size_t)P * 4);
     return c;
 }
 
 int64_t gso_num_rendered(const GsoCtx *c) { return c->I; }
+void gso_timings(const GsoCtx *c, double *out3) { out3[0] = c->t_pre; out3[1] = c->t_bin; out3[2] = c->t_comp; }
 const float *gso_depth(const GsoCtx *c) { return c->depth; }
 const float *gso_xy(const GsoCtx *c) { return c->xy; }
 const float *gso_conic_opacity(const GsoCtx *c) { return c->conic_o; }
@@ -394,7 +409,7 @@ static void composite_backward(const GsoCtx *c, const float *dL_dpix, PixAcc *ac
     const int W = c->W, H = c->H;
     const size_t HW = (size_t)H * W;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-    for (int ty = 0; ty < c->gy; ++ty)
+    for (int ty = (c->row0 > 0 ? c->row0 : 0); ty < c->gy && ty < c->row1; ++ty)
         for (int tx = 0; tx < c->gx; ++tx) {
             uint32_t lo = c->ranges[2 * (ty * c->gx + tx)];
             for (int py = ty * TILE_Y; py < (ty + 1) * TILE_Y && py < H; ++py)
