@@ -94,8 +94,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
                 const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
                 if (valid) {
                     any = true;
-                    const float one_m = 1.0f - alpha;
-                    T[k] = T[k] / one_m;
+                    // backward is tolerance-checked (atomics reorder sums anyway): 1-ulp v_rcp_f32
+                    const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T[k] = T[k] * inv_one_m;
                     const float dch = alpha * T[k];
                     acc0[k] = FMA(last_alpha[k], lc0[k], (1.0f - last_alpha[k]) * acc0[k]);
                     acc1[k] = FMA(last_alpha[k], lc1[k], (1.0f - last_alpha[k]) * acc1[k]);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
                     g_c2 = FMA(dch, dp2[k], g_c2);
                     dL_dalpha = dL_dalpha * T[k];
                     last_alpha[k] = alpha;
-                    dL_dalpha = FMA(-Tfin[k] / one_m, bgdot[k], dL_dalpha);
+                    dL_dalpha = FMA(-(Tfin[k] * inv_one_m), bgdot[k], dL_dalpha);
                     const float dL_dG = b.y * dL_dalpha;     // straight-through min(0.99, .)
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = FMA(-gdx, a.z, -(gdy * a.w));

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/e3dgs_hip.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 thread_local char g_err[512] = "";
@@ -10,6 +11,9 @@ int e3_fail(hipError_t e, const char* what) {
     snprintf(g_err, sizeof g_err, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
     return e == hipSuccess ? -1 : (int)e;
 }
+
+// exact tile culling (forward.hip: tile_touched); E3DGS_TILE_CULL=0 in the environment disables it
+int g_tile_cull = [] { const char* e = getenv("E3DGS_TILE_CULL"); return (e && e[0] == '0') ? 0 : 1; }();
 
 // ---- event profiler
 bool g_prof_on = false;
@@ -147,6 +151,9 @@ int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, f
     return e3_adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, lr_b, period, split,
                         (hipStream_t)stream);
 }
+
+void e3dgs_set_tile_cull(int on) { g_tile_cull = on ? 1 : 0; }
+int e3dgs_get_tile_cull(void) { return g_tile_cull; }
 
 void e3dgs_profile_enable(int on) {
     g_prof_on = on != 0;

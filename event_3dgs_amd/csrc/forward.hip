@@ -172,32 +172,116 @@ __device__ __forceinline__ uint32_t rect_area(uint2 r) {
     return w * h;
 }
 
-__global__ __launch_bounds__(256) void gather_tiles_kernel(int P, const uint32_t* __restrict__ order,
-                                                           const uint2* __restrict__ rect,
-                                                           uint32_t* __restrict__ tiles) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P) return;
-    tiles[s] = rect_area(rect[order[s]]);
+// ------------------------------------------------------------------------------------ binning
+// Conservative "does this Gaussian reach any pixel of this tile" test.  A pixel receives a
+// contribution only if alpha = o*exp(power) >= 1/255, i.e. q(d) = A dx^2 + 2B dx dy + C dy^2
+// <= 2 ln(255 o).  The minimum of the convex quadratic q over the tile's pixel box is either 0
+// (centre inside) or attained on one of the four edges (1-D clamped minimiser).  Instances whose
+// minimum exceeds the bound by a safety margin (1e-4 relative + 1e-3 absolute, orders of magnitude
+// above fp32 rounding) contribute to no pixel, so dropping them leaves image and gradients
+// bit-identical while shrinking the sorted lists (~1.8x on the benchmark scene).
+__device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float B, float C, float thr, int tx, int ty) {
+    if (!(A > 0.0f) || !(C > 0.0f)) return true;   // degenerate / NaN conic: never cull
+    const float pxl = (float)(tx * E3_TILE), pyl = (float)(ty * E3_TILE);
+    const float dxlo = x0 - (pxl + (float)(E3_TILE - 1)), dxhi = x0 - pxl;
+    const float dylo = y0 - (pyl + (float)(E3_TILE - 1)), dyhi = y0 - pyl;
+    float qmin = 0.0f;
+    if (!(dxlo <= 0.0f && dxhi >= 0.0f && dylo <= 0.0f && dyhi >= 0.0f)) {
+        const float B2 = 2.0f * B;
+        auto qadj = [&](float dx, float dy) {
+            float t0 = A * dx * dx, t1 = B2 * dx * dy, t2 = C * dy * dy;
+            return (t0 + t1 + t2) - 1e-4f * (fabsf(t0) + fabsf(t1) + fabsf(t2));
+        };
+        const float iC = -B / C, iA = -B / A;
+        float q0 = qadj(dxlo, fminf(dyhi, fmaxf(dylo, iC * dxlo)));
+        float q1 = qadj(dxhi, fminf(dyhi, fmaxf(dylo, iC * dxhi)));
+        float q2 = qadj(fminf(dxhi, fmaxf(dxlo, iA * dylo)), dylo);
+        float q3 = qadj(fminf(dxhi, fmaxf(dxlo, iA * dyhi)), dyhi);
+        qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+    }
+    return !(qmin > thr);
 }
 
-// one thread per depth-sorted Gaussian; row-major over its tile rectangle (y outer, x inner)
-__global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __restrict__ order,
-                                                   const uint2* __restrict__ rect,
-                                                   const uint32_t* __restrict__ offsets, int gx,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P) return;
-    uint32_t g = order[s];
-    uint2 r = rect[g];
-    uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu, ymax = r.y >> 16;
-    if (xmax == xmin || ymax == ymin) return;
-    uint32_t off = s == 0 ? 0u : offsets[s - 1];
-    for (uint32_t y = ymin; y < ymax; ++y)
-        for (uint32_t x = xmin; x < xmax; ++x) {
-            keys[off] = y * (uint32_t)gx + x;
-            vals[off] = g;
-            ++off;
+// Flattened, wave-cooperative binning.  A wave owns 64 consecutive depth-sorted Gaussians; the
+// union of their tile rectangles is walked 64 candidate (Gaussian, tile) items at a time, so lanes
+// stay busy whatever the individual splat sizes are.  EMIT=false counts the kept items per wave
+// (-> exclusive scan -> total instance count I); EMIT=true replays the identical walk and writes
+// (tile id, Gaussian id) compacted with a ballot prefix.  Emission order = depth order of the
+// Gaussians, row-major inside a rectangle -- exactly the order the reference's per-Gaussian loop
+// produces, so a stable sort on the tile id alone finishes the job.
+constexpr int BIN_WAVES = 4;
+template <bool EMIT>
+__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint32_t* __restrict__ order,
+                                                              const uint2* __restrict__ rect,
+                                                              const float4* __restrict__ recA,
+                                                              const float4* __restrict__ recB, int gx, int cull,
+                                                              const uint32_t* __restrict__ wave_offsets,
+                                                              uint32_t* __restrict__ wave_counts,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
+    __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
+    __shared__ uint32_t sIncl[BIN_WAVES][WAVE];
+    __shared__ uint32_t sId[BIN_WAVES][WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * BIN_WAVES + wave;
+    const int s = gw * WAVE + lane;
+    if (gw * WAVE >= P) return;
+    uint32_t n = 0, g = 0;
+    float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+    if (s < P) {
+        g = order[s];
+        uint2 r = rect[g];
+        uint32_t w = (r.y & 0xFFFFu) - (r.x & 0xFFFFu), h = (r.y >> 16) - (r.x >> 16);
+        n = w * h;
+        if (n) {
+            a = recA[g];
+            float4 t = recB[g];
+            // 2 ln(255 o) with the safety margin folded in; o <= 0 -> -inf -> nothing kept
+            float thr = 2.0f * logf(255.0f * t.y);
+            thr = thr + fabsf(thr) * 1e-4f + 1e-3f;
+            b = make_float4(t.x, thr, __uint_as_float(r.x), __uint_as_float(w));
         }
+    }
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    sA[wave][lane] = a; sB[wave][lane] = b; sIncl[wave][lane] = incl; sId[wave][lane] = g;
+    wave_sync();
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t count = 0;
+    const uint32_t out_base = EMIT ? wave_offsets[gw] : 0u;
+    for (uint32_t m0 = 0; m0 < total; m0 += WAVE) {
+        const uint32_t m = m0 + lane;
+        const bool active = m < total;
+        // smallest j with incl[j] > m
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            int mid = (lo + hi) >> 1;
+            if (sIncl[wave][mid] > m) hi = mid; else lo = mid + 1;
+        }
+        const int j = lo;
+        const uint32_t excl = j ? sIncl[wave][j - 1] : 0u;
+        const float4 A4 = sA[wave][j], B4 = sB[wave][j];
+        const uint32_t k = m - excl, w = __float_as_uint(B4.w), xy0 = __float_as_uint(B4.z);
+        uint32_t row = (uint32_t)(((float)k + 0.5f) / (float)w);   // w, k < 2^24: exact after the fix-up
+        if (row * w > k) --row;
+        if ((row + 1) * w <= k) ++row;
+        const int tx = (int)((xy0 & 0xFFFFu) + (k - row * w)), ty = (int)((xy0 >> 16) + row);
+        const bool keep = active && (!cull || tile_touched(A4.x, A4.y, A4.z, A4.w, B4.x, B4.y, tx, ty));
+        const uint64_t mask = __ballot(keep);
+        if (EMIT && keep) {
+            const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
+            keys[pos] = (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+            vals[pos] = sId[wave][j];
+        }
+        count += (uint32_t)__popcll(mask);
+    }
+    if (!EMIT && lane == 0) wave_counts[gw] = count;
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint32_t* __restrict__ keys,
@@ -321,6 +405,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
 
 // ------------------------------------------------------------------------------------ host driver
 extern thread_local char g_err[512];
+extern int g_tile_cull;
 int e3_fail(hipError_t e, const char* what);
 #define HIP_OK(expr)                                          \
     do {                                                      \
@@ -388,14 +473,19 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
                                 &order, s);
         }
         KERNEL_OK("radix sort (depth)");
+        const unsigned nwaves = (unsigned)((P + WAVE - 1) / WAVE);
+        const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
+        HIP_OK(hipMemsetAsync(geom.offsets, 0, sizeof(uint32_t), s));
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        gather_tiles_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, order, geom.rect, geom.tiles);
-        launch_exclusive_scan_u32(geom.tiles, geom.offsets, (size_t)P, geom.scratch, true, s);
+        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.recA, geom.recB, vp.gx,
+                                                                     g_tile_cull, nullptr, geom.tiles, nullptr, nullptr);
+        // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
+        launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
         }
-        KERNEL_OK("scan");
+        KERNEL_OK("bin count + scan");
         // the single device->host synchronisation of the op: the instance count sizes the binning buffers
-        HIP_OK(hipMemcpyAsync(&I, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&I, geom.offsets + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
     }
     *num_rendered_host = (int)I;
@@ -409,12 +499,14 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
         // choose the emit target so that the final sorted values land in bin.point_list
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.point_list, *v1 = bin.vals_alt;
         if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
-        const unsigned pb = (unsigned)((P + 255) / 256);
+        const unsigned nwaves = (unsigned)((P + WAVE - 1) / WAVE);
+        const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        emit_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, order, geom.rect, geom.offsets, vp.gx, k0, v0);
+        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.recA, geom.recB, vp.gx,
+                                                                    g_tile_cull, geom.offsets, nullptr, k0, v0);
         }
-        KERNEL_OK("emit_kernel");
+        KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
         {
         ProfScope ps(PS_SORT_TILE, s);

@@ -117,6 +117,17 @@ int e3dgs_rasterize_backward(
     void* stream);
 
 /*
+ * Exact tile culling (default ON; environment E3DGS_TILE_CULL=0 turns it off at load time).
+ * The reference op bins every Gaussian into all tiles of its 3-sigma bounding rectangle.  With
+ * culling ON, (tile, Gaussian) instances that provably reach no pixel of the tile with
+ * alpha >= 1/255 are not emitted: image, radii and gradients are bit-identical, but
+ * num_rendered, the sorted lists and n_contrib index a sub-sequence of the reference's lists.
+ * Turn it OFF to reproduce the reference's integer binning exactly (used by the parity tests).
+ */
+void e3dgs_set_tile_cull(int on);
+int e3dgs_get_tile_cull(void);
+
+/*
  * Byte offsets of the members of the three scratch buffers, for tests and tools that want to
  * inspect intermediate state (sorted lists, tile ranges, per-pixel n_contrib).
  *   out[0..4]  geom:    recA (float4: x,y,conic.x,conic.y), recB (float4: conic.z,opacity,r,g),

@@ -85,7 +85,18 @@ def test_forward_backward_parity(N, W, H, use_sh, use_cov, bg, boost):
     assert np.all(grads["means2D"][:, 2] == 0)
 
 
-def test_intermediate_state_is_exact():
+@pytest.fixture
+def no_tile_cull():
+    """Reproduce the reference's integer binning exactly (all tiles of the 3-sigma rectangle)."""
+    from event_3dgs_amd import _lib
+    L = _lib.lib()
+    old = L.e3dgs_get_tile_cull()
+    L.e3dgs_set_tile_cull(0)
+    yield
+    L.e3dgs_set_tile_cull(old)
+
+
+def test_intermediate_state_is_exact(no_tile_cull):
     """Sorted (tile, depth, index) lists, tile ranges and n_contrib match the oracle exactly."""
     from event_3dgs_amd import rasterizer
     from oracle import c_oracle
@@ -113,6 +124,46 @@ def test_intermediate_state_is_exact():
     rect = st["rect"].cpu().numpy().astype(np.uint32)
     unpacked = np.stack([rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, rect[:, 1] >> 16], -1)
     assert np.array_equal(unpacked[vis].astype(np.int32), f.rect[vis])
+
+
+@pytest.mark.parametrize("boost", [1.0, 2.5])
+def test_tile_culling_changes_lists_but_not_results(boost):
+    """Default mode drops (tile, Gaussian) instances that reach no pixel: the kept list is a
+    sub-sequence of the reference list, the image stays bit-identical, gradients agree."""
+    from event_3dgs_amd import _lib, rasterizer
+    from oracle import c_oracle
+    L = _lib.lib()
+    assert L.e3dgs_get_tile_cull() == 1
+    dev = torch.device("cuda:0")
+    N, W, H = 4000, 208, 144
+    act, cam = scene(N, W, H, seed=21, scale_boost=boost)
+    bg = (0.05, 0.1, 0.2)
+    rs = _settings(cam, bg, dev)
+    d = lambda t: t.to(dev)
+    raw = rasterizer.forward_raw(d(act["means3D"]), d(act["shs"]), None, d(act["opacities"]), d(act["scales"]),
+                                 d(act["rotations"]), None, rs)
+    torch.cuda.synchronize()
+    f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, False))
+    assert np.array_equal(raw["color"].cpu().numpy(), f.out_color)
+    assert np.array_equal(raw["radii"].cpu().numpy(), f.radii)
+    assert 0 < raw["num_rendered"] < f.num_rendered
+    st = rasterizer.state_views(raw, N, W, H)
+    pl, rg = st["point_list"].cpu().numpy().astype(np.uint32), st["ranges"].cpu().numpy().astype(np.int64)
+    kept = 0
+    for t in range(rg.shape[0]):                      # per tile: kept ids appear in the reference order
+        mine = pl[rg[t, 0]:rg[t, 1]]
+        ref = f.point_list[f.ranges[t, 0]:f.ranges[t, 1]]
+        pos = {int(g): i for i, g in enumerate(ref)}
+        idx = [pos[int(g)] for g in mine]             # KeyError = instance the reference does not have
+        assert idx == sorted(idx)
+        kept += len(mine)
+    assert kept == raw["num_rendered"]
+    # final transmittance identical -> every dropped instance really contributed nothing
+    assert np.array_equal(st["final_T"].cpu().numpy(), f.final_T)
+    img, radii, grads, gw = _run_hip(act, cam, bg, True, False)
+    gb = f.backward(gw)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations", "means2D"):
+        assert rel_l2(grads[k], gb[k].reshape(grads[k].shape)) <= GRAD_TOL, k
 
 
 def test_edge_cases_empty_and_culled():
