@@ -8,21 +8,28 @@
 //   geom_bwd_kernel    a20+a21 fused: conic -> Sigma2 -> Sigma3 and view-space mean, NDC mean through
 //                           the projection, SH backward, Sigma3 -> scale / quaternion.
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int BWD_WAVES = 4;
 
+int tile_stride_for(int ntiles);
+__device__ __forceinline__ int tile_of(int unit, int ntiles, int stride) {
+    if (unit >= ntiles) return ntiles;
+    return (int)(((long long)unit * stride) % ntiles);
+}
+
 __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
-    int ntiles, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ recA, const float4* __restrict__ recB, const float* __restrict__ recC,
+    int ntiles, int tile_stride, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D /*P,3*/, float* __restrict__ dL_dconic /*P,4*/,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor /*P,3*/) {
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor /*P,3*/, int dbg) {
     __shared__ float4 sA[BWD_WAVES][WAVE];
     __shared__ float4 sB[BWD_WAVES][WAVE];
-    __shared__ float sC[BWD_WAVES][WAVE];
+    __shared__ float2 sC[BWD_WAVES][WAVE];
     __shared__ uint32_t sId[BWD_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * BWD_WAVES + wave;
+    const int tile = tile_of(blockIdx.x * BWD_WAVES + wave, ntiles, tile_stride);
     if (tile >= ntiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * E3_TILE + (lane & 15);
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
 
     // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
-    float rc = 0.0f;
+    float2 rc = make_float2(0, 0);
     uint32_t rid = 0;
     if (lane < n) {
         rid = point_list[range.x + (uint32_t)(n - 1 - lane)];
@@ -75,70 +82,73 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
-            const float cb = sC[wave][j];
+            const float2 c = sC[wave][j];
+            const float cb = c.x;
             const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
             const float qx = cxdx * dx;
             const float cydx = a.w * dx;
-            float g_mx = 0.0f, g_my = 0.0f, g_A = 0.0f, g_B = 0.0f, g_C = 0.0f, g_o = 0.0f, g_c0 = 0.0f, g_c1 = 0.0f,
-                  g_c2 = 0.0f;
+            // per-lane partial sums over its (up to) 4 pixels; h = dL/dG * G
+            //   Sx = sum h dx, Sy = sum h dy, Sxx = sum h dx^2, Sxy = sum h dx dy, Syy = sum h dy^2,
+            //   So = sum G dL/dalpha, Sc* = sum alpha T dL/dC*
+            float Sx = 0.0f, Sy = 0.0f, Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, So = 0.0f, Sc0 = 0.0f, Sc1 = 0.0f, Sc2 = 0.0f;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dy = a.y - pfy[k];
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
-                const float G = exp_det(power);
-                const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
-                const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
-                if (valid) {
-                    any = true;
-                    // backward is tolerance-checked (atomics reorder sums anyway): 1-ulp v_rcp_f32
-                    const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T[k] = T[k] * inv_one_m;
-                    const float dch = alpha * T[k];
-                    acc0[k] = FMA(last_alpha[k], lc0[k], (1.0f - last_alpha[k]) * acc0[k]);
-                    acc1[k] = FMA(last_alpha[k], lc1[k], (1.0f - last_alpha[k]) * acc1[k]);
-                    acc2[k] = FMA(last_alpha[k], lc2[k], (1.0f - last_alpha[k]) * acc2[k]);
-                    lc0[k] = b.z; lc1[k] = b.w; lc2[k] = cb;
-                    float dL_dalpha = (b.z - acc0[k]) * dp0[k];
-                    dL_dalpha = FMA(b.w - acc1[k], dp1[k], dL_dalpha);
-                    dL_dalpha = FMA(cb - acc2[k], dp2[k], dL_dalpha);
-                    g_c0 = FMA(dch, dp0[k], g_c0);
-                    g_c1 = FMA(dch, dp1[k], g_c1);
-                    g_c2 = FMA(dch, dp2[k], g_c2);
-                    dL_dalpha = dL_dalpha * T[k];
-                    last_alpha[k] = alpha;
-                    dL_dalpha = FMA(-(Tfin[k] * inv_one_m), bgdot[k], dL_dalpha);
-                    const float dL_dG = b.y * dL_dalpha;     // straight-through min(0.99, .)
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = FMA(-gdx, a.z, -(gdy * a.w));
-                    const float dG_ddely = FMA(-gdy, b.x, -(gdx * a.w));
-                    g_mx = FMA(dL_dG * dG_ddelx, ddelx_dx, g_mx);
-                    g_my = FMA(dL_dG * dG_ddely, ddely_dy, g_my);
-                    g_A = FMA(-0.5f * gdx * dx, dL_dG, g_A);
-                    g_B = FMA(-(gdx * dy), dL_dG, g_B);
-                    g_C = FMA(-0.5f * gdy * dy, dL_dG, g_C);
-                    g_o = FMA(G, dL_dalpha, g_o);
+                const bool live = (contributor <= last[k]) && !(power > 0.0f) && (power >= c.y);
+                if (__any(live)) {
+                    const float G = exp_det_noclamp(power);
+                    const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
+                    const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
+                    if (valid && !(dbg & 4)) {
+                        any = true;
+                        // backward is tolerance-checked (atomics reorder sums anyway): 1-ulp v_rcp_f32
+                        const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
+                        T[k] = T[k] * inv_one_m;
+                        const float dch = alpha * T[k];
+                        const float om_la = 1.0f - last_alpha[k];
+                        acc0[k] = FMA(last_alpha[k], lc0[k], om_la * acc0[k]);
+                        acc1[k] = FMA(last_alpha[k], lc1[k], om_la * acc1[k]);
+                        acc2[k] = FMA(last_alpha[k], lc2[k], om_la * acc2[k]);
+                        lc0[k] = b.z; lc1[k] = b.w; lc2[k] = cb;
+                        float dL_dalpha = (b.z - acc0[k]) * dp0[k];
+                        dL_dalpha = FMA(b.w - acc1[k], dp1[k], dL_dalpha);
+                        dL_dalpha = FMA(cb - acc2[k], dp2[k], dL_dalpha);
+                        Sc0 = FMA(dch, dp0[k], Sc0);
+                        Sc1 = FMA(dch, dp1[k], Sc1);
+                        Sc2 = FMA(dch, dp2[k], Sc2);
+                        dL_dalpha = dL_dalpha * T[k];
+                        last_alpha[k] = alpha;
+                        dL_dalpha = FMA(-(Tfin[k] * inv_one_m), bgdot[k], dL_dalpha);
+                        So = FMA(G, dL_dalpha, So);
+                        const float h = (b.y * dL_dalpha) * G;      // straight-through min(0.99, .)
+                        const float hx = h * dx, hy = h * dy;
+                        Sx += hx; Sy += hy;
+                        Sxx = FMA(hx, dx, Sxx); Sxy = FMA(hx, dy, Sxy); Syy = FMA(hy, dy, Syy);
+                    }
                 }
             }
-            if (__any(any)) {
-                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-                g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
-                g_o = wave_sum_to_lane63(g_o);
-                g_c0 = wave_sum_to_lane63(g_c0); g_c1 = wave_sum_to_lane63(g_c1); g_c2 = wave_sum_to_lane63(g_c2);
-                if (lane == 63) {
+            if (__any(any) && !(dbg & 2)) {
+                Sx = wave_sum_to_lane63(Sx); Sy = wave_sum_to_lane63(Sy);
+                Sxx = wave_sum_to_lane63(Sxx); Sxy = wave_sum_to_lane63(Sxy); Syy = wave_sum_to_lane63(Syy);
+                So = wave_sum_to_lane63(So);
+                Sc0 = wave_sum_to_lane63(Sc0); Sc1 = wave_sum_to_lane63(Sc1); Sc2 = wave_sum_to_lane63(Sc2);
+                if (lane == 63 && !(dbg & 1)) {
                     const uint32_t id = sId[wave][j];
-                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], g_mx);
-                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], g_my);
-                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], g_A);
-                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], g_B);
-                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 2], g_C);
-                    unsafeAtomicAdd(&dL_dopacity[id], g_o);
-                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 0], g_c0);
-                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 1], g_c1);
-                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 2], g_c2);
+                    // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
+                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], -(a.z * Sx + a.w * Sy) * ddelx_dx);
+                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], -(b.x * Sy + a.w * Sx) * ddely_dy);
+                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], -0.5f * Sxx);
+                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], -Sxy);
+                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 2], -0.5f * Syy);
+                    unsafeAtomicAdd(&dL_dopacity[id], So);
+                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 0], Sc0);
+                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 1], Sc1);
+                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 2], Sc2);
                 }
             }
         }
@@ -381,8 +391,8 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     if (num_rendered > 0) {
         ProfScope ps(PS_RENDER_BWD, s);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            ntiles, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
-            img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+            ntiles, tile_stride_for(ntiles), vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
+            img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, getenv("E3DGS_DBG") ? atoi(getenv("E3DGS_DBG")) : 0);
     }
     KERNEL_OK("render_bwd_kernel");
     {

@@ -35,6 +35,20 @@ __device__ __forceinline__ float exp_det(float x) {
     p = FMA(p, f, 1.0f);
     return __builtin_ldexpf(p, (int)n);
 }
+// Same value wherever o*exp can reach 1/255; without the underflow clamp (v_cvt_i32_f32 saturates and
+// v_ldexp_f32 flushes to 0, so far-negative arguments give 0 instead of ~2^-126: both are < 1/255).
+__device__ __forceinline__ float exp_det_noclamp(float x) {
+    float t = x * 1.4426950408889634f;
+    float n = __builtin_rintf(t);
+    float f = t - n;
+    float p = 0.0013218672247603536f;
+    p = FMA(p, f, 0.009671698324382305f);
+    p = FMA(p, f, 0.05550893023610115f);
+    p = FMA(p, f, 0.24022237956523895f);
+    p = FMA(p, f, 0.6931468844413757f);
+    p = FMA(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
 
 // flat[4*c + r]: row r of the column-vector matrix applied to (x,y,z,1)
 #define XFORM(M, r, x, y, z) FMA((M)[(r)], (x), FMA((M)[4 + (r)], (y), FMA((M)[8 + (r)], (z), (M)[12 + (r)])))
@@ -98,7 +112,7 @@ static inline size_t sort_scratch_words(size_t n) {
 struct GeomState {
     float4* recA;      // (x, y, conic.x, conic.y)
     float4* recB;      // (conic.z, opacity, r, g)
-    float* recC;       // b
+    float2* recC;      // (b, pmin): alpha >= 1/255 needs power >= pmin = -(ln(255 o) + margin)
     uint32_t* clamped; // SH clamp bitmask (bit ch)
     uint2* rect;       // packed tile rectangle: .x = xmin | ymin<<16, .y = xmax | ymax<<16
     uint32_t* key0;    // depth keys (ping)
@@ -119,7 +133,7 @@ struct GeomState {
         size_t n = P ? P : 1;
         g.recA = carve<float4>(p, n);
         g.recB = carve<float4>(p, n);
-        g.recC = carve<float>(p, n);
+        g.recC = carve<float2>(p, n);
         g.clamped = carve<uint32_t>(p, n);
         g.rect = carve<uint2>(p, n);
         g.key0 = carve<uint32_t>(p, n);

@@ -14,6 +14,7 @@
 // The two-level sort (depth on P Gaussians, then tile on I instances) yields exactly the order
 // of the reference's single 64-bit (tile<<32 | depth) stable sort with 6x less sort traffic.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ SH colour
 __device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, float mx, float my, float mz,
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
     const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewParams vp, int* __restrict__ radii,
-    float4* __restrict__ recA, float4* __restrict__ recB, float* __restrict__ recC, uint32_t* __restrict__ clamped,
+    float4* __restrict__ recA, float4* __restrict__ recB, float2* __restrict__ recC, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -153,7 +154,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 }
                 recA[i] = make_float4(px, py, conx, cony);
                 recB[i] = make_float4(conz, opac[i], rgb[0], rgb[1]);
-                recC[i] = rgb[2];
+                // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
+                // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
+                const float o_ = opac[i];
+                recC[i] = make_float2(rgb[2], -(logf(255.0f * o_) + 1e-3f));
                 clamped[i] = cl;
                 radius_out = radius;
                 rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
@@ -177,8 +181,8 @@ __device__ __forceinline__ uint32_t rect_area(uint2 r) {
 // contribution only if alpha = o*exp(power) >= 1/255, i.e. q(d) = A dx^2 + 2B dx dy + C dy^2
 // <= 2 ln(255 o).  The minimum of the convex quadratic q over the tile's pixel box is either 0
 // (centre inside) or attained on one of the four edges (1-D clamped minimiser).  Instances whose
-// minimum exceeds the bound by a safety margin (1e-4 relative + 1e-3 absolute, orders of magnitude
-// above fp32 rounding) contribute to no pixel, so dropping them leaves image and gradients
+// minimum exceeds the bound by a safety margin (1e-4 of the summed |terms| + an absolute slack folded
+// into `thr` by the caller, orders of magnitude above fp32 rounding) contribute to no pixel, so dropping them leaves image and gradients
 // bit-identical while shrinking the sorted lists (~1.8x on the benchmark scene).
 __device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float B, float C, float thr, int tx, int ty) {
     if (!(A > 0.0f) || !(C > 0.0f)) return true;   // degenerate / NaN conic: never cull
@@ -237,8 +241,10 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
             a = recA[g];
             float4 t = recB[g];
             // 2 ln(255 o) with the safety margin folded in; o <= 0 -> -inf -> nothing kept
+            // margins: see tile_touched(); the Lambda term bounds the rounding of the compositing kernels'
+            // own `power` at any pixel of the tile (|terms| <= 2(|terms at the minimiser| + Lambda*15^2*2))
             float thr = 2.0f * logf(255.0f * t.y);
-            thr = thr + fabsf(thr) * 1e-4f + 1e-3f;
+            thr = thr + fabsf(thr) * 1e-4f + 1e-3f + 2e-3f * (fabsf(a.z) + 2.0f * fabsf(a.w) + fabsf(t.x));
             b = make_float4(t.x, thr, __uint_as_float(r.x), __uint_as_float(w));
         }
     }
@@ -300,43 +306,52 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint
 // them with broadcast ds_read_b128; the next round's gathers are in flight meanwhile.
 constexpr int RENDER_WAVES = 4;
 
+// Work-unit -> tile permutation.  Consecutive workgroups land on the same CU, and neighbouring tiles
+// have correlated list lengths, so the identity map leaves whole CUs with only light (or only heavy)
+// tiles.  u -> (u * stride) mod ntiles with gcd(stride, ntiles) = 1 is a bijection that spreads them.
+__device__ __forceinline__ int tile_of(int unit, int ntiles, int stride) {
+    if (unit >= ntiles) return ntiles;
+    return (int)(((long long)unit * stride) % ntiles);
+}
+
 __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
-    int ntiles, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ recA, const float4* __restrict__ recB, const float* __restrict__ recC,
+    int ntiles, int tile_stride, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
     const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
     __shared__ float4 sB[RENDER_WAVES][WAVE];
-    __shared__ float sC[RENDER_WAVES][WAVE];
+    __shared__ float2 sC[RENDER_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * RENDER_WAVES + wave;
+    const int tile = tile_of(blockIdx.x * RENDER_WAVES + wave, ntiles, tile_stride);
     if (tile >= ntiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
     const float pfx = (float)px;
+    // T[k] > 0: pixel live.  A finished (or out-of-image) pixel keeps -T, so "done" costs no flag register.
     float pfy[4], T[4], C0[4], C1[4], C2[4];
     uint32_t last[4];
-    bool done[4], inside[4];
+    bool inside[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int py = py0 + 4 * k;
         pfy[k] = (float)py;
         inside[k] = (px < W) && (py < H);
-        done[k] = !inside[k];
-        T[k] = 1.0f; C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
+        T[k] = inside[k] ? 1.0f : -1.0f;
+        C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
     }
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
-    float rc = 0.0f;
+    float2 rc = make_float2(0, 0);
     if (lane < n) {
         uint32_t id = point_list[range.x + lane];
         ra = recA[id]; rb = recB[id]; rc = recC[id];
     }
     for (int base = 0; base < n; base += WAVE) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        if (__builtin_amdgcn_ballot_w64(T[0] > 0.0f || T[1] > 0.0f || T[2] > 0.0f || T[3] > 0.0f) == 0) break;
         const int cnt = min(WAVE, n - base);
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
         wave_sync();
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
-            const float cb = sC[wave][j];
+            const float2 c = sC[wave][j];
             const uint32_t contributor = (uint32_t)(base + j + 1);
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
@@ -355,26 +370,31 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
             const float cydx = a.w * dx;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                // lanes of one k form a 16x4 pixel strip: skip the strip when no pixel can reach alpha >= 1/255
                 const float dy = a.y - pfy[k];
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
-                const float G = exp_det(power);
-                const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
-                const bool valid = !done[k] && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
-                const float test_T = T[k] * (1.0f - alpha);
-                const bool stop = valid && (test_T < E3_T_STOP);
-                const bool apply = valid && !stop;
-                const float w = alpha * T[k];
-                C0[k] = apply ? FMA(b.z, w, C0[k]) : C0[k];
-                C1[k] = apply ? FMA(b.w, w, C1[k]) : C1[k];
-                C2[k] = apply ? FMA(cb, w, C2[k]) : C2[k];
-                T[k] = apply ? test_T : T[k];
-                last[k] = apply ? contributor : last[k];
-                done[k] = done[k] || stop;
+                const bool live = (T[k] > 0.0f) && !(power > 0.0f) && (power >= c.y);
+                if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                    const float G = exp_det_noclamp(power);
+                    const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
+                    const bool valid = (T[k] > 0.0f) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
+                    const float w = alpha * T[k];
+                    const float test_T = T[k] - w;
+                    const bool stop = valid && (test_T < E3_T_STOP);
+                    const bool apply = valid && !stop;
+                    C0[k] = apply ? FMA(b.z, w, C0[k]) : C0[k];
+                    C1[k] = apply ? FMA(b.w, w, C1[k]) : C1[k];
+                    C2[k] = apply ? FMA(c.x, w, C2[k]) : C2[k];
+                    last[k] = apply ? contributor : last[k];
+                    T[k] = apply ? test_T : (stop ? -T[k] : T[k]);
+                }
             }
         }
         wave_sync();
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T[k] = fabsf(T[k]);
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
 #pragma unroll
@@ -421,6 +441,17 @@ int e3_fail(hipError_t e, const char* what);
             if (_e != hipSuccess) return e3_fail(_e, name);   \
         }                                                     \
     } while (0)
+
+int tile_stride_for(int ntiles) {
+    // E3DGS_TILE_STRIDE=1 restores the identity map (A/B measurements)
+    const char* e = getenv("E3DGS_TILE_STRIDE");
+    if (e) return atoi(e) > 0 ? atoi(e) : 1;
+    if (ntiles < 64) return 1;
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    int st = (int)(0.6180339887 * ntiles) | 1;      // golden-ratio stride: consecutive units far apart
+    while (gcd(st, ntiles) != 1) st += 2;
+    return st;
+}
 
 static int ceil_log2(uint32_t v) {
     int b = 0;
@@ -522,7 +553,7 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
     }
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        ntiles, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
+        ntiles, tile_stride_for(ntiles), vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
         img.final_T, img.n_contrib);
     KERNEL_OK("render_fwd_kernel");
     return 0;

@@ -127,7 +127,7 @@ def state_views(raw, P, W, H):
     g, b, im = raw["geom"], raw["binning"], raw["image"]
     return dict(
         recA=view(g, offs[0], torch.float32, 4 * P, (P, 4)), recB=view(g, offs[1], torch.float32, 4 * P, (P, 4)),
-        recC=view(g, offs[2], torch.float32, P, (P,)), clamped=view(g, offs[3], torch.int32, P, (P,)),
+        recC=view(g, offs[2], torch.float32, 2 * P, (P, 2)), clamped=view(g, offs[3], torch.int32, P, (P,)),
         rect=view(g, offs[4], torch.int32, 2 * P, (P, 2)),
         point_list=view(b, offs[5], torch.int32, I, (I,)),
         ranges=view(im, offs[6], torch.int32, 2 * gx * gy, (gx * gy, 2)),

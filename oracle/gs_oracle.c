@@ -323,9 +323,9 @@ static void composite(GsoCtx *c, float *out) {
                         float G = exp_det(power);
                         float alpha = fminf(ALPHA_CLAMP, o * G);
                         if (alpha < ALPHA_SKIP) continue;
-                        float test_T = T * (1.0f - alpha);
-                        if (test_T < T_STOP) break; /* pixel done; entry not applied */
                         float w = alpha * T;
+                        float test_T = T - w;   /* = T(1-alpha), one rounding less */
+                        if (test_T < T_STOP) break; /* pixel done; entry not applied */
                         C0 = FMA(c->rgb[3 * g], w, C0);
                         C1 = FMA(c->rgb[3 * g + 1], w, C1);
                         C2 = FMA(c->rgb[3 * g + 2], w, C2);
