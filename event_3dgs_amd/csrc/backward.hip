@@ -12,25 +12,26 @@
 
 constexpr int BWD_WAVES = 4;
 
-int tile_stride_for(int ntiles);
-__device__ __forceinline__ int tile_of(int unit, int ntiles, int stride) {
-    if (unit >= ntiles) return ntiles;
-    return (int)(((long long)unit * stride) % ntiles);
-}
-
+extern unsigned long long* g_trace;
 __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
-    int ntiles, int tile_stride, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D /*P,3*/, float* __restrict__ dL_dconic /*P,4*/,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor /*P,3*/, int dbg) {
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor /*P,3*/) {
     __shared__ float4 sA[BWD_WAVES][WAVE];
     __shared__ float4 sB[BWD_WAVES][WAVE];
     __shared__ float2 sC[BWD_WAVES][WAVE];
     __shared__ uint32_t sId[BWD_WAVES][WAVE];
+    // per-round gradient staging: lane 63 parks the 9 reduced sums of entry j here; at the end of the
+    // round lane l commits entry l, so the global atomics are 9 full-width instructions per 64 entries
+    // instead of 576 single-lane ones
+    __shared__ float4 sPart[BWD_WAVES][WAVE][3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = tile_of(blockIdx.x * BWD_WAVES + wave, ntiles, tile_stride);
-    if (tile >= ntiles) return;
+    const int unit = blockIdx.x * BWD_WAVES + wave;
+    if (unit >= ntiles) return;
+    const int tile = (int)order[unit];
+    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
@@ -39,8 +40,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-    float pfy[4], T[4], Tfin[4], dp0[4], dp1[4], dp2[4], bgdot[4];
-    float acc0[4], acc1[4], acc2[4], lc0[4], lc1[4], lc2[4], last_alpha[4];
+    // Per-pixel state of the back-to-front walk.  With C = sum_j c_j a_j T_j + T_final bg and
+    // T_j = prod_{i<j}(1 - a_i):   dC/da_g = c_g T_g - (sum_{j>g} c_j a_j T_j + T_final bg) / (1 - a_g).
+    // Contracting with dL/dC first leaves ONE scalar running sum per pixel,
+    //   Q_g = T_final (bg . dL/dC) + sum_{j>g} a_j T_j (c_j . dL/dC),
+    // instead of the reference's accumulated colour / last colour / last alpha (7 registers -> 1).
+    float pfy[4], T[4], Q[4], dp0[4], dp1[4], dp2[4];
     uint32_t last[4];
     uint32_t maxc = 0;
 #pragma unroll
@@ -49,19 +54,19 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
         pfy[k] = (float)py;
         bool inside = (px < W) && (py < H);
         size_t pix = (size_t)py * W + px;
-        Tfin[k] = inside ? final_T[pix] : 0.0f;
-        T[k] = Tfin[k];
+        T[k] = inside ? final_T[pix] : 0.0f;
         last[k] = inside ? n_contrib[pix] : 0u;
         dp0[k] = inside ? dL_dpix[pix] : 0.0f;
         dp1[k] = inside ? dL_dpix[HW + pix] : 0.0f;
         dp2[k] = inside ? dL_dpix[2 * HW + pix] : 0.0f;
-        bgdot[k] = FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
-        acc0[k] = acc1[k] = acc2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = 0.0f;
+        Q[k] = T[k] * FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
         maxc = last[k] > maxc ? last[k] : maxc;
     }
     maxc = wave_max_u32(maxc);
     const uint2 range = ranges[tile];
     const int n = (int)maxc;   // entries [0, n) of the tile list can contribute
+    const unsigned long long t_loop = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long seg_k = 0, seg_r = 0;
 
     // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
@@ -79,11 +84,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
             rid = point_list[range.x + (uint32_t)(n - 1 - (base + WAVE + lane))];
             ra = recA[rid]; rb = recB[rid]; rc = recC[rid];
         }
+        unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; ++j) {
+            const unsigned long long tA = trace ? __builtin_amdgcn_s_memtime() : 0ull;
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
             const float2 c = sC[wave][j];
-            const float cb = c.x;
             const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
@@ -100,59 +106,70 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
                 const bool live = (contributor <= last[k]) && !(power > 0.0f) && (power >= c.y);
-                if (__any(live)) {
+                if (__builtin_amdgcn_ballot_w64(live) != 0) {
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
-                    if (valid && !(dbg & 4)) {
+                    if (valid) {
                         any = true;
                         // backward is tolerance-checked (atomics reorder sums anyway): 1-ulp v_rcp_f32
                         const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
-                        T[k] = T[k] * inv_one_m;
-                        const float dch = alpha * T[k];
-                        const float om_la = 1.0f - last_alpha[k];
-                        acc0[k] = FMA(last_alpha[k], lc0[k], om_la * acc0[k]);
-                        acc1[k] = FMA(last_alpha[k], lc1[k], om_la * acc1[k]);
-                        acc2[k] = FMA(last_alpha[k], lc2[k], om_la * acc2[k]);
-                        lc0[k] = b.z; lc1[k] = b.w; lc2[k] = cb;
-                        float dL_dalpha = (b.z - acc0[k]) * dp0[k];
-                        dL_dalpha = FMA(b.w - acc1[k], dp1[k], dL_dalpha);
-                        dL_dalpha = FMA(cb - acc2[k], dp2[k], dL_dalpha);
-                        Sc0 = FMA(dch, dp0[k], Sc0);
-                        Sc1 = FMA(dch, dp1[k], Sc1);
-                        Sc2 = FMA(dch, dp2[k], Sc2);
-                        dL_dalpha = dL_dalpha * T[k];
-                        last_alpha[k] = alpha;
-                        dL_dalpha = FMA(-(Tfin[k] * inv_one_m), bgdot[k], dL_dalpha);
+                        T[k] = T[k] * inv_one_m;                        // transmittance in front of this entry
+                        const float cd = FMA(b.z, dp0[k], FMA(b.w, dp1[k], c.x * dp2[k]));
+                        const float w = alpha * T[k];
+                        const float dL_dalpha = FMA(T[k], cd, -(Q[k] * inv_one_m));
+                        Q[k] = FMA(w, cd, Q[k]);
+                        Sc0 = FMA(w, dp0[k], Sc0);
+                        Sc1 = FMA(w, dp1[k], Sc1);
+                        Sc2 = FMA(w, dp2[k], Sc2);
                         So = FMA(G, dL_dalpha, So);
-                        const float h = (b.y * dL_dalpha) * G;      // straight-through min(0.99, .)
+                        const float h = (b.y * dL_dalpha) * G;          // straight-through min(0.99, .)
                         const float hx = h * dx, hy = h * dy;
                         Sx += hx; Sy += hy;
                         Sxx = FMA(hx, dx, Sxx); Sxy = FMA(hx, dy, Sxy); Syy = FMA(hy, dy, Syy);
                     }
                 }
             }
-            if (__any(any) && !(dbg & 2)) {
+            const unsigned long long tB = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (trace) seg_k += tB - tA;
+            if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                touched |= 1ull << j;
                 Sx = wave_sum_to_lane63(Sx); Sy = wave_sum_to_lane63(Sy);
                 Sxx = wave_sum_to_lane63(Sxx); Sxy = wave_sum_to_lane63(Sxy); Syy = wave_sum_to_lane63(Syy);
                 So = wave_sum_to_lane63(So);
                 Sc0 = wave_sum_to_lane63(Sc0); Sc1 = wave_sum_to_lane63(Sc1); Sc2 = wave_sum_to_lane63(Sc2);
-                if (lane == 63 && !(dbg & 1)) {
-                    const uint32_t id = sId[wave][j];
+                if (lane == 63) {
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
-                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], -(a.z * Sx + a.w * Sy) * ddelx_dx);
-                    unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], -(b.x * Sy + a.w * Sx) * ddely_dy);
-                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], -0.5f * Sxx);
-                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], -Sxy);
-                    unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 2], -0.5f * Syy);
-                    unsafeAtomicAdd(&dL_dopacity[id], So);
-                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 0], Sc0);
-                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 1], Sc1);
-                    unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 2], Sc2);
+                    sPart[wave][j][0] = make_float4(-(a.z * Sx + a.w * Sy) * ddelx_dx, -(b.x * Sy + a.w * Sx) * ddely_dy,
+                                                    -0.5f * Sxx, -Sxy);
+                    sPart[wave][j][1] = make_float4(-0.5f * Syy, So, Sc0, Sc1);
+                    sPart[wave][j][2].x = Sc2;
                 }
             }
+            if (trace) seg_r += __builtin_amdgcn_s_memtime() - tB;
         }
         wave_sync();
+        if ((touched >> lane) & 1ull) {
+            const uint32_t id = sId[wave][lane];
+            const float4 p0 = sPart[wave][lane][0], p1 = sPart[wave][lane][1];
+            const float p2 = sPart[wave][lane][2].x;
+            unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], p0.x);
+            unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], p0.y);
+            unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], p0.z);
+            unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], p0.w);
+            unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 2], p1.x);
+            unsafeAtomicAdd(&dL_dopacity[id], p1.y);
+            unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 0], p1.z);
+            unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 1], p1.w);
+            unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 2], p2);
+        }
+        wave_sync();
+    }
+    if (trace && lane == 0) {
+        trace[4 * (size_t)tile + 0] = t_start;
+        trace[4 * (size_t)tile + 1] = __builtin_amdgcn_s_memtime();
+        trace[4 * (size_t)tile + 2] = ((unsigned long long)(range.y - range.x) << 32) | (unsigned)n;
+        trace[4 * (size_t)tile + 3] = ((seg_k >> 4) << 40) | ((seg_r >> 4) << 16) | ((t_loop - t_start) >> 8);
     }
 }
 
@@ -391,8 +408,8 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     if (num_rendered > 0) {
         ProfScope ps(PS_RENDER_BWD, s);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            ntiles, tile_stride_for(ntiles), vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
-            img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, getenv("E3DGS_DBG") ? atoi(getenv("E3DGS_DBG")) : 0);
+            g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
+            img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
     }
     KERNEL_OK("render_bwd_kernel");
     {

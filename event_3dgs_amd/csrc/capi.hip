@@ -152,6 +152,8 @@ int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, f
                         (hipStream_t)stream);
 }
 
+extern unsigned long long* g_trace;
+void e3dgs_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }   /* not in the public header */
 void e3dgs_set_tile_cull(int on) { g_tile_cull = on ? 1 : 0; }
 int e3dgs_get_tile_cull(void) { return g_tile_cull; }
 

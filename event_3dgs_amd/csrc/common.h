@@ -176,6 +176,7 @@ struct ImageState {
     uint2* ranges;       // per tile [start, end) into point_list
     float* final_T;      // per pixel
     uint32_t* n_contrib; // per pixel
+    uint32_t* order;     // tiles by descending list length (launch order of the compositing kernels)
     static size_t required(size_t npix, size_t ntiles) {
         char* p = nullptr;
         from(p, npix, ntiles);
@@ -186,6 +187,7 @@ struct ImageState {
         s.ranges = carve<uint2>(p, ntiles ? ntiles : 1);
         s.final_T = carve<float>(p, npix ? npix : 1);
         s.n_contrib = carve<uint32_t>(p, npix ? npix : 1);
+        s.order = carve<uint32_t>(p, ntiles ? ntiles : 1);
         return s;
     }
 };

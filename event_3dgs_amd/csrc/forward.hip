@@ -306,16 +306,53 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint
 // them with broadcast ds_read_b128; the next round's gathers are in flight meanwhile.
 constexpr int RENDER_WAVES = 4;
 
-// Work-unit -> tile permutation.  Consecutive workgroups land on the same CU, and neighbouring tiles
-// have correlated list lengths, so the identity map leaves whole CUs with only light (or only heavy)
-// tiles.  u -> (u * stride) mod ntiles with gcd(stride, ntiles) = 1 is a bijection that spreads them.
-__device__ __forceinline__ int tile_of(int unit, int ntiles, int stride) {
-    if (unit >= ntiles) return ntiles;
-    return (int)(((long long)unit * stride) % ntiles);
+// Launch order of the compositing kernels: longest lists first (LPT).  Workgroups are dispatched in index
+// order as slots free up, so heavy tiles start at t = 0 and the short ones fill the tail; without this the
+// last long tiles run alone on their SIMDs at single-wave (latency-bound) speed.  Single workgroup:
+// block max -> 1024-bucket histogram in LDS -> scan -> scatter.  Order inside a bucket is arbitrary, which
+// only affects scheduling, never results.
+__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t smax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t m = 0;
+    for (int t = tid; t < ntiles; t += 1024) { uint2 r = ranges[t]; m = max(m, r.y - r.x); }
+    m = wave_max_u32(m);
+    if (lane == 0) wsum[wave] = m;
+    hist[tid] = 0;
+    __syncthreads();
+    if (tid == 0) { uint32_t x = 0; for (int w = 0; w < 16; ++w) x = max(x, wsum[w]); smax = x; }
+    __syncthreads();
+    const uint32_t width = smax / 1024u + 1u;
+    for (int t = tid; t < ntiles; t += 1024) {
+        uint2 r = ranges[t];
+        atomicAdd(&hist[1023u - min(1023u, (r.y - r.x) / width)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of hist (one bucket per thread)
+    uint32_t v = hist[tid], inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    hist[tid] = woff + inc - v;
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+        uint2 r = ranges[t];
+        uint32_t pos = atomicAdd(&hist[1023u - min(1023u, (r.y - r.x) / width)], 1u);
+        order[pos] = (uint32_t)t;
+    }
 }
 
+unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
+
 __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
-    int ntiles, int tile_stride, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
     const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib) {
@@ -323,8 +360,11 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     __shared__ float4 sB[RENDER_WAVES][WAVE];
     __shared__ float2 sC[RENDER_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = tile_of(blockIdx.x * RENDER_WAVES + wave, ntiles, tile_stride);
-    if (tile >= ntiles) return;
+    const int unit = blockIdx.x * RENDER_WAVES + wave;
+    if (unit >= ntiles) return;
+    const int tile = (int)order[unit];
+    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    int processed = 0;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
@@ -353,6 +393,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     for (int base = 0; base < n; base += WAVE) {
         if (__builtin_amdgcn_ballot_w64(T[0] > 0.0f || T[1] > 0.0f || T[2] > 0.0f || T[3] > 0.0f) == 0) break;
         const int cnt = min(WAVE, n - base);
+        processed += cnt;
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
         wave_sync();
         if (base + WAVE + lane < n) {
@@ -395,6 +436,13 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) T[k] = fabsf(T[k]);
+    if (trace && lane == 0) {
+        trace[4 * (size_t)tile + 0] = t_start;
+        trace[4 * (size_t)tile + 1] = __builtin_amdgcn_s_memtime();
+        trace[4 * (size_t)tile + 2] = ((unsigned long long)n << 32) | (unsigned)processed;
+        trace[4 * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
+                                      (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
 #pragma unroll
@@ -441,17 +489,6 @@ int e3_fail(hipError_t e, const char* what);
             if (_e != hipSuccess) return e3_fail(_e, name);   \
         }                                                     \
     } while (0)
-
-int tile_stride_for(int ntiles) {
-    // E3DGS_TILE_STRIDE=1 restores the identity map (A/B measurements)
-    const char* e = getenv("E3DGS_TILE_STRIDE");
-    if (e) return atoi(e) > 0 ? atoi(e) : 1;
-    if (ntiles < 64) return 1;
-    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
-    int st = (int)(0.6180339887 * ntiles) | 1;      // golden-ratio stride: consecutive units far apart
-    while (gcd(st, ntiles) != 1) st += 2;
-    return st;
-}
 
 static int ceil_log2(uint32_t v) {
     int b = 0;
@@ -551,9 +588,14 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
         }
         KERNEL_OK("tile_ranges_kernel");
     }
+    {
+    ProfScope ps(PS_RANGES, s);
+    tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.order);
+    }
+    KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        ntiles, tile_stride_for(ntiles), vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
+        g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
         img.final_T, img.n_contrib);
     KERNEL_OK("render_fwd_kernel");
     return 0;
