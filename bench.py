@@ -91,9 +91,7 @@ def main():
     gt_params = dict(params)
     gt_params["xyz"] = params["xyz"] + 0.01 * torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     gt_tr = EventTrainer(gt_params, dev)
-    with torch.no_grad():
-        gt_tr._activations()
-        gts = [gt_tr.render(c, bg)["render"].clone() for c in (cam_int, cam_now, cam_next)]
+    gts = [gt_tr.render_raw(c, bg)["color"].clone() for c in (cam_int, cam_now, cam_next)]
     gt_blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
     del gt_tr
     trainer = EventTrainer(params, dev)
@@ -129,22 +127,11 @@ def main():
         name = L.e3dgs_profile_slot_name(slot).decode()
         kern[name] = (ms.value, n.value)
     L.e3dgs_profile_enable(0)
-    loss_val = float(loss.item())
+    loss_val = float(loss[0].item())
 
-    # workload statistics of the last intensity render
-    with torch.no_grad():
-        vis = int((trainer.last_render["radii"] > 0).sum())
-    from event_3dgs_amd import rasterizer
-    trainer._activations()
-    with torch.no_grad():
-        v = trainer.views
-        rs = rasterizer.GaussianRasterizationSettings(H, W, math.tan(cam_int.FoVx * 0.5), math.tan(cam_int.FoVy * 0.5),
-                                                      bg, 1.0, cam_int.world_view_transform,
-                                                      cam_int.full_proj_transform, 3, cam_int.camera_center, False,
-                                                      False)
-        raw = rasterizer.forward_raw(v["xyz"], v["features"], None, trainer._opac, trainer._scales, trainer._rots,
-                                     None, rs)
-    I = raw["num_rendered"]
+    # workload statistics of the intensity view
+    vis = int((trainer.last_radii > 0).sum())
+    I = trainer.render_raw(cam_int, bg)["num_rendered"]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     npx = W * H
 

@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _fp, _ip, _vp, _cp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
@@ -38,11 +38,11 @@ def lib():
     L.e3dgs_rasterize_forward.restype = C.c_int
     L.e3dgs_rasterize_forward.argtypes = (
         [ALLOC_FN, _vp] * 3 + [C.c_int] * 3 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5
-        + [C.c_float, C.c_float, C.c_int, _fp, _ip, C.c_int, C.POINTER(C.c_int), _vp])
+        + [C.c_float, C.c_float, C.c_int, _fp, _ip, C.c_int, C.c_int, C.POINTER(C.c_int), _vp])
     L.e3dgs_rasterize_backward.restype = C.c_int
     L.e3dgs_rasterize_backward.argtypes = (
-        [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
-        + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, _vp])
+        [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
+        + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, C.c_int, _vp])
     L.e3dgs_set_tile_cull.restype = None
     L.e3dgs_set_tile_cull.argtypes = [C.c_int]
     L.e3dgs_get_tile_cull.restype = C.c_int
@@ -85,6 +85,10 @@ def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
 
+
+FLAG_PREACT = 1
+FLAG_ACCUMULATE = 2
+ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_backward",

@@ -17,8 +17,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D /*P,3*/, float* __restrict__ dL_dconic /*P,4*/,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor /*P,3*/) {
+    const float* __restrict__ dL_dpix, float* __restrict__ acc /* (P,12): mx my A B C o c0 c1 c2 - - - */) {
     __shared__ float4 sA[BWD_WAVES][WAVE];
     __shared__ float4 sB[BWD_WAVES][WAVE];
     __shared__ float2 sC[BWD_WAVES][WAVE];
@@ -153,15 +152,10 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
             const uint32_t id = sId[wave][lane];
             const float4 p0 = sPart[wave][lane][0], p1 = sPart[wave][lane][1];
             const float p2 = sPart[wave][lane][2].x;
-            unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 0], p0.x);
-            unsafeAtomicAdd(&dL_dmean2D[3 * (size_t)id + 1], p0.y);
-            unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 0], p0.z);
-            unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 1], p0.w);
-            unsafeAtomicAdd(&dL_dconic[4 * (size_t)id + 2], p1.x);
-            unsafeAtomicAdd(&dL_dopacity[id], p1.y);
-            unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 0], p1.z);
-            unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 1], p1.w);
-            unsafeAtomicAdd(&dL_dcolor[3 * (size_t)id + 2], p2);
+            float* g = acc + E3_ACC_STRIDE * (size_t)id;      // one 48-B record: the 9 atomics touch 1-2 cache lines
+            unsafeAtomicAdd(g + 0, p0.x); unsafeAtomicAdd(g + 1, p0.y); unsafeAtomicAdd(g + 2, p0.z);
+            unsafeAtomicAdd(g + 3, p0.w); unsafeAtomicAdd(g + 4, p1.x); unsafeAtomicAdd(g + 5, p1.y);
+            unsafeAtomicAdd(g + 6, p1.z); unsafeAtomicAdd(g + 7, p1.w); unsafeAtomicAdd(g + 8, p2);
         }
         wave_sync();
     }
@@ -174,6 +168,10 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------ per-Gaussian backward
+template <bool ACCUM>
+__device__ __forceinline__ void put(float* p, float v) { if (ACCUM) *p += v; else *p = v; }
+
+template <bool ACCUM>
 __device__ __forceinline__ void sh_backward(int D, int M, const float* __restrict__ sh, float* __restrict__ dsh,
                                             float mx, float my, float mz, const float* __restrict__ campos,
                                             uint32_t clamped, const float gin[3], float gmean[3]) {
@@ -192,7 +190,7 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
     auto term = [&](int k, float Y, float Yx, float Yy, float Yz) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            dsh[k * 3 + ch] = Y * g[ch];
+            put<ACCUM>(&dsh[k * 3 + ch], Y * g[ch]);
             float s = sh[k * 3 + ch] * g[ch];
             ddx = FMA(Yx, s, ddx); ddy = FMA(Yy, s, ddy); ddz = FMA(Yz, s, ddz);
         }
@@ -223,38 +221,57 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
             }
         }
     }
-    for (int k = (D + 1) * (D + 1); k < M; ++k) { dsh[k * 3] = 0.0f; dsh[k * 3 + 1] = 0.0f; dsh[k * 3 + 2] = 0.0f; }
+    if (!ACCUM)
+        for (int k = (D + 1) * (D + 1); k < M; ++k) { dsh[k * 3] = 0.0f; dsh[k * 3 + 1] = 0.0f; dsh[k * 3 + 2] = 0.0f; }
     float dot = x * ddx + y * ddy + z * ddz;
     gmean[0] += (ddx - x * dot) / len;
     gmean[1] += (ddy - y * dot) / len;
     gmean[2] += (ddz - z * dot) / len;
 }
 
+// One thread per Gaussian.  ACCUM=false writes every output element (zeros for culled Gaussians, so the
+// caller never has to pre-zero); ACCUM=true adds into the outputs for visible Gaussians only, which lets the
+// three renders of a training iteration accumulate straight into the flat gradient buffer.
+template <bool ACCUM>
 __global__ __launch_bounds__(256) void geom_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
-    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov_pre,
-    ViewParams vp, const int* __restrict__ radii, const uint32_t* __restrict__ clamped,
-    const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolor,
-    float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
+    const float* __restrict__ cov_pre, ViewParams vp, int flags, const int* __restrict__ radii,
+    const uint32_t* __restrict__ clamped, const float* __restrict__ acc, float* dL_dmean2D, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    if (radii[i] <= 0) return;   // all outputs pre-zeroed by the caller
+    const bool preact = (flags & E3_FLAG_PREACT) != 0;
+    if (radii[i] <= 0) {
+        if (!ACCUM) {
+            if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
+            if (dL_dopacity) dL_dopacity[i] = 0.0f;
+            if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = 0.0f; dL_dcolor[3 * (size_t)i + 1] = 0.0f; dL_dcolor[3 * (size_t)i + 2] = 0.0f; }
+            dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
+            if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+            if (dL_dsh) for (int k = 0; k < 3 * M; ++k) dL_dsh[(size_t)i * M * 3 + k] = 0.0f;
+            if (dL_dscale) { dL_dscale[3 * (size_t)i] = 0.0f; dL_dscale[3 * (size_t)i + 1] = 0.0f; dL_dscale[3 * (size_t)i + 2] = 0.0f; }
+            if (dL_drot) for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = 0.0f;
+        }
+        return;
+    }
     const float* V = vp.view;
     const float* Pm = vp.proj;
+    const float* g12 = acc + E3_ACC_STRIDE * (size_t)i;
     float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     float S[6];
     if (cov_pre) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
     }
-    float qr = 0, qx = 0, qy = 0, qz = 0, s0 = 0, s1 = 0, s2 = 0;
+    float qr = 0, qx = 0, qy = 0, qz = 0, s0 = 0, s1 = 0, s2 = 0, qinv = 1.0f;
+    float sact[3] = {0, 0, 0};
     float R[3][3];
     if (!cov_pre) {
-        const float* q = rots + 4 * (size_t)i;
-        const float* s3 = scales + 3 * (size_t)i;
-        qr = q[0]; qx = q[1]; qy = q[2]; qz = q[3];
-        s0 = vp.scale_modifier * s3[0]; s1 = vp.scale_modifier * s3[1]; s2 = vp.scale_modifier * s3[2];
+        float qn[4];
+        act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, preact, sact, qn, qinv);
+        qr = qn[0]; qx = qn[1]; qy = qn[2]; qz = qn[3];
+        s0 = vp.scale_modifier * sact[0]; s1 = vp.scale_modifier * sact[1]; s2 = vp.scale_modifier * sact[2];
         R[0][0] = 1.0f - 2.0f * FMA(qy, qy, qz * qz); R[0][1] = 2.0f * FMA(qx, qy, -(qr * qz)); R[0][2] = 2.0f * FMA(qx, qz, qr * qy);
         R[1][0] = 2.0f * FMA(qx, qy, qr * qz); R[1][1] = 1.0f - 2.0f * FMA(qx, qx, qz * qz); R[1][2] = 2.0f * FMA(qy, qz, -(qr * qx));
         R[2][0] = 2.0f * FMA(qx, qz, -(qr * qy)); R[2][1] = 2.0f * FMA(qy, qz, qr * qx); R[2][2] = 1.0f - 2.0f * FMA(qx, qx, qy * qy);
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     float b = FMA(T10, u0, FMA(T11, u1, T12 * u2));
     float c = FMA(T10, w0, FMA(T11, w1, T12 * w2)) + E3_DILATION;
     // ---- conic -> (a,b,c)
-    float gA = dL_dconic[4 * (size_t)i], gB = dL_dconic[4 * (size_t)i + 1], gC = dL_dconic[4 * (size_t)i + 2];
+    float gA = g12[2], gB = g12[3], gC = g12[4];
     float det = a * c - b * b;
     float d2inv = 1.0f / (det * det + E3_DET2_EPS);
     float g_a = 0.0f, g_b = 0.0f, g_c = 0.0f;
@@ -307,8 +324,10 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     gcov[1] = 2.0f * T00 * T01 * g_a + (T00 * T11 + T01 * T10) * g_b + 2.0f * T10 * T11 * g_c;
     gcov[2] = 2.0f * T00 * T02 * g_a + (T00 * T12 + T02 * T10) * g_b + 2.0f * T10 * T12 * g_c;
     gcov[4] = 2.0f * T02 * T01 * g_a + (T01 * T12 + T02 * T11) * g_b + 2.0f * T11 * T12 * g_c;
+    if (dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = gcov[k];
+        for (int k = 0; k < 6; ++k) put<ACCUM>(&dL_dcov3D[6 * (size_t)i + k], gcov[k]);
+    }
     float gT00 = 2.0f * g_a * u0 + g_b * w0, gT01 = 2.0f * g_a * u1 + g_b * w1, gT02 = 2.0f * g_a * u2 + g_b * w2;
     float gT10 = 2.0f * g_c * w0 + g_b * u0, gT11 = 2.0f * g_c * w1 + g_b * u1, gT12 = 2.0f * g_c * w2 + g_b * u2;
     float gJ00 = V[0] * gT00 + V[4] * gT01 + V[8] * gT02;
@@ -325,7 +344,19 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     gmean[1] = V[4] * gtx + V[5] * gty + V[6] * gtz;
     gmean[2] = V[8] * gtx + V[9] * gty + V[10] * gtz;
     // ---- NDC mean gradient through the projection
-    float gm2x = dL_dmean2D[3 * (size_t)i], gm2y = dL_dmean2D[3 * (size_t)i + 1];
+    float gm2x = g12[0], gm2y = g12[1];
+    if (dL_dmean2D) {   // NDC-unit screen-space gradient (scene/gaussian_model.py:405-407); overwritten
+        dL_dmean2D[3 * (size_t)i] = gm2x; dL_dmean2D[3 * (size_t)i + 1] = gm2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+    }
+    {
+        float go = g12[5];
+        if (preact) { float o = act_sigmoid(opac_in[i]); go = go * o * (1.0f - o); }
+        if (dL_dopacity) put<ACCUM>(&dL_dopacity[i], go);
+    }
+    if (dL_dcolor) {
+        put<ACCUM>(&dL_dcolor[3 * (size_t)i], g12[6]); put<ACCUM>(&dL_dcolor[3 * (size_t)i + 1], g12[7]);
+        put<ACCUM>(&dL_dcolor[3 * (size_t)i + 2], g12[8]);
+    }
     float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
     float pw = 1.0f / (hw + E3_W_EPS);
     float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
@@ -333,13 +364,13 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     gmean[1] += (Pm[4] * pw - Pm[7] * mul1) * gm2x + (Pm[5] * pw - Pm[7] * mul2) * gm2y;
     gmean[2] += (Pm[8] * pw - Pm[11] * mul1) * gm2x + (Pm[9] * pw - Pm[11] * mul2) * gm2y;
     if (shs) {
-        float gcol[3] = {dL_dcolor[3 * (size_t)i], dL_dcolor[3 * (size_t)i + 1], dL_dcolor[3 * (size_t)i + 2]};
-        sh_backward(D, M, shs + (size_t)i * M * 3, dL_dsh + (size_t)i * M * 3, mx, my, mz, vp.campos, clamped[i], gcol,
-                    gmean);
+        float gcol[3] = {g12[6], g12[7], g12[8]};
+        sh_backward<ACCUM>(D, M, shs + (size_t)i * M * 3, dL_dsh + (size_t)i * M * 3, mx, my, mz, vp.campos, clamped[i],
+                           gcol, gmean);
     }
-    dL_dmean3D[3 * (size_t)i] = gmean[0];
-    dL_dmean3D[3 * (size_t)i + 1] = gmean[1];
-    dL_dmean3D[3 * (size_t)i + 2] = gmean[2];
+    put<ACCUM>(&dL_dmean3D[3 * (size_t)i], gmean[0]);
+    put<ACCUM>(&dL_dmean3D[3 * (size_t)i + 1], gmean[1]);
+    put<ACCUM>(&dL_dmean3D[3 * (size_t)i + 2], gmean[2]);
     // ---- Sigma3 = (R diag s)(R diag s)^T
     if (!cov_pre) {
         const float s[3] = {s0, s1, s2};
@@ -359,11 +390,22 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
             }
             ds[j] = vp.scale_modifier * t;
         }
-        dL_dscale[3 * (size_t)i] = ds[0]; dL_dscale[3 * (size_t)i + 1] = ds[1]; dL_dscale[3 * (size_t)i + 2] = ds[2];
-        dL_drot[4 * (size_t)i + 0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
-        dL_drot[4 * (size_t)i + 1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - qr * dR[1][2] + qz * dR[2][0] + qr * dR[2][1] - 2.0f * qx * dR[2][2]);
-        dL_drot[4 * (size_t)i + 2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - qr * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
-        dL_drot[4 * (size_t)i + 3] = 2.0f * (-2.0f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        float dq[4];
+        dq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        dq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - qr * dR[1][2] + qz * dR[2][0] + qr * dR[2][1] - 2.0f * qx * dR[2][2]);
+        dq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - qr * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
+        dq[3] = 2.0f * (-2.0f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        if (preact) {
+            // scales = exp(raw): d/draw = d/dscale * scale;  rotation = raw/|raw|: project out the radial part
+            ds[0] *= sact[0]; ds[1] *= sact[1]; ds[2] *= sact[2];
+            float dot = qr * dq[0] + qx * dq[1] + qy * dq[2] + qz * dq[3];
+            dq[0] = (dq[0] - qr * dot) * qinv; dq[1] = (dq[1] - qx * dot) * qinv;
+            dq[2] = (dq[2] - qy * dot) * qinv; dq[3] = (dq[3] - qz * dot) * qinv;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) put<ACCUM>(&dL_dscale[3 * (size_t)i + k], ds[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) put<ACCUM>(&dL_drot[4 * (size_t)i + k], dq[k]);
     }
 }
 
@@ -380,13 +422,13 @@ int e3_fail(hipError_t e, const char* what);
     } while (0)
 
 int e3_backward_impl(int P, int D, int M, int num_rendered, const float* background, int W, int H,
-                     const float* means3D, const float* shs, const float* colors, const float* scales,
-                     float scale_modifier, const float* rots, const float* cov_pre, const float* view,
-                     const float* proj, const float* campos, float tanfovx, float tanfovy, const int* radii,
-                     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
-                     const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                     const float* means3D, const float* shs, const float* colors, const float* opacities,
+                     const float* scales, float scale_modifier, const float* rots, const float* cov_pre,
+                     const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
+                     const int* radii, const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                     const float* dL_dpix, float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                      float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                     hipStream_t s) {
+                     int flags, hipStream_t s) {
     (void)colors;
     if (P <= 0) return 0;
     ViewParams vp;
@@ -408,15 +450,20 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     if (num_rendered > 0) {
         ProfScope ps(PS_RENDER_BWD, s);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, img.final_T,
-            img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+            g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC,
+            background, img.final_T, img.n_contrib, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");
     {
     ProfScope ps(PS_GEOM_BWD, s);
-    geom_bwd_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, D, M, means3D, shs, scales, rots, cov_pre, vp, radii,
-                                                               geom.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
-                                                               dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    if (flags & E3_FLAG_ACCUMULATE)
+        geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, grad_acc,
+            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else
+        geom_bwd_kernel<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, grad_acc,
+            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     }
     KERNEL_OK("geom_bwd_kernel");
     return 0;

@@ -46,11 +46,11 @@ void prof_end(int slot, hipStream_t s) {
 int e3_forward_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*,
                     int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
                     const float*, float, const float*, const float*, const float*, const float*, const float*, float,
-                    float, int, float*, int*, int, int*, hipStream_t);
+                    float, int, float*, int*, int, int, int*, hipStream_t);
 int e3_backward_impl(int, int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
-                     float, const float*, const float*, const float*, const float*, const float*, float, float,
-                     const int*, const char*, const char*, const char*, const float*, float*, float*, float*, float*,
-                     float*, float*, float*, float*, float*, int, hipStream_t);
+                     const float*, float, const float*, const float*, const float*, const float*, const float*, float,
+                     float, const int*, const char*, const char*, const char*, const float*, float*, float*, float*,
+                     float*, float*, float*, float*, float*, float*, int, int, hipStream_t);
 int e3_mark_visible_impl(int, const float*, const float*, uint8_t*, hipStream_t);
 size_t e3_knn_scratch_bytes(int);
 int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
@@ -62,7 +62,7 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 1; }
+int e3dgs_abi_version(void) { return 2; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
@@ -71,7 +71,7 @@ int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_al
                             const float* colors_precomp, const float* opacities, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                            float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                            float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, int flags,
                             int* num_rendered_host, void* stream) {
     g_err[0] = 0;
     if (P < 0 || width <= 0 || height <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
@@ -79,6 +79,7 @@ int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_al
         return e3_fail(hipErrorInvalidValue, "provide exactly one of shs / colors_precomp");
     if (((scales == nullptr || rotations == nullptr) == (cov3D_precomp == nullptr)) && P > 0)
         return e3_fail(hipErrorInvalidValue, "provide exactly one of scales+rotations / cov3D_precomp");
+    if ((flags & E3_FLAG_PREACT) && cov3D_precomp) return e3_fail(hipErrorInvalidValue, "PREACT needs scales+rotations");
     if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1)))
         return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
     if ((width + 15) / 16 > 65535 || (height + 15) / 16 > 65535)
@@ -86,25 +87,29 @@ int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_al
     return e3_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
                            background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                            rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
-                           out_color, radii, debug, num_rendered_host, (hipStream_t)stream);
+                           out_color, radii, debug, flags, num_rendered_host, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
-                             const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
-                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                             const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                             float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
-                             const char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                             float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                             float* dL_dscale, float* dL_drot, int debug, void* stream) {
+                             const float* means3D, const float* shs, const float* colors_precomp,
+                             const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                             const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                             const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                             const float* dL_dpix, float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
+                             float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                             float* dL_drot, int debug, int flags, void* stream) {
     g_err[0] = 0;
+    if (P > 0 && (!grad_acc || !dL_dmean3D)) return e3_fail(hipErrorInvalidValue, "grad_acc and dL_dmean3D are required");
     if (shs && !dL_dsh) return e3_fail(hipErrorInvalidValue, "dL_dsh required when shs is given");
     if (!cov3D_precomp && (!dL_dscale || !dL_drot))
         return e3_fail(hipErrorInvalidValue, "dL_dscale/dL_drot required when scales+rotations are given");
-    return e3_backward_impl(P, D, M, num_rendered, background, width, height, means3D, shs, colors_precomp, scales,
-                            scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                            tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
-                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
+    if ((flags & E3_FLAG_PREACT) && (cov3D_precomp || !opacities))
+        return e3_fail(hipErrorInvalidValue, "PREACT needs scales+rotations and opacities");
+    return e3_backward_impl(P, D, M, num_rendered, background, width, height, means3D, shs, colors_precomp, opacities,
+                            scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                            tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D,
+                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, flags,
                             (hipStream_t)stream);
 }
 

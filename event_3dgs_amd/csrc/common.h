@@ -19,6 +19,11 @@
 #define E3_W_EPS 0.0000001f
 #define E3_DET2_EPS 0.0000001f
 
+// flags of e3dgs_rasterize_forward / _backward (include/e3dgs_hip.h)
+#define E3_FLAG_PREACT 1      // scales = log-scales, rotations = raw quaternions, opacities = logits
+#define E3_FLAG_ACCUMULATE 2  // backward adds into its outputs (only for visible Gaussians)
+#define E3_ACC_STRIDE 12      // floats per Gaussian in the backward accumulation record
+
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define WAVE 64
 
@@ -48,6 +53,21 @@ __device__ __forceinline__ float exp_det_noclamp(float x) {
     p = FMA(p, f, 0.6931468844413757f);
     p = FMA(p, f, 1.0f);
     return __builtin_ldexpf(p, (int)n);
+}
+
+// activations of scene/gaussian_model.py:95-118 (used when E3_FLAG_PREACT is set)
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void act_load_scale_rot(const float* __restrict__ s3, const float* __restrict__ q4, bool preact,
+                                                   float s[3], float q[4], float& qinv) {
+    s[0] = s3[0]; s[1] = s3[1]; s[2] = s3[2];
+    q[0] = q4[0]; q[1] = q4[1]; q[2] = q4[2]; q[3] = q4[3];
+    qinv = 1.0f;
+    if (preact) {
+        s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+        float nrm = __builtin_sqrtf(FMA(q[0], q[0], FMA(q[1], q[1], FMA(q[2], q[2], q[3] * q[3]))));
+        qinv = 1.0f / fmaxf(nrm, 1e-12f);          // torch.nn.functional.normalize eps
+        q[0] *= qinv; q[1] *= qinv; q[2] *= qinv; q[3] *= qinv;
+    }
 }
 
 // flat[4*c + r]: row r of the column-vector matrix applied to (x,y,z,1)

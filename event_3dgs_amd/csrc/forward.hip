@@ -60,8 +60,7 @@ __device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, f
     }
 }
 
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s3, float mod,
-                                                     const float* __restrict__ q, float cov[6]) {
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q, float cov[6]) {
     float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
     float r = q[0], x = q[1], y = q[2], z = q[3];
     float R00 = 1.0f - 2.0f * FMA(y, y, z * z), R01 = 2.0f * FMA(x, y, -(r * z)), R02 = 2.0f * FMA(x, z, r * y);
@@ -84,7 +83,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
-    const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewParams vp, int* __restrict__ radii,
+    const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewParams vp, int flags,
+    int* __restrict__ radii,
     float4* __restrict__ recA, float4* __restrict__ recB, float2* __restrict__ recC, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 #pragma unroll
             for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
         } else {
-            cov3d_from_scale_rot(scales + 3 * (size_t)i, vp.scale_modifier, rots + 4 * (size_t)i, S);
+            float sc[3], qn[4], qinv;
+            act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, (flags & E3_FLAG_PREACT) != 0, sc, qn, qinv);
+            cov3d_from_scale_rot(sc, vp.scale_modifier, qn, S);
         }
         // EWA: T = J * Wr, Sigma2 = T Sigma3 T^T
         float limx = E3_GUARD_BAND * vp.tanfovx, limy = E3_GUARD_BAND * vp.tanfovy;
@@ -153,10 +155,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
                 }
                 recA[i] = make_float4(px, py, conx, cony);
-                recB[i] = make_float4(conz, opac[i], rgb[0], rgb[1]);
+                const float o_ = (flags & E3_FLAG_PREACT) ? act_sigmoid(opac[i]) : opac[i];
+                recB[i] = make_float4(conz, o_, rgb[0], rgb[1]);
                 // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
                 // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
-                const float o_ = opac[i];
                 recC[i] = make_float2(rgb[2], -(logf(255.0f * o_) + 1e-3f));
                 clamped[i] = cl;
                 radius_out = radius;
@@ -502,7 +504,7 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
                     const float* colors, const float* opac, const float* scales, float scale_modifier,
                     const float* rots, const float* cov_pre, const float* view, const float* proj,
                     const float* campos, float tanfovx, float tanfovy, int prefiltered, float* out_color, int* radii,
-                    int debug, int* num_rendered_host, hipStream_t s) {
+                    int debug, int flags, int* num_rendered_host, hipStream_t s) {
     (void)prefiltered;
     ViewParams vp;
     vp.view = view; vp.proj = proj; vp.campos = campos;
@@ -530,7 +532,7 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
         {
         ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
-                                                         vp, radii, geom.recA, geom.recB, geom.recC, geom.clamped,
+                                                         vp, flags, radii, geom.recA, geom.recB, geom.recC, geom.clamped,
                                                          geom.rect, geom.key0, geom.ord0);
         }
         KERNEL_OK("preprocess_kernel");

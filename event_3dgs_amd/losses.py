@@ -40,6 +40,30 @@ class _EventLoss(torch.autograd.Function):
                 None)
 
 
+def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17, out=None):
+    """Direct call of e3dgs_event_loss (no autograd).  Returns (scalars[8], d_image, d_now, d_next):
+    scalars[0] = loss, [1] = dL/dc, [2] = rho, [3..5] = L1 event / intensity / blur.  `out` may carry
+    preallocated (scalars, d_image, d_now, d_next, scratch) tensors to reuse across steps."""
+    L = _lib.lib()
+    dev = image.device
+    _, H, W = image.shape
+    for t in (image, img_now, img_next, gt_int, gt_now, gt_next):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("event_loss_raw needs contiguous fp32 GPU tensors")
+    if out is None:
+        out = (torch.empty(8, dtype=torch.float32, device=dev), torch.empty_like(image), torch.empty_like(image),
+               torch.empty_like(image),
+               torch.empty(L.e3dgs_event_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev))
+    scalars, d_image, d_now, d_next, scratch = out
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_event_loss(W, H, _lib.ptr(image), _lib.ptr(img_now), _lib.ptr(img_next), _lib.ptr(gt_int),
+                                _lib.ptr(gt_now), _lib.ptr(gt_next), _lib.ptr(gt_blur), _lib.ptr(c), float(gt_c),
+                                _lib.ptr(d_image), _lib.ptr(d_now), _lib.ptr(d_next), _lib.ptr(scalars),
+                                _lib.ptr(scratch), _lib.current_stream())
+    _lib.check(rc, "e3dgs_event_loss")
+    return scalars, d_image, d_now, d_next
+
+
 def event_iteration_loss(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17):
     """loss of train.py:165-203; `c` is the learnable contrast threshold (train.py:71-73)."""
     if not image.is_cuda:

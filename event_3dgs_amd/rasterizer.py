@@ -66,7 +66,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
-def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, flags=0):
     """One call of e3dgs_rasterize_forward.  Returns a dict with the outputs, the prepared
     (contiguous) inputs and the three scratch tensors that backward needs."""
     import ctypes as C
@@ -106,11 +106,12 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
             _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(scales_c),
             float(rs.scale_modifier), _lib.ptr(rots_c), _lib.ptr(cov_c), _lib.ptr(view), _lib.ptr(proj),
             _lib.ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
-            _lib.ptr(out_color), _lib.ptr(radii), int(bool(rs.debug)), C.byref(num_rendered),
+            _lib.ptr(out_color), _lib.ptr(radii), int(bool(rs.debug)), int(flags), C.byref(num_rendered),
             _lib.current_stream())
     _lib.check(rc, "e3dgs_rasterize_forward")
-    return dict(color=out_color, radii=radii, num_rendered=num_rendered.value, M=M,
-                inputs=(means3D_c, sh_c, colors_c, scales_c, rots_c, cov_c), consts=(bg, view, proj, campos),
+    return dict(color=out_color, radii=radii, num_rendered=num_rendered.value, M=M, settings=rs, flags=int(flags),
+                inputs=(means3D_c, sh_c, colors_c, scales_c, rots_c, cov_c), opacities=opac_c,
+                consts=(bg, view, proj, campos),
                 geom=geom.tensor, binning=binning.tensor, image=img.tensor)
 
 
@@ -150,36 +151,57 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
-        L = _lib.lib()
         rs = ctx.raster_settings
         means3D, sh, colors, scales, rots, cov, radii, geomB, binB, imgB = ctx.saved_tensors
-        bg, view, proj, campos = ctx.consts
         dev = means3D.device
         P, M = means3D.shape[0], ctx.M
-        H, W = int(rs.image_height), int(rs.image_width)
-        g = grad_out_color
-        if g.dtype != torch.float32:
-            g = g.float()
-        g = g.contiguous()
-        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        dL_dmeans2D, dL_dconic, dL_dopacity = z(P, 3), z(P, 4), z(P, 1)
-        dL_dcolors, dL_dmeans3D, dL_dcov3D = z(P, 3), z(P, 3), z(P, 6)
-        dL_dsh = z(P, M, 3) if sh is not None else None
-        dL_dscales = z(P, 3) if cov is None else None
-        dL_drots = z(P, 4) if cov is None else None
-        if P:
-            with torch.cuda.device(dev):
-                rc = L.e3dgs_rasterize_backward(
-                    P, int(rs.sh_degree), M, ctx.num_rendered, _lib.ptr(bg), W, H, _lib.ptr(means3D), _lib.ptr(sh),
-                    _lib.ptr(colors), _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots), _lib.ptr(cov),
-                    _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                    _lib.ptr(radii), _lib.ptr(geomB), _lib.ptr(binB), _lib.ptr(imgB), _lib.ptr(g),
-                    _lib.ptr(dL_dmeans2D), _lib.ptr(dL_dconic), _lib.ptr(dL_dopacity), _lib.ptr(dL_dcolors),
-                    _lib.ptr(dL_dmeans3D), _lib.ptr(dL_dcov3D), _lib.ptr(dL_dsh), _lib.ptr(dL_dscales),
-                    _lib.ptr(dL_drots), int(bool(rs.debug)), _lib.current_stream())
-            _lib.check(rc, "e3dgs_rasterize_backward")
-        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if colors is not None else None, dL_dopacity,
-                dL_dscales, dL_drots, dL_dcov3D if cov is not None else None, None)
+        e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # kernels write every element
+        out = dict(means2D=e(P, 3), opacities=e(P, 1), colors=e(P, 3) if colors is not None else None,
+                   means3D=e(P, 3), cov3D=e(P, 6) if cov is not None else None,
+                   sh=e(P, M, 3) if sh is not None else None, scales=e(P, 3) if cov is None else None,
+                   rots=e(P, 4) if cov is None else None)
+        raw = dict(num_rendered=ctx.num_rendered, M=M, settings=rs, flags=0,
+                   inputs=(means3D, sh, colors, scales, rots, cov), opacities=None, consts=ctx.consts, radii=radii,
+                   geom=geomB, binning=binB, image=imgB)
+        backward_raw(raw, grad_out_color, out)
+        return (out["means3D"], out["means2D"], out["sh"], out["colors"], out["opacities"], out["scales"], out["rots"],
+                out["cov3D"], None)
+
+
+def backward_raw(raw, grad_out_color, out, flags=None, grad_acc=None):
+    """One call of e3dgs_rasterize_backward for a forward_raw() result.  `out` maps
+    means2D/opacities/colors/means3D/cov3D/sh/scales/rots to destination tensors (or None);
+    with FLAG_ACCUMULATE they are added to, otherwise fully overwritten."""
+    L = _lib.lib()
+    rs = raw["settings"]
+    flags = raw["flags"] if flags is None else flags
+    means3D, sh, colors, scales, rots, cov = raw["inputs"]
+    bg, view, proj, campos = raw["consts"]
+    dev = means3D.device
+    P = means3D.shape[0]
+    if P == 0:
+        for t in out.values():
+            if t is not None and not (flags & _lib.FLAG_ACCUMULATE):
+                t.zero_()
+        return
+    H, W = int(rs.image_height), int(rs.image_width)
+    g = grad_out_color
+    if g.dtype != torch.float32:
+        g = g.float()
+    g = g.contiguous()
+    if grad_acc is None:
+        grad_acc = torch.zeros(P, _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_rasterize_backward(
+            P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(bg), W, H, _lib.ptr(means3D), _lib.ptr(sh),
+            _lib.ptr(colors), _lib.ptr(raw.get("opacities")), _lib.ptr(scales), float(rs.scale_modifier),
+            _lib.ptr(rots), _lib.ptr(cov), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(rs.tanfovx),
+            float(rs.tanfovy), _lib.ptr(raw["radii"]), _lib.ptr(raw["geom"]), _lib.ptr(raw["binning"]),
+            _lib.ptr(raw["image"]), _lib.ptr(g), _lib.ptr(grad_acc), _lib.ptr(out.get("means2D")),
+            _lib.ptr(out.get("opacities")), _lib.ptr(out.get("colors")), _lib.ptr(out.get("means3D")),
+            _lib.ptr(out.get("cov3D")), _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")), _lib.ptr(out.get("rots")),
+            int(bool(rs.debug)), int(flags), _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_backward")
 
 
 class GaussianRasterizer(nn.Module):

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import losses
+from . import _lib, losses, parallel, rasterizer
 from .rasterizer import GaussianRasterizationSettings, rasterize_gaussians
 
 
@@ -44,19 +44,28 @@ FLOATS_PER_GAUSSIAN = sum(n for _, n in SEGMENTS)   # 59
 
 
 class EventTrainer:
-    """Holds the Gaussian parameters (pre-activation, scene/gaussian_model.py:44-59) and runs steps."""
+    """Holds the Gaussian parameters (pre-activation, scene/gaussian_model.py:44-59) and runs steps.
+
+    step()          fused path: no autograd; activations inside the kernels (E3DGS_FLAG_PREACT) and the three
+                    backward passes accumulate straight into the flat gradient buffer (E3DGS_FLAG_ACCUMULATE).
+    step_autograd() the same iteration through the drop-in autograd operator + torch activations, as the
+                    reference's train.py does; kept as the equivalence check of the fused path.
+    """
 
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
-                 scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None):
+                 scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
+                 track_densification_stats=False):
         self.device = torch.device(device)
         self.N = params["xyz"].shape[0]
         N = self.N
-        self.flat = torch.empty(N * FLOATS_PER_GAUSSIAN, dtype=torch.float32, device=self.device)
+        # one flat buffer each for parameters / gradients / Adam moments; the last element is the threshold c
+        nflat = N * FLOATS_PER_GAUSSIAN + 1
+        self.flat = torch.empty(nflat, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros_like(self.flat)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.views, self.seg = {}, {}
+        self.views, self.grads, self.seg = {}, {}, {}
         off = 0
         shapes = {"xyz": (N, 3), "features": (N, 16, 3), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
         feats = torch.cat((params["features_dc"], params["features_rest"]), dim=1)
@@ -67,12 +76,14 @@ class EventTrainer:
             self.seg[name] = (off, n)
             p = self.flat[off:off + n].view(shapes[name])
             p.copy_(src[name].to(self.device))
-            p.requires_grad_(True)
-            p.grad = self.flat_grad[off:off + n].view(shapes[name])
             self.views[name] = p
+            self.grads[name] = self.flat_grad[off:off + n].view(shapes[name])
             off += n
-        self.c = torch.full((1,), c_init, dtype=torch.float32, device=self.device, requires_grad=True)
-        self.c_opt = torch.optim.Adam([self.c], lr=c_lr)
+        self.seg["c"] = (off, 1)
+        self.c = self.flat[off:off + 1]
+        self.c.fill_(c_init)
+        self.c_grad = self.flat_grad[off:off + 1]
+        self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
                                         lr_delay_mult=position_lr_delay_mult, max_steps=position_lr_max_steps)
         self.lrs = dict(features=feature_lr, features_rest=feature_lr / 20.0, opacity=opacity_lr, scaling=scaling_lr,
@@ -81,60 +92,98 @@ class EventTrainer:
         self.iteration = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.last_stats = None
+        self.track_stats = track_densification_stats
+        # reusable scratch
+        self.acc = torch.empty(N, _lib.ACC_STRIDE, dtype=torch.float32, device=self.device)
+        self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if track_densification_stats else None
+        self._loss_bufs = None
+        self.last_radii = None
+        self.last_scalars = None
 
-    # ---- gaussian_renderer.render() on the fused path (gaussian_renderer/__init__.py:20-104)
-    def render(self, cam, bg, scaling_modifier=1.0):
-        v = self.views
-        rs = GaussianRasterizationSettings(
+    # ---- raster settings for one view (gaussian_renderer/__init__.py:35-51)
+    def _settings(self, cam, bg, scaling_modifier=1.0):
+        return GaussianRasterizationSettings(
             image_height=int(cam.image_height), image_width=int(cam.image_width),
             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg,
             scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
             sh_degree=self.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
-        means2D = torch.zeros_like(v["xyz"], requires_grad=True)
-        img, radii = rasterize_gaussians(v["xyz"], means2D, v["features"], None, self._opac, self._scales, self._rots,
-                                         None, rs)
-        return {"render": img, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
 
-    def _activations(self):
+    def render_raw(self, cam, bg):
+        """Forward only, fused activations.  Returns the forward_raw dict (image in ["color"])."""
         v = self.views
-        self._scales = torch.exp(v["scaling"])                               # gaussian_model.py:97
-        self._rots = torch.nn.functional.normalize(v["rotation"])            # :101
-        self._opac = torch.sigmoid(v["opacity"])                             # :117
+        return rasterizer.forward_raw(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None,
+                                      self._settings(cam, bg), flags=_lib.FLAG_PREACT)
 
     def step(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
-        """One event iteration.  Returns the (device) loss tensor; no host synchronisation besides the
-        rasteriser's own instance-count read-back."""
+        """One event iteration (train.py:97-332 without densification).  Returns the device scalars tensor of
+        the loss kernel ([0] = loss); the only host synchronisations are the rasteriser's three
+        instance-count read-backs."""
         self.iteration += 1
         it = self.iteration
         self.flat_grad.zero_()
-        self.c.grad = None
-        self._activations()
-        r0 = self.render(cam_int, bg)
-        r1 = self.render(cam_now, bg)
-        r2 = self.render(cam_next, bg)
-        loss = losses.event_iteration_loss(r0["render"], r1["render"], r2["render"], self.c, gt_int, gt_now, gt_next,
-                                           gt_blur)
-        loss.backward()
+        raws = [self.render_raw(c, bg) for c in (cam_int, cam_now, cam_next)]       # train.py:144,159,161
+        if self._loss_bufs is None:
+            img = raws[0]["color"]
+            self._loss_bufs = (torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(img),
+                               torch.empty_like(img), torch.empty_like(img),
+                               torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(img.shape[2], img.shape[1]),
+                                           dtype=torch.uint8, device=self.device))
+        scalars, d_image, d_now, d_next = losses.event_loss_raw(raws[0]["color"], raws[1]["color"], raws[2]["color"],
+                                                                self.c, gt_int, gt_now, gt_next, gt_blur,
+                                                                out=self._loss_bufs)          # train.py:165-203
+        g = self.grads
+        out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
+        for k, (raw, dpix) in enumerate(zip(raws, (d_image, d_now, d_next))):         # loss.backward(), train.py:211
+            self.acc.zero_()
+            o = dict(out)
+            if k == 0 and self.track_stats:
+                o["means2D"] = self.viewspace_grad          # densification statistics use render #1 only (train.py:145)
+            rasterizer.backward_raw(raw, dpix, o, flags=_lib.FLAG_PREACT | _lib.FLAG_ACCUMULATE, grad_acc=self.acc)
+        self.c_grad.copy_(scalars[1:2])
         if self.world > 1 and sync_grads:
-            # view-parallel data parallelism: one all-reduce of the 59 floats/Gaussian (+ c)
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            dist.all_reduce(self.c.grad, op=dist.ReduceOp.SUM, group=self.pg)
-            self.flat_grad.div_(self.world)
-            self.c.grad.div_(self.world)
-        self.c_opt.step()                                                   # train.py:212
+            parallel.allreduce_mean_(self.flat_grad, self.pg)      # ONE collective: 59 floats/Gaussian + c
         self._adam(it)
-        self.last_render = r0
-        return loss
+        self.last_radii = raws[0]["radii"]
+        self.last_scalars = scalars
+        return scalars
 
     def _adam(self, it):
-        for name, _ in SEGMENTS:
+        for name, _ in SEGMENTS + (("c", 1),):
             off, n = self.seg[name]
             sl = slice(off, off + n)
+            eps = 1e-15                                             # scene/gaussian_model.py:163
             if name == "xyz":
                 lr, kw = self.xyz_lr(it), {}
             elif name == "features":
                 lr, kw = self.lrs["features"], dict(lr_b=self.lrs["features_rest"], period=48, split=3)
+            elif name == "c":
+                lr, kw, eps = self.c_lr, {}, 1e-8                   # torch.optim.Adam([c], lr=0.1), train.py:73
             else:
                 lr, kw = self.lrs[name], {}
-            losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, **kw)
+            losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, eps=eps,
+                              **kw)
+
+    # ------------------------------------------------------------------ reference-style path (autograd)
+    def step_autograd(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):
+        """Same iteration through torch autograd: torch activations (gaussian_model.py:95-118), the drop-in
+        rasteriser operator with in-kernel SH, the autograd event loss.  Gradients land in flat_grad."""
+        self.iteration += 1
+        it = self.iteration
+        self.flat_grad.zero_()
+        leaves = {k: v.detach().requires_grad_(True) for k, v in self.views.items()}
+        c = self.c.detach().clone().requires_grad_(True)
+        scales, rots = torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"])
+        opac = torch.sigmoid(leaves["opacity"])
+        imgs = []
+        for cam in (cam_int, cam_now, cam_next):
+            m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
+            img, radii = rasterize_gaussians(leaves["xyz"], m2, leaves["features"], None, opac, scales, rots, None,
+                                             self._settings(cam, bg))
+            imgs.append(img)
+        loss = losses.event_iteration_loss(imgs[0], imgs[1], imgs[2], c, gt_int, gt_now, gt_next, gt_blur)
+        loss.backward()
+        for k, v in leaves.items():
+            self.grads[k].copy_(v.grad)
+        self.c_grad.copy_(c.grad)
+        self._adam(it)
+        return loss

@@ -41,6 +41,15 @@ int e3dgs_abi_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* e3dgs_last_error(void);
 
+/* flags for e3dgs_rasterize_forward / e3dgs_rasterize_backward */
+#define E3DGS_FLAG_PREACT 1      /* scales = log-scales, rotations = raw quaternions, opacities = logits: the
+                                    activations of scene/gaussian_model.py:95-118 (exp, normalize, sigmoid) run
+                                    inside the kernels, and backward returns gradients w.r.t. the raw parameters */
+#define E3DGS_FLAG_ACCUMULATE 2  /* backward ADDS into dL_dmean3D / dL_dsh / dL_dscale / dL_drot / dL_dopacity /
+                                    dL_dcolor / dL_dcov3D (visible Gaussians only) instead of overwriting them: the
+                                    three renders of one training iteration (train.py:144,159,161) accumulate
+                                    straight into one gradient buffer */
+
 /*
  * Forward rasterisation of P Gaussians into a (3,H,W) planar fp32 image.
  * Replaces: diff_gaussian_rasterization._C.rasterize_gaussians, called by
@@ -79,6 +88,7 @@ int e3dgs_rasterize_forward(
     float* out_color,                 /* (3,H,W) */
     int* radii,                       /* (P) */
     int debug,
+    int flags,                        /* E3DGS_FLAG_PREACT or 0 */
     int* num_rendered_host,
     void* stream);
 
@@ -87,16 +97,18 @@ int e3dgs_rasterize_forward(
  * diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
  * loss.backward() at train.py:211 through _RasterizeGaussians.backward.
  *
- * All dL_d* outputs must be zero-filled by the caller.  dL_dmean2D is (P,3)
- * with the third component left 0 and the first two in NDC units
- * (consumed by scene/gaussian_model.py:405-407).  dL_dcov3D (P,6) is always
- * written (it is the returned gradient when cov3D_precomp was given, scratch
- * otherwise).
+ * grad_acc (P,12) must be ZERO-FILLED by the caller: the compositing backward accumulates
+ * into it atomically (per Gaussian: dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad).
+ * Without E3DGS_FLAG_ACCUMULATE every other output is written in full (zeros for culled
+ * Gaussians), so nothing else needs pre-zeroing.  dL_dmean2D is (P,3): first two components in
+ * NDC units (consumed by scene/gaussian_model.py:405-407), third 0; always overwritten.
+ * Optional outputs may be NULL: dL_dmean2D, dL_dopacity, dL_dcolor, dL_dcov3D.
  */
 int e3dgs_rasterize_backward(
     int P, int D, int M, int num_rendered,
     const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp,
+    const float* opacities,           /* (P): only read with E3DGS_FLAG_PREACT */
     const float* scales, float scale_modifier, const float* rotations,
     const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
@@ -104,16 +116,17 @@ int e3dgs_rasterize_backward(
     const int* radii,
     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
     const float* dL_dpix,             /* (3,H,W) */
-    float* dL_dmean2D,                /* (P,3) */
-    float* dL_dconic,                 /* (P,4) scratch */
-    float* dL_dopacity,               /* (P) */
-    float* dL_dcolor,                 /* (P,3) */
+    float* grad_acc,                  /* (P,12) zero-filled scratch */
+    float* dL_dmean2D,                /* (P,3) or NULL */
+    float* dL_dopacity,               /* (P) or NULL */
+    float* dL_dcolor,                 /* (P,3) or NULL */
     float* dL_dmean3D,                /* (P,3) */
-    float* dL_dcov3D,                 /* (P,6) */
+    float* dL_dcov3D,                 /* (P,6) or NULL */
     float* dL_dsh,                    /* (P,M,3) or NULL */
     float* dL_dscale,                 /* (P,3) or NULL */
     float* dL_drot,                   /* (P,4) or NULL */
     int debug,
+    int flags,
     void* stream);
 
 /*

@@ -1,0 +1,152 @@
+"""GPU tests of the pieces around the rasteriser: fused pre-activation path, event loss, Adam, distCUDA2,
+and the fused training step against the autograd (reference-style) step."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scene(N=3000, W=176, H=128, seed=0):
+    from event_3dgs_amd import synth
+    from event_3dgs_amd.cameras import orbit_camera
+    params = synth.make_scene(N, "trained", seed=seed, device=DEV)
+    cams = [orbit_camera(0, 16, W, H, device=DEV, daz=d) for d in (0.0, 0.004, 0.012)]
+    return params, cams
+
+
+def _gts(params, cams, bg):
+    from event_3dgs_amd.train_step import EventTrainer
+    gp = dict(params)
+    gp["xyz"] = params["xyz"] + 0.01 * torch.randn(params["xyz"].shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    t = EventTrainer(gp, DEV)
+    return [t.render_raw(c, bg)["color"].clone() for c in cams]
+
+
+def test_preact_forward_matches_torch_activations():
+    """E3DGS_FLAG_PREACT (exp / normalize / sigmoid inside the kernel) == torch activations + plain path."""
+    from event_3dgs_amd import _lib, rasterizer, synth
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene()
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    tr = EventTrainer(params, DEV)
+    raw = tr.render_raw(cams[0], bg)
+    act = synth.activate(params)
+    ref = rasterizer.forward_raw(act["means3D"], act["shs"], None, act["opacities"], act["scales"], act["rotations"],
+                                 None, tr._settings(cams[0], bg))
+    assert (raw["radii"] != ref["radii"]).sum().item() <= 2          # activations differ by an ulp at most
+    assert (raw["color"] - ref["color"]).abs().max().item() <= 1e-4   # north_star image tolerance
+    assert (raw["color"] - ref["color"]).abs().mean().item() <= 1e-6
+
+
+@pytest.mark.parametrize("deblur", [False, True])
+def test_fused_step_equals_autograd_step(deblur):
+    """The no-autograd fused iteration produces the same gradients and the same parameter update as the
+    reference-style iteration (torch activations + drop-in operator + autograd event loss)."""
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene()
+    bg = torch.zeros(3, device=DEV)
+    gts = _gts(params, cams, bg)
+    blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
+    a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
+    sa = a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+    lb = b.step_autograd(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+    torch.cuda.synchronize()
+    assert abs(float(sa[0]) - float(lb)) <= 1e-5 * abs(float(lb))
+    for name in ("xyz", "features", "opacity", "scaling", "rotation"):
+        ga, gb = a.grads[name].cpu().numpy(), b.grads[name].cpu().numpy()
+        assert np.abs(gb).max() > 0
+        assert rel_l2(ga, gb) <= 1e-3, (name, rel_l2(ga, gb))
+    assert abs(float(a.c_grad) - float(b.c_grad)) <= 1e-4 * abs(float(b.c_grad))
+    # Adam moments agree to the gradient tolerance (the update itself is sign-like at step 1, so compare moments)
+    assert rel_l2(a.exp_avg.cpu().numpy(), b.exp_avg.cpu().numpy()) <= 1e-3
+    assert float((a.flat - b.flat).abs().max()) <= 0.25            # one Adam step moves each parameter by <= lr
+
+
+def test_event_loss_kernel_matches_reference_golden():
+    from event_3dgs_amd import losses
+    g = np.load(os.path.join(GOLDEN, "event_loss.npz"))
+    T = lambda k: torch.tensor(g[k], device=DEV)
+    for tag, blur in (("", None), ("_deblur", T("gt_blur"))):
+        c = torch.tensor([float(g["c" + tag])], device=DEV)
+        sc, d_image, d_now, d_next = losses.event_loss_raw(T("image"), T("now"), T("next"), c, T("gt_int"),
+                                                           T("gt_now"), T("gt_next"), blur)
+        sc = sc.cpu().numpy()
+        assert abs(sc[0] - float(g["loss" + tag])) <= 2e-6 * abs(float(g["loss" + tag]))
+        assert abs(sc[2] - float(g["rho"])) <= 1e-6
+        assert abs(sc[1] - float(g["d_c" + tag])) <= 5e-5 * abs(float(g["d_c" + tag]))
+        for name, t in (("d_image", d_image), ("d_now", d_now), ("d_next", d_next)):
+            ref = g[name + tag]
+            assert np.abs(t.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-9, name
+    # autograd wrapper
+    img, now, nxt = (T(k).requires_grad_(True) for k in ("image", "now", "next"))
+    c = torch.tensor(float(g["c"]), device=DEV, requires_grad=True)
+    loss = losses.event_iteration_loss(img, now, nxt, c, T("gt_int"), T("gt_now"), T("gt_next"))
+    (2.0 * loss).backward()
+    assert np.abs(now.grad.cpu().numpy() - 2.0 * g["d_now"]).max() <= 4e-5 * np.abs(g["d_now"]).max() + 1e-9
+    assert abs(float(c.grad) - 2.0 * float(g["d_c"])) <= 1e-4 * abs(float(g["d_c"]))
+
+
+def test_adam_kernel_matches_torch_adam():
+    from event_3dgs_amd import losses
+    g = torch.Generator().manual_seed(0)
+    n = 48 * 1000
+    p0 = torch.randn(n, generator=g)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    ref_rest = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=2.5e-3, eps=1e-15)
+    opt2 = torch.optim.Adam([ref_rest], lr=2.5e-3 / 20, eps=1e-15)
+    dc = (torch.arange(n) % 48) < 3
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=g)))
+        ref.grad = grad.clone(); ref_rest.grad = grad.clone()
+        opt.step(); opt2.step()
+        losses.adam_step_(p, grad.to(DEV), m, v, 2.5e-3, step, lr_b=2.5e-3 / 20, period=48, split=3)
+    expect = torch.where(dc, ref.detach(), ref_rest.detach())
+    assert float((p.cpu() - expect).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("P", [5, 777, 20000])
+def test_dist_knn3_is_exact(P):
+    from simple_knn._C import distCUDA2
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(P)
+    pts = torch.rand(P, 3, generator=g) * torch.tensor([2.6, 2.6, 0.7]) - 1.3
+    if P >= 700:
+        pts[5] = pts[9]                       # duplicated point -> distance 0 contributes
+        pts[100:200] *= 0.01                  # dense cluster (non-uniform cells)
+    got = distCUDA2(pts.to(DEV)).cpu().numpy()
+    if P <= 5000:
+        ref = c_oracle.knn3(pts.numpy())
+    else:
+        from scipy.spatial import cKDTree
+        d, _ = cKDTree(pts.numpy().astype(np.float64)).query(pts.numpy().astype(np.float64), k=4)
+        ref = (d[:, 1:] ** 2).mean(1)
+    assert np.allclose(got, ref, rtol=2e-5, atol=1e-12)
+
+
+def test_training_reduces_loss_and_tracks_reference_trainer():
+    """A short run: the fused trainer and the autograd trainer stay together and the loss goes down."""
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene(N=4000, W=160, H=112, seed=3)
+    bg = torch.zeros(3, device=DEV)
+    gts = _gts(params, cams, bg)
+    a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
+    la, lb = [], []
+    for _ in range(30):
+        la.append(float(a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)[0]))
+        lb.append(float(b.step_autograd(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)))
+    assert la[-1] < 0.9 * la[0]
+    assert abs(la[-1] - lb[-1]) <= 0.03 * abs(lb[-1])
+    psnr = lambda x, y: 20 * math.log10(1.0 / math.sqrt(float(((x - y) ** 2).mean())))
+    ia, ib = a.render_raw(cams[0], bg)["color"], b.render_raw(cams[0], bg)["color"]
+    assert abs(psnr(ia, gts[0]) - psnr(ib, gts[0])) <= 0.1          # north_star: PSNR within 0.1 dB
