@@ -13,6 +13,8 @@
 constexpr int BWD_WAVES = 4;
 
 extern unsigned long long* g_trace;
+__global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ work,
+                                  uint32_t* __restrict__ order);
 __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;
     const int tile = (int)order[unit];
-    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
@@ -64,8 +66,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     maxc = wave_max_u32(maxc);
     const uint2 range = ranges[tile];
     const int n = (int)maxc;   // entries [0, n) of the tile list can contribute
-    const unsigned long long t_loop = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long seg_k = 0, seg_r = 0;
+    const unsigned long long t_loop = trace ? wall_clock64() : 0ull;
 
     // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
@@ -85,7 +86,6 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
         }
         unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; ++j) {
-            const unsigned long long tA = trace ? __builtin_amdgcn_s_memtime() : 0ull;
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
             const float2 c = sC[wave][j];
@@ -129,8 +129,6 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
                     }
                 }
             }
-            const unsigned long long tB = trace ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (trace) seg_k += tB - tA;
             if (__builtin_amdgcn_ballot_w64(any) != 0) {
                 touched |= 1ull << j;
                 Sx = wave_sum_to_lane63(Sx); Sy = wave_sum_to_lane63(Sy);
@@ -145,7 +143,6 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
                     sPart[wave][j][2].x = Sc2;
                 }
             }
-            if (trace) seg_r += __builtin_amdgcn_s_memtime() - tB;
         }
         wave_sync();
         if ((touched >> lane) & 1ull) {
@@ -161,9 +158,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;
-        trace[4 * (size_t)tile + 1] = __builtin_amdgcn_s_memtime();
+        trace[4 * (size_t)tile + 1] = wall_clock64();
         trace[4 * (size_t)tile + 2] = ((unsigned long long)(range.y - range.x) << 32) | (unsigned)n;
-        trace[4 * (size_t)tile + 3] = ((seg_k >> 4) << 40) | ((seg_r >> 4) << 16) | ((t_loop - t_start) >> 8);
+        trace[4 * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
+                                      (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        (void)t_loop;
     }
 }
 
@@ -449,8 +448,9 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
     if (num_rendered > 0) {
         ProfScope ps(PS_RENDER_BWD, s);
+        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC,
+            g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC,
             background, img.final_T, img.n_contrib, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");

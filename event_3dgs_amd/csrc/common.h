@@ -196,7 +196,9 @@ struct ImageState {
     uint2* ranges;       // per tile [start, end) into point_list
     float* final_T;      // per pixel
     uint32_t* n_contrib; // per pixel
-    uint32_t* order;     // tiles by descending list length (launch order of the compositing kernels)
+    uint32_t* order;     // tiles by descending list length (launch order of the forward compositing kernel)
+    uint32_t* work;      // per tile: entries the backward walk has to visit (max n_contrib), written by forward
+    uint32_t* order_bwd; // tiles by descending `work` (launch order of the backward compositing kernel)
     static size_t required(size_t npix, size_t ntiles) {
         char* p = nullptr;
         from(p, npix, ntiles);
@@ -208,6 +210,8 @@ struct ImageState {
         s.final_T = carve<float>(p, npix ? npix : 1);
         s.n_contrib = carve<uint32_t>(p, npix ? npix : 1);
         s.order = carve<uint32_t>(p, ntiles ? ntiles : 1);
+        s.work = carve<uint32_t>(p, ntiles ? ntiles : 1);
+        s.order_bwd = carve<uint32_t>(p, ntiles ? ntiles : 1);
         return s;
     }
 };

@@ -314,13 +314,15 @@ constexpr int RENDER_WAVES = 4;
 // block max -> 1024-bucket histogram in LDS -> scan -> scatter.  Order inside a bucket is arbitrary, which
 // only affects scheduling, never results.
 __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ work,
                                                           uint32_t* __restrict__ order) {
+    auto key = [&](int t) -> uint32_t { if (work) return work[t]; uint2 r = ranges[t]; return r.y - r.x; };
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t smax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t m = 0;
-    for (int t = tid; t < ntiles; t += 1024) { uint2 r = ranges[t]; m = max(m, r.y - r.x); }
+    for (int t = tid; t < ntiles; t += 1024) m = max(m, key(t));
     m = wave_max_u32(m);
     if (lane == 0) wsum[wave] = m;
     hist[tid] = 0;
@@ -328,10 +330,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
     if (tid == 0) { uint32_t x = 0; for (int w = 0; w < 16; ++w) x = max(x, wsum[w]); smax = x; }
     __syncthreads();
     const uint32_t width = smax / 1024u + 1u;
-    for (int t = tid; t < ntiles; t += 1024) {
-        uint2 r = ranges[t];
-        atomicAdd(&hist[1023u - min(1023u, (r.y - r.x) / width)], 1u);
-    }
+    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[1023u - min(1023u, key(t) / width)], 1u);
     __syncthreads();
     // exclusive scan of hist (one bucket per thread)
     uint32_t v = hist[tid], inc = v;
@@ -345,8 +344,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
     hist[tid] = woff + inc - v;
     __syncthreads();
     for (int t = tid; t < ntiles; t += 1024) {
-        uint2 r = ranges[t];
-        uint32_t pos = atomicAdd(&hist[1023u - min(1023u, (r.y - r.x) / width)], 1u);
+        uint32_t pos = atomicAdd(&hist[1023u - min(1023u, key(t) / width)], 1u);
         order[pos] = (uint32_t)t;
     }
 }
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
     const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
     __shared__ float4 sB[RENDER_WAVES][WAVE];
     __shared__ float2 sC[RENDER_WAVES][WAVE];
@@ -365,7 +363,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     const int unit = blockIdx.x * RENDER_WAVES + wave;
     if (unit >= ntiles) return;
     const int tile = (int)order[unit];
-    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     int processed = 0;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * E3_TILE + (lane & 15);
@@ -438,9 +436,14 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) T[k] = fabsf(T[k]);
+    {
+        uint32_t mw = max(max(last[0], last[1]), max(last[2], last[3]));
+        mw = wave_max_u32(mw);
+        if (lane == 0) tile_work[tile] = mw;
+    }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;
-        trace[4 * (size_t)tile + 1] = __builtin_amdgcn_s_memtime();
+        trace[4 * (size_t)tile + 1] = wall_clock64();
         trace[4 * (size_t)tile + 2] = ((unsigned long long)n << 32) | (unsigned)processed;
         trace[4 * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
                                       (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
@@ -592,13 +595,13 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
     }
     {
     ProfScope ps(PS_RANGES, s);
-    tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.order);
+    tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, nullptr, img.order);
     }
     KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
         g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
-        img.final_T, img.n_contrib);
+        img.final_T, img.n_contrib, img.work);
     KERNEL_OK("render_fwd_kernel");
     return 0;
 }

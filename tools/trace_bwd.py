@@ -31,11 +31,22 @@ run(buf.data_ptr())
 t = buf.cpu().numpy().reshape(T, 4)
 dur = t[:, 1] - t[:, 0]
 n_list, n = t[:, 2] >> 32, t[:, 2] & 0xFFFFFFFF
-pro = (t[:, 3] & 0xFFFF) << 8
-segk = ((t[:, 3] >> 40) & 0xFFFFFF) << 4
-segr = ((t[:, 3] >> 16) & 0xFFFFFF) << 4
-print('per-entry cycles: k-blocks', (segk / np.maximum(t[:, 2] & 0xFFFFFFFF, 1)).mean(), 'reduce+atomics', (segr / np.maximum(t[:, 2] & 0xFFFFFFFF, 1)).mean())
-print("mean wave dur", dur.mean(), "max", dur.max(), "prologue mean/max", pro.mean(), pro.max())
-print("list mean", n_list.mean(), "walked mean", n.mean(), "max", n.max())
-cpe = (dur - pro) / np.maximum(n, 1)
-print("cycles per walked entry mean", cpe.mean(), "p10/p50/p90", np.percentile(cpe, [10, 50, 90]))
+xcc, hw = (t[:, 3] >> 32) & 0xF, t[:, 3] & 0xFFFFFFFF
+cu, se, simd = (hw >> 8) & 0xF, (hw >> 13) & 0x7, (hw >> 4) & 0x3
+print("mean wave dur", dur.mean(), "max", dur.max(), "walked mean", n.mean(), "max", n.max(), "cycles/entry p10/50/90", np.percentile(dur / np.maximum(n, 1), [10, 50, 90]))
+print("global span (10ns ticks)", t[:, 1].max() - t[:, 0].min())
+T0 = t[:, 0].min(); SPAN = t[:, 1].max() - T0
+for x in range(8):
+    m = xcc == x
+    s0, e0 = t[m, 0], t[m, 1]
+    t0 = T0; span = SPAN
+    # active waves over time (20 buckets)
+    edges = np.linspace(0, span, 21)
+    act = [int(((s0 - t0) < edges[i + 1]) .sum() - ((e0 - t0) < edges[i]).sum()) for i in range(20)]
+    busy = dur[m].sum()
+    print(f"xcc{x}: waves {m.sum()} span {span} avg active {busy / span:.0f} (slots 640) profile {act}")
+key = xcc * 10000 + se * 1000 + cu * 10 + simd
+import collections
+per = collections.defaultdict(list)
+for k, s_, e_ in zip(key, t[:, 0], t[:, 1]): per[k].append((s_, e_))
+print("SIMDs seen", len(per), "waves per SIMD min/mean/max", min(map(len, per.values())), np.mean(list(map(len, per.values()))), max(map(len, per.values())))
