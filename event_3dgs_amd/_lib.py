@@ -39,6 +39,13 @@ def lib():
     L.e3dgs_rasterize_forward.argtypes = (
         [ALLOC_FN, _vp] * 3 + [C.c_int] * 3 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5
         + [C.c_float, C.c_float, C.c_int, _fp, _ip, C.c_int, C.c_int, C.POINTER(C.c_int), _vp])
+    L.e3dgs_rasterize_forward_begin.restype = C.c_int
+    L.e3dgs_rasterize_forward_begin.argtypes = (
+        [ALLOC_FN, _vp] * 2 + [C.c_int] * 5 + [_fp] * 5 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float, _ip, C.c_int,
+                                                                                   C.c_int, _vp, _vp])
+    L.e3dgs_rasterize_forward_finish.restype = C.c_int
+    L.e3dgs_rasterize_forward_finish.argtypes = [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp, C.c_int, _fp,
+                                                 C.c_int, _vp]
     L.e3dgs_rasterize_backward.restype = C.c_int
     L.e3dgs_rasterize_backward.argtypes = (
         [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
@@ -91,7 +98,8 @@ FLAG_ACCUMULATE = 2
 ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [
-    "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_backward",
+    "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
+    "e3dgs_rasterize_backward",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_state_offsets", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

@@ -43,10 +43,12 @@ void prof_end(int slot, hipStream_t s) {
     g_open[slot] = false;
 }
 
-int e3_forward_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*,
-                    int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
-                    const float*, float, const float*, const float*, const float*, const float*, const float*, float,
-                    float, int, float*, int*, int, int, int*, hipStream_t);
+int e3_forward_begin_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*, int, int, int, int, int,
+                          const float*, const float*, const float*, const float*, const float*, float, const float*,
+                          const float*, const float*, const float*, const float*, float, float, int*, int, int, int*,
+                          hipStream_t);
+int e3_forward_finish_impl(char* (*)(void*, size_t), void*, int, int, int, const float*, char*, char*, int, float*, int,
+                           hipStream_t);
 int e3_backward_impl(int, int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
                      const float*, float, const float*, const float*, const float*, const float*, const float*, float,
                      float, const int*, const char*, const char*, const char*, const float*, float*, float*, float*,
@@ -62,6 +64,8 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
+static int check_forward_args(int P, int D, int M, int width, int height, const float* shs, const float* colors_precomp,
+                              const float* scales, const float* rotations, const float* cov3D_precomp, int flags);
 int e3dgs_abi_version(void) { return 2; }
 const char* e3dgs_last_error(void) { return g_err; }
 
@@ -74,6 +78,30 @@ int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_al
                             float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, int flags,
                             int* num_rendered_host, void* stream) {
     g_err[0] = 0;
+    {
+        int rc0 = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+        if (rc0) return rc0;
+    }
+    struct Keep { e3dgs_alloc_fn fn; void* user; char* ptr; };
+    // remember the two buffers handed out in `begin` so that `finish` can be fed without a second callback
+    static thread_local Keep kg, ki;
+    kg = Keep{geom_alloc, geom_user, nullptr};
+    ki = Keep{image_alloc, image_user, nullptr};
+    auto grab_g = [](void* u, size_t n) -> char* { Keep* k = (Keep*)u; k->ptr = k->fn(k->user, n); return k->ptr; };
+    int count = 0;
+    int rc = e3_forward_begin_impl(grab_g, &kg, grab_g, &ki, P, D, M, width, height, means3D, shs, colors_precomp,
+                                   opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                   cam_pos, tan_fovx, tan_fovy, radii, debug, flags, &count, (hipStream_t)stream);
+    if (rc) return rc;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);   // the op's single device->host synchronisation
+    if (e != hipSuccess) return e3_fail(e, "hipStreamSynchronize (instance count)");
+    *num_rendered_host = count;
+    return e3_forward_finish_impl(binning_alloc, binning_user, P, width, height, background, kg.ptr, ki.ptr, count,
+                                  out_color, debug, (hipStream_t)stream);
+}
+
+static int check_forward_args(int P, int D, int M, int width, int height, const float* shs, const float* colors_precomp,
+                              const float* scales, const float* rotations, const float* cov3D_precomp, int flags) {
     if (P < 0 || width <= 0 || height <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
     if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
         return e3_fail(hipErrorInvalidValue, "provide exactly one of shs / colors_precomp");
@@ -84,10 +112,32 @@ int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_al
         return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
     if ((width + 15) / 16 > 65535 || (height + 15) / 16 > 65535)
         return e3_fail(hipErrorInvalidValue, "image too large for 16-bit tile coordinates");
-    return e3_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
-                           background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                           rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
-                           out_color, radii, debug, flags, num_rendered_host, (hipStream_t)stream);
+    return 0;
+}
+
+int e3dgs_rasterize_forward_begin(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn image_alloc,
+                                  void* image_user, int P, int D, int M, int width, int height, const float* means3D,
+                                  const float* shs, const float* colors_precomp, const float* opacities,
+                                  const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                  const float* cam_pos, float tan_fovx, float tan_fovy, int* radii, int debug, int flags,
+                                  int* num_rendered_host, void* stream) {
+    g_err[0] = 0;
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+    if (rc) return rc;
+    return e3_forward_begin_impl(geom_alloc, geom_user, image_alloc, image_user, P, D, M, width, height, means3D, shs,
+                                 colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                                 projmatrix, cam_pos, tan_fovx, tan_fovy, radii, debug, flags, num_rendered_host,
+                                 (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_forward_finish(e3dgs_alloc_fn binning_alloc, void* binning_user, int P, int width, int height,
+                                   const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
+                                   float* out_color, int debug, void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || num_rendered < 0 || !geom_buffer || !image_buffer) return e3_fail(hipErrorInvalidValue, "bad arguments");
+    return e3_forward_finish_impl(binning_alloc, binning_user, P, width, height, background, geom_buffer, image_buffer,
+                                  num_rendered, out_color, debug, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,

@@ -501,14 +501,15 @@ static int ceil_log2(uint32_t v) {
     return b;
 }
 
-int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (*bin_alloc)(void*, size_t),
-                    void* bin_user, char* (*img_alloc)(void*, size_t), void* img_user, int P, int D, int M,
-                    const float* background, int W, int H, const float* means3D, const float* shs,
-                    const float* colors, const float* opac, const float* scales, float scale_modifier,
-                    const float* rots, const float* cov_pre, const float* view, const float* proj,
-                    const float* campos, float tanfovx, float tanfovy, int prefiltered, float* out_color, int* radii,
-                    int debug, int flags, int* num_rendered_host, hipStream_t s) {
-    (void)prefiltered;
+// Forward is split in two enqueue-only halves around the instance count so that a caller rendering
+// several views can issue every `begin`, synchronise ONCE, and then issue every `finish`
+// (EventTrainer.step does; the one-call e3dgs_rasterize_forward = begin + stream sync + finish).
+int e3_forward_begin_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (*img_alloc)(void*, size_t),
+                          void* img_user, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                          const float* colors, const float* opac, const float* scales, float scale_modifier,
+                          const float* rots, const float* cov_pre, const float* view, const float* proj,
+                          const float* campos, float tanfovx, float tanfovy, int* radii, int debug, int flags,
+                          int* count_host, hipStream_t s) {
     ViewParams vp;
     vp.view = view; vp.proj = proj; vp.campos = campos;
     vp.tanfovx = tanfovx; vp.tanfovy = tanfovy;
@@ -527,9 +528,7 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
     GeomState geom = GeomState::from(gp, P);
     ImageState img = ImageState::from(ip, npix, ntiles);
     HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * sizeof(uint2), s));
-
-    uint32_t I = 0;
-    uint32_t* order = geom.ord0;
+    *count_host = 0;
     if (P > 0) {
         const unsigned pb = (unsigned)((P + 255) / 256);
         {
@@ -539,13 +538,14 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
                                                          geom.rect, geom.key0, geom.ord0);
         }
         KERNEL_OK("preprocess_kernel");
-        uint32_t* keys_sorted;
+        uint32_t *keys_sorted, *order;
         {
         ProfScope ps(PS_SORT_DEPTH, s);
         launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, (size_t)P, 32, geom.scratch, &keys_sorted,
                                 &order, s);
         }
         KERNEL_OK("radix sort (depth)");
+        if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
         const unsigned nwaves = (unsigned)((P + WAVE - 1) / WAVE);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         HIP_OK(hipMemsetAsync(geom.offsets, 0, sizeof(uint32_t), s));
@@ -557,12 +557,22 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
         launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
         }
         KERNEL_OK("bin count + scan");
-        // the single device->host synchronisation of the op: the instance count sizes the binning buffers
-        HIP_OK(hipMemcpyAsync(&I, geom.offsets + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
+        // the instance count sizes the binning buffers: the op's single device->host read-back
+        HIP_OK(hipMemcpyAsync(count_host, geom.offsets + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
-    *num_rendered_host = (int)I;
+    return 0;
+}
 
+int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, int P, int W, int H,
+                           const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
+                           float* out_color, int debug, hipStream_t s) {
+    const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
+    const int ntiles = gx * gy;
+    const uint32_t I = (uint32_t)num_rendered;
+    char* gp = geom_buffer;
+    char* ip = image_buffer;
+    GeomState geom = GeomState::from(gp, P);
+    ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
     char* bp = bin_alloc(bin_user, BinningState::required(I));
     if (!bp) return e3_fail(hipErrorOutOfMemory, "binning allocation callback returned NULL");
     BinningState bin = BinningState::from(bp, I);
@@ -576,7 +586,7 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.recA, geom.recB, vp.gx,
+        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, geom.ord0, geom.rect, geom.recA, geom.recB, gx,
                                                                     g_tile_cull, geom.offsets, nullptr, k0, v0);
         }
         KERNEL_OK("bin emit");
@@ -600,8 +610,8 @@ int e3_forward_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (
     KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        g_trace, ntiles, img.order, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background, out_color,
-        img.final_T, img.n_contrib, img.work);
+        g_trace, ntiles, img.order, gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background,
+        out_color, img.final_T, img.n_contrib, img.work);
     KERNEL_OK("render_fwd_kernel");
     return 0;
 }

@@ -115,6 +115,62 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
                 geom=geom.tensor, binning=binning.tensor, image=img.tensor)
 
 
+class PendingForward:
+    """Result of forward_begin(); finish() it after the stream has been synchronised."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def forward_begin(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, flags=0,
+                  count_host=None):
+    """Enqueue-only first half of the forward (e3dgs_rasterize_forward_begin).  `count_host` is a pinned
+    int32 host tensor with one element that receives the instance count asynchronously."""
+    L = _lib.lib()
+    rs = raster_settings
+    dev = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D_c = _prep(means3D, "means3D")
+    sh_c, colors_c, opac_c = _prep(sh, "shs"), _prep(colors_precomp, "colors_precomp"), _prep(opacities, "opacities")
+    scales_c, rots_c, cov_c = _prep(scales, "scales"), _prep(rotations, "rotations"), _prep(cov3Ds_precomp, "cov3D_precomp")
+    bg = _prep(rs.bg, "bg"); view = _prep(rs.viewmatrix, "viewmatrix")
+    proj = _prep(rs.projmatrix, "projmatrix"); campos = _prep(rs.campos, "campos")
+    M = 0 if sh_c is None else sh_c.shape[1]
+    if count_host is None:
+        count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    geom, img = _Scratch(dev), _Scratch(dev)
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_rasterize_forward_begin(
+            geom.cb, None, img.cb, None, P, int(rs.sh_degree), M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c),
+            _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(scales_c), float(rs.scale_modifier), _lib.ptr(rots_c),
+            _lib.ptr(cov_c), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
+            _lib.ptr(radii), int(bool(rs.debug)), int(flags), count_host.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_forward_begin")
+    return PendingForward(rs=rs, flags=int(flags), P=P, W=W, H=H, M=M, radii=radii, geom=geom.tensor, image=img.tensor,
+                          inputs=(means3D_c, sh_c, colors_c, scales_c, rots_c, cov_c), opacities=opac_c,
+                          consts=(bg, view, proj, campos), count_host=count_host, device=dev)
+
+
+def forward_finish(pending):
+    """Second half; the caller has synchronised the stream since forward_begin()."""
+    L = _lib.lib()
+    p = pending
+    I = int(p.count_host[0])
+    out_color = torch.empty(3, p.H, p.W, dtype=torch.float32, device=p.device)
+    binning = _Scratch(p.device)
+    with torch.cuda.device(p.device):
+        rc = L.e3dgs_rasterize_forward_finish(binning.cb, None, p.P, p.W, p.H, _lib.ptr(p.consts[0]), _lib.ptr(p.geom),
+                                              _lib.ptr(p.image), I, _lib.ptr(out_color), int(bool(p.rs.debug)),
+                                              _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_forward_finish")
+    return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, flags=p.flags, inputs=p.inputs,
+                opacities=p.opacities, consts=p.consts, geom=p.geom, binning=binning.tensor, image=p.image)
+
+
 def state_views(raw, P, W, H):
     """Typed views into the scratch buffers of a forward_raw() result (tests / tools)."""
     import ctypes as C

@@ -97,6 +97,7 @@ class EventTrainer:
         self.acc = torch.empty(N, _lib.ACC_STRIDE, dtype=torch.float32, device=self.device)
         self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if track_densification_stats else None
         self._loss_bufs = None
+        self._counts = None
         self.last_radii = None
         self.last_scalars = None
 
@@ -121,7 +122,16 @@ class EventTrainer:
         self.iteration += 1
         it = self.iteration
         self.flat_grad.zero_()
-        raws = [self.render_raw(c, bg) for c in (cam_int, cam_now, cam_next)]       # train.py:144,159,161
+        # train.py:144,159,161 -- three renders; every `begin` is enqueued first, ONE host sync reads the
+        # three instance counts, then every `finish` (tile sort + compositing) is enqueued
+        v = self.views
+        if self._counts is None:
+            self._counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(3)]
+        pend = [rasterizer.forward_begin(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None,
+                                         self._settings(c, bg), flags=_lib.FLAG_PREACT, count_host=self._counts[k])
+                for k, c in enumerate((cam_int, cam_now, cam_next))]
+        torch.cuda.current_stream().synchronize()
+        raws = [rasterizer.forward_finish(p) for p in pend]
         if self._loss_bufs is None:
             img = raws[0]["color"]
             self._loss_bufs = (torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(img),

@@ -93,6 +93,27 @@ int e3dgs_rasterize_forward(
     void* stream);
 
 /*
+ * The same forward as two enqueue-only halves around the instance count.  A caller that renders
+ * several views per iteration (train.py:144,159,161) issues every `begin`, synchronises the stream
+ * ONCE, then issues every `finish`: one host synchronisation per iteration instead of one per render.
+ *   begin : preprocess, depth sort, tile counting; enqueues the async copy of the instance count into
+ *           *num_rendered_host (use pinned host memory); allocates geom + image scratch.
+ *   finish: after the stream has been synchronised and *num_rendered_host read: binning, tile sort,
+ *           compositing into out_color.  geom_buffer / image_buffer are the pointers `begin` obtained.
+ * e3dgs_rasterize_forward(...) == begin + hipStreamSynchronize + finish.
+ */
+int e3dgs_rasterize_forward_begin(
+    e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+    int* radii, int debug, int flags, int* num_rendered_host, void* stream);
+int e3dgs_rasterize_forward_finish(
+    e3dgs_alloc_fn binning_alloc, void* binning_user, int P, int width, int height, const float* background,
+    char* geom_buffer, char* image_buffer, int num_rendered, float* out_color, int debug, void* stream);
+
+/*
  * Backward of the above.  Replaces:
  * diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
  * loss.backward() at train.py:211 through _RasterizeGaussians.backward.
