@@ -24,10 +24,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     __shared__ float4 sB[BWD_WAVES][WAVE];
     __shared__ float2 sC[BWD_WAVES][WAVE];
     __shared__ uint32_t sId[BWD_WAVES][WAVE];
-    // per-round gradient staging: lane 63 parks the 9 reduced sums of entry j here; at the end of the
-    // round lane l commits entry l, so the global atomics are 9 full-width instructions per 64 entries
-    // instead of 576 single-lane ones
-    __shared__ float4 sPart[BWD_WAVES][WAVE][3];
+    // Gradient staging.  Per entry the nine per-lane sums are reduced only WITHIN each row of 16 lanes, with a
+    // transposed butterfly (after the xor-1 / xor-2 quad steps every lane owns two of the eight values, so the
+    // later steps move a quarter of the data): 26 DPP/select ops instead of 54.  The four row partials are parked
+    // here and every 16 entries lanes 0..15 add the rows, convert to conic / mean gradients and commit with nine
+    // 16-lane atomic instructions (instead of 9 single-lane atomics per entry).
+    __shared__ float4 sPart[BWD_WAVES][16][4][3];   // [entry & 15][row of 16 lanes][12 floats]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     const size_t HW = (size_t)H * W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
 
     // Per-pixel state of the back-to-front walk.  With C = sum_j c_j a_j T_j + T_final bg and
     // T_j = prod_{i<j}(1 - a_i):   dC/da_g = c_g T_g - (sum_{j>g} c_j a_j T_j + T_final bg) / (1 - a_g).
@@ -131,28 +134,65 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
             }
             if (__builtin_amdgcn_ballot_w64(any) != 0) {
                 touched |= 1ull << j;
-                Sx = wave_sum_to_lane63(Sx); Sy = wave_sum_to_lane63(Sy);
-                Sxx = wave_sum_to_lane63(Sxx); Sxy = wave_sum_to_lane63(Sxy); Syy = wave_sum_to_lane63(Syy);
-                So = wave_sum_to_lane63(So);
-                Sc0 = wave_sum_to_lane63(Sc0); Sc1 = wave_sum_to_lane63(Sc1); Sc2 = wave_sum_to_lane63(Sc2);
-                if (lane == 63) {
-                    // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
-                    sPart[wave][j][0] = make_float4(-(a.z * Sx + a.w * Sy) * ddelx_dx, -(b.x * Sy + a.w * Sx) * ddely_dy,
-                                                    -0.5f * Sxx, -Sxy);
-                    sPart[wave][j][1] = make_float4(-0.5f * Syy, So, Sc0, Sc1);
-                    sPart[wave][j][2].x = Sc2;
+                // V = [Sx, Sy, Sxx, Sxy | Syy, So, Sc0, Sc1]; step 1 pairs lanes l, l^1; step 2 lanes l, l^2
+                float r0, r1, r2, r3;
+                {
+                    const float k0 = odd1 ? Syy : Sx, s0 = odd1 ? Sx : Syy;
+                    const float k1 = odd1 ? So : Sy, s1 = odd1 ? Sy : So;
+                    const float k2 = odd1 ? Sc0 : Sxx, s2 = odd1 ? Sxx : Sc0;
+                    const float k3 = odd1 ? Sc1 : Sxy, s3 = odd1 ? Sxy : Sc1;
+                    r0 = k0 + dpp_f<DPP_QUAD_XOR1>(s0); r1 = k1 + dpp_f<DPP_QUAD_XOR1>(s1);
+                    r2 = k2 + dpp_f<DPP_QUAD_XOR1>(s2); r3 = k3 + dpp_f<DPP_QUAD_XOR1>(s3);
                 }
+                float u0, u1;
+                {
+                    const float k0 = odd2 ? r2 : r0, s0 = odd2 ? r0 : r2;
+                    const float k1 = odd2 ? r3 : r1, s1 = odd2 ? r1 : r3;
+                    u0 = k0 + dpp_f<DPP_QUAD_XOR2>(s0); u1 = k1 + dpp_f<DPP_QUAD_XOR2>(s1);
+                }
+                // class c = lane & 3 now owns: c0 (Sx,Sy)  c1 (Syy,So)  c2 (Sxx,Sxy)  c3 (Sc0,Sc1), summed over its quad
+                u0 += dpp_f<DPP_ROW_ROR4>(u0); u1 += dpp_f<DPP_ROW_ROR4>(u1);
+                u0 += dpp_f<DPP_ROW_ROR8>(u0); u1 += dpp_f<DPP_ROW_ROR8>(u1);
+                float w8 = Sc2 + dpp_f<DPP_QUAD_XOR1>(Sc2);
+                w8 += dpp_f<DPP_QUAD_XOR2>(w8);
+                w8 += dpp_f<DPP_ROW_ROR4>(w8);
+                w8 += dpp_f<DPP_ROW_ROR8>(w8);
+                float* prow = reinterpret_cast<float*>(&sPart[wave][j & 15][lane >> 4][0]);
+                if ((lane & 12) == 0) *reinterpret_cast<float2*>(prow + 2 * (lane & 3)) = make_float2(u0, u1);
+                if ((lane & 15) == 0) prow[8] = w8;
             }
-        }
-        wave_sync();
-        if ((touched >> lane) & 1ull) {
-            const uint32_t id = sId[wave][lane];
-            const float4 p0 = sPart[wave][lane][0], p1 = sPart[wave][lane][1];
-            const float p2 = sPart[wave][lane][2].x;
-            float* g = acc + E3_ACC_STRIDE * (size_t)id;      // one 48-B record: the 9 atomics touch 1-2 cache lines
-            unsafeAtomicAdd(g + 0, p0.x); unsafeAtomicAdd(g + 1, p0.y); unsafeAtomicAdd(g + 2, p0.z);
-            unsafeAtomicAdd(g + 3, p0.w); unsafeAtomicAdd(g + 4, p1.x); unsafeAtomicAdd(g + 5, p1.y);
-            unsafeAtomicAdd(g + 6, p1.z); unsafeAtomicAdd(g + 7, p1.w); unsafeAtomicAdd(g + 8, p2);
+            if ((j & 15) == 15 || j == cnt - 1) {
+                // commit the (up to) 16 entries parked since the last commit
+                const int jb = j & ~15;
+                wave_sync();
+                if (lane < 16 && ((touched >> (jb + lane)) & 1ull)) {
+                    const int e = jb + lane;
+                    float4 p0 = sPart[wave][lane][0][0], p1 = sPart[wave][lane][0][1];
+                    float p2 = sPart[wave][lane][0][2].x;
+#pragma unroll
+                    for (int rr = 1; rr < 4; ++rr) {
+                        const float4 q0 = sPart[wave][lane][rr][0], q1 = sPart[wave][lane][rr][1];
+                        p0.x += q0.x; p0.y += q0.y; p0.z += q0.z; p0.w += q0.w;
+                        p1.x += q1.x; p1.y += q1.y; p1.z += q1.z; p1.w += q1.w;
+                        p2 += sPart[wave][lane][rr][2].x;
+                    }
+                    // slots: p0 = (Sx, Sy, Syy, So)   p1 = (Sxx, Sxy, Sc0, Sc1)   p2 = Sc2
+                    const float4 ea = sA[wave][e];
+                    const float4 eb = sB[wave][e];
+                    float* g = acc + E3_ACC_STRIDE * (size_t)sId[wave][e];   // one 48-B record: 1-2 cache lines
+                    // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
+                    unsafeAtomicAdd(g + 0, -(ea.z * p0.x + ea.w * p0.y) * ddelx_dx);
+                    unsafeAtomicAdd(g + 1, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy);
+                    unsafeAtomicAdd(g + 2, -0.5f * p1.x);
+                    unsafeAtomicAdd(g + 3, -p1.y);
+                    unsafeAtomicAdd(g + 4, -0.5f * p0.z);
+                    unsafeAtomicAdd(g + 5, p0.w);
+                    unsafeAtomicAdd(g + 6, p1.z);
+                    unsafeAtomicAdd(g + 7, p1.w);
+                    unsafeAtomicAdd(g + 8, p2);
+                }
+                wave_sync();
+            }
         }
         wave_sync();
     }
