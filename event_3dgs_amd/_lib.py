@@ -95,6 +95,7 @@ def current_stream():
 
 FLAG_PREACT = 1
 FLAG_ACCUMULATE = 2
+FLAG_SH_PLANAR = 4
 ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [

@@ -211,7 +211,7 @@ template <bool ACCUM>
 __device__ __forceinline__ void put(float* p, float v) { if (ACCUM) *p += v; else *p = v; }
 
 template <bool ACCUM>
-__device__ __forceinline__ void sh_backward(int D, int M, const float* __restrict__ sh, float* __restrict__ dsh,
+__device__ __forceinline__ void sh_backward(int D, int M, const float* __restrict__ sh, float* __restrict__ dsh, size_t st,
                                             float mx, float my, float mz, const float* __restrict__ campos,
                                             uint32_t clamped, const float gin[3], float gmean[3]) {
     const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
@@ -229,8 +229,8 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
     auto term = [&](int k, float Y, float Yx, float Yy, float Yz) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            put<ACCUM>(&dsh[k * 3 + ch], Y * g[ch]);
-            float s = sh[k * 3 + ch] * g[ch];
+            put<ACCUM>(&dsh[(size_t)(k * 3 + ch) * st], Y * g[ch]);
+            float s = sh[(size_t)(k * 3 + ch) * st] * g[ch];
             ddx = FMA(Yx, s, ddx); ddy = FMA(Yy, s, ddy); ddz = FMA(Yz, s, ddz);
         }
     };
@@ -261,7 +261,7 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
         }
     }
     if (!ACCUM)
-        for (int k = (D + 1) * (D + 1); k < M; ++k) { dsh[k * 3] = 0.0f; dsh[k * 3 + 1] = 0.0f; dsh[k * 3 + 2] = 0.0f; }
+        for (int k = 3 * (D + 1) * (D + 1); k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
     float dot = x * ddx + y * ddy + z * ddz;
     gmean[0] += (ddx - x * dot) / len;
     gmean[1] += (ddy - y * dot) / len;
@@ -288,7 +288,12 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
             if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = 0.0f; dL_dcolor[3 * (size_t)i + 1] = 0.0f; dL_dcolor[3 * (size_t)i + 2] = 0.0f; }
             dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
             if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
-            if (dL_dsh) for (int k = 0; k < 3 * M; ++k) dL_dsh[(size_t)i * M * 3 + k] = 0.0f;
+            if (dL_dsh) {
+                const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
+                float* d0 = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
+                const size_t st0 = pl ? (size_t)P : (size_t)1;
+                for (int k = 0; k < 3 * M; ++k) d0[(size_t)k * st0] = 0.0f;
+            }
             if (dL_dscale) { dL_dscale[3 * (size_t)i] = 0.0f; dL_dscale[3 * (size_t)i + 1] = 0.0f; dL_dscale[3 * (size_t)i + 2] = 0.0f; }
             if (dL_drot) for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = 0.0f;
         }
@@ -404,8 +409,9 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     gmean[2] += (Pm[8] * pw - Pm[11] * mul1) * gm2x + (Pm[9] * pw - Pm[11] * mul2) * gm2y;
     if (shs) {
         float gcol[3] = {g12[6], g12[7], g12[8]};
-        sh_backward<ACCUM>(D, M, shs + (size_t)i * M * 3, dL_dsh + (size_t)i * M * 3, mx, my, mz, vp.campos, clamped[i],
-                           gcol, gmean);
+        const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
+        sh_backward<ACCUM>(D, M, pl ? shs + i : shs + (size_t)i * M * 3, pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3,
+                           pl ? (size_t)P : (size_t)1, mx, my, mz, vp.campos, clamped[i], gcol, gmean);
     }
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i], gmean[0]);
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i + 1], gmean[1]);

@@ -17,7 +17,9 @@
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ SH colour
-__device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, float mx, float my, float mz,
+// element (k, ch) of one Gaussian's SH block lives at sh[(k*3 + ch) * st]: st = 1 for the reference's
+// (P,M,3) layout, st = P for the coefficient-major layout (E3_FLAG_SH_PLANAR, coalesced across lanes)
+__device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, size_t st, float mx, float my, float mz,
                                           const float* __restrict__ campos, float rgb[3], uint32_t& clamped) {
     const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
     const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
@@ -31,26 +33,26 @@ __device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, f
     clamped = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float r = SH_C0 * sh[0 * 3 + ch];
+        float r = SH_C0 * sh[(size_t)(0 * 3 + ch) * st];
         if (D > 0) {
-            r = FMA(-(SH_C1 * y), sh[1 * 3 + ch], r);
-            r = FMA(SH_C1 * z, sh[2 * 3 + ch], r);
-            r = FMA(-(SH_C1 * x), sh[3 * 3 + ch], r);
+            r = FMA(-(SH_C1 * y), sh[(size_t)(1 * 3 + ch) * st], r);
+            r = FMA(SH_C1 * z, sh[(size_t)(2 * 3 + ch) * st], r);
+            r = FMA(-(SH_C1 * x), sh[(size_t)(3 * 3 + ch) * st], r);
             if (D > 1) {
                 float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                r = FMA(C20 * xy, sh[4 * 3 + ch], r);
-                r = FMA(C21 * yz, sh[5 * 3 + ch], r);
-                r = FMA(C22 * (FMA(2.0f, zz, -xx) - yy), sh[6 * 3 + ch], r);
-                r = FMA(C23 * xz, sh[7 * 3 + ch], r);
-                r = FMA(C24 * (xx - yy), sh[8 * 3 + ch], r);
+                r = FMA(C20 * xy, sh[(size_t)(4 * 3 + ch) * st], r);
+                r = FMA(C21 * yz, sh[(size_t)(5 * 3 + ch) * st], r);
+                r = FMA(C22 * (FMA(2.0f, zz, -xx) - yy), sh[(size_t)(6 * 3 + ch) * st], r);
+                r = FMA(C23 * xz, sh[(size_t)(7 * 3 + ch) * st], r);
+                r = FMA(C24 * (xx - yy), sh[(size_t)(8 * 3 + ch) * st], r);
                 if (D > 2) {
-                    r = FMA(C30 * y * FMA(3.0f, xx, -yy), sh[9 * 3 + ch], r);
-                    r = FMA(C31 * xy * z, sh[10 * 3 + ch], r);
-                    r = FMA(C32 * y * (FMA(4.0f, zz, -xx) - yy), sh[11 * 3 + ch], r);
-                    r = FMA(C33 * z * (FMA(2.0f, zz, -(3.0f * xx)) - 3.0f * yy), sh[12 * 3 + ch], r);
-                    r = FMA(C34 * x * (FMA(4.0f, zz, -xx) - yy), sh[13 * 3 + ch], r);
-                    r = FMA(C35 * z * (xx - yy), sh[14 * 3 + ch], r);
-                    r = FMA(C36 * x * FMA(-3.0f, yy, xx), sh[15 * 3 + ch], r);
+                    r = FMA(C30 * y * FMA(3.0f, xx, -yy), sh[(size_t)(9 * 3 + ch) * st], r);
+                    r = FMA(C31 * xy * z, sh[(size_t)(10 * 3 + ch) * st], r);
+                    r = FMA(C32 * y * (FMA(4.0f, zz, -xx) - yy), sh[(size_t)(11 * 3 + ch) * st], r);
+                    r = FMA(C33 * z * (FMA(2.0f, zz, -(3.0f * xx)) - 3.0f * yy), sh[(size_t)(12 * 3 + ch) * st], r);
+                    r = FMA(C34 * x * (FMA(4.0f, zz, -xx) - yy), sh[(size_t)(13 * 3 + ch) * st], r);
+                    r = FMA(C35 * z * (xx - yy), sh[(size_t)(14 * 3 + ch) * st], r);
+                    r = FMA(C36 * x * FMA(-3.0f, yy, xx), sh[(size_t)(15 * 3 + ch) * st], r);
                 }
             }
         }
@@ -150,7 +152,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 float rgb[3];
                 uint32_t cl = 0;
                 if (shs) {
-                    sh_to_rgb(D, shs + (size_t)i * M * 3, mx, my, mz, vp.campos, rgb, cl);
+                    const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
+                    sh_to_rgb(D, planar ? shs + i : shs + (size_t)i * M * 3, planar ? (size_t)P : (size_t)1, mx, my, mz,
+                              vp.campos, rgb, cl);
                 } else {
                     rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
                 }

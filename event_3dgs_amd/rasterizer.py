@@ -88,7 +88,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
     cov_c = _prep(cov3Ds_precomp, "cov3D_precomp")
     bg = _prep(rs.bg, "bg"); view = _prep(rs.viewmatrix, "viewmatrix")
     proj = _prep(rs.projmatrix, "projmatrix"); campos = _prep(rs.campos, "campos")
-    M = 0 if sh_c is None else sh_c.shape[1]
+    M = 0 if sh_c is None else (sh_c.shape[0] // 3 if (flags & _lib.FLAG_SH_PLANAR) else sh_c.shape[1])
     if P:
         if opac_c is None or opac_c.numel() != P:
             raise RuntimeError("opacities must have P elements")
@@ -138,7 +138,7 @@ def forward_begin(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     scales_c, rots_c, cov_c = _prep(scales, "scales"), _prep(rotations, "rotations"), _prep(cov3Ds_precomp, "cov3D_precomp")
     bg = _prep(rs.bg, "bg"); view = _prep(rs.viewmatrix, "viewmatrix")
     proj = _prep(rs.projmatrix, "projmatrix"); campos = _prep(rs.campos, "campos")
-    M = 0 if sh_c is None else sh_c.shape[1]
+    M = 0 if sh_c is None else (sh_c.shape[0] // 3 if (flags & _lib.FLAG_SH_PLANAR) else sh_c.shape[1])
     if count_host is None:
         count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
     radii = torch.empty(P, dtype=torch.int32, device=dev)

@@ -52,6 +52,12 @@ class EventTrainer:
                     reference's train.py does; kept as the equivalence check of the fused path.
     """
 
+    FWD_FLAGS = _lib.FLAG_PREACT | _lib.FLAG_SH_PLANAR
+
+    def features_reference_layout(self):
+        """(N,16,3) view-copy of the SH coefficients in the reference's layout (gaussian_model.py:105-108)."""
+        return self.views["features"].t().reshape(self.N, 16, 3).contiguous()
+
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
@@ -67,8 +73,9 @@ class EventTrainer:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.views, self.grads, self.seg = {}, {}, {}
         off = 0
-        shapes = {"xyz": (N, 3), "features": (N, 16, 3), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
-        feats = torch.cat((params["features_dc"], params["features_rest"]), dim=1)
+        # features are stored coefficient-major, (16*3, N) (E3DGS_FLAG_SH_PLANAR): rows 0..2 = f_dc, 3..47 = f_rest
+        shapes = {"xyz": (N, 3), "features": (48, N), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+        feats = torch.cat((params["features_dc"], params["features_rest"]), dim=1).reshape(N, 48).t()
         src = {"xyz": params["xyz"], "features": feats, "opacity": params["opacity"], "scaling": params["scaling"],
                "rotation": params["rotation"]}
         for name, per in SEGMENTS:
@@ -113,7 +120,7 @@ class EventTrainer:
         """Forward only, fused activations.  Returns the forward_raw dict (image in ["color"])."""
         v = self.views
         return rasterizer.forward_raw(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None,
-                                      self._settings(cam, bg), flags=_lib.FLAG_PREACT)
+                                      self._settings(cam, bg), flags=self.FWD_FLAGS)
 
     def step(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
         """One event iteration (train.py:97-332 without densification).  Returns the device scalars tensor of
@@ -128,7 +135,7 @@ class EventTrainer:
         if self._counts is None:
             self._counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(3)]
         pend = [rasterizer.forward_begin(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None,
-                                         self._settings(c, bg), flags=_lib.FLAG_PREACT, count_host=self._counts[k])
+                                         self._settings(c, bg), flags=self.FWD_FLAGS, count_host=self._counts[k])
                 for k, c in enumerate((cam_int, cam_now, cam_next))]
         torch.cuda.current_stream().synchronize()
         raws = [rasterizer.forward_finish(p) for p in pend]
@@ -148,7 +155,7 @@ class EventTrainer:
             o = dict(out)
             if k == 0 and self.track_stats:
                 o["means2D"] = self.viewspace_grad          # densification statistics use render #1 only (train.py:145)
-            rasterizer.backward_raw(raw, dpix, o, flags=_lib.FLAG_PREACT | _lib.FLAG_ACCUMULATE, grad_acc=self.acc)
+            rasterizer.backward_raw(raw, dpix, o, flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE, grad_acc=self.acc)
         self.c_grad.copy_(scalars[1:2])
         if self.world > 1 and sync_grads:
             parallel.allreduce_mean_(self.flat_grad, self.pg)      # ONE collective: 59 floats/Gaussian + c
@@ -165,7 +172,8 @@ class EventTrainer:
             if name == "xyz":
                 lr, kw = self.xyz_lr(it), {}
             elif name == "features":
-                lr, kw = self.lrs["features"], dict(lr_b=self.lrs["features_rest"], period=48, split=3)
+                # f_dc rows first, then f_rest rows: "element i uses lr if (i % period) < split" with period = n
+                lr, kw = self.lrs["features"], dict(lr_b=self.lrs["features_rest"], period=n, split=3 * self.N)
             elif name == "c":
                 lr, kw, eps = self.c_lr, {}, 1e-8                   # torch.optim.Adam([c], lr=0.1), train.py:73
             else:
@@ -181,13 +189,14 @@ class EventTrainer:
         it = self.iteration
         self.flat_grad.zero_()
         leaves = {k: v.detach().requires_grad_(True) for k, v in self.views.items()}
+        feats_ref = leaves["features"].t().reshape(self.N, 16, 3)           # reference (N,16,3) layout for the op
         c = self.c.detach().clone().requires_grad_(True)
         scales, rots = torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"])
         opac = torch.sigmoid(leaves["opacity"])
         imgs = []
         for cam in (cam_int, cam_now, cam_next):
             m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
-            img, radii = rasterize_gaussians(leaves["xyz"], m2, leaves["features"], None, opac, scales, rots, None,
+            img, radii = rasterize_gaussians(leaves["xyz"], m2, feats_ref, None, opac, scales, rots, None,
                                              self._settings(cam, bg))
             imgs.append(img)
         loss = losses.event_iteration_loss(imgs[0], imgs[1], imgs[2], c, gt_int, gt_now, gt_next, gt_blur)

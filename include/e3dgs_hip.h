@@ -50,6 +50,10 @@ const char* e3dgs_last_error(void);
                                     three renders of one training iteration (train.py:144,159,161) accumulate
                                     straight into one gradient buffer */
 
+#define E3DGS_FLAG_SH_PLANAR 4   /* shs and dL_dsh are coefficient-major, (M*3, P), instead of the reference's
+                                    (P,M,3): neighbouring lanes read neighbouring addresses (used by the fused
+                                    trainer, which owns its parameter layout) */
+
 /*
  * Forward rasterisation of P Gaussians into a (3,H,W) planar fp32 image.
  * Replaces: diff_gaussian_rasterization._C.rasterize_gaussians, called by
