@@ -135,7 +135,9 @@ static inline size_t scan_blocks(size_t n) { return (n + SCAN_TILE - 1) / SCAN_T
 // scratch (in uint32) needed to sort n pairs: per-block digit histograms + scan block sums
 static inline size_t sort_scratch_words(size_t n) {
     size_t h = sort_blocks(n) * 256;
-    return h + scan_blocks(h) + 64;
+    size_t classic = h + scan_blocks(h) + 64;
+    size_t onesweep = 1024 + 64 + 4 * h;      // global histograms, tickets, per-pass look-back descriptors
+    return classic > onesweep ? classic : onesweep;
 }
 
 // ---------------------------------------------------------------- scratch layouts

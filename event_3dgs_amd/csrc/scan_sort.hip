@@ -12,6 +12,7 @@
 //                  prefix over the 4 wave counters.  No inter-workgroup communication inside a
 //                  launch, so no agent-scope fences are needed.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ scan
 // 3-phase scan: block sums -> spine (one workgroup, loops) -> block scan with carry-in.
@@ -189,10 +190,174 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     }
 }
 
+// ------------------------------------------------------------------------------------ onesweep variant
+// One launch per digit instead of five: the digit histograms of ALL passes come from one upfront kernel,
+// and each pass fuses histogram + cross-workgroup prefix + scatter using a chained scan with decoupled
+// look-back.  Inter-workgroup protocol (cdna_hip_programming.md G16, form R2): each (block, digit) descriptor
+// is ONE 32-bit word {2-bit status, 30-bit count} written and read with relaxed agent-scope atomics
+// (sc1: write-through / L1-bypass), so the data is its own flag and no fence is needed.  Logical block ids
+// are handed out by an atomic ticket, so a block only ever waits for blocks that have already started
+// (no dependence on dispatch order or placement).  All descriptor words are zeroed by a memset before the pass.
+constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_MASK = (1u << 30) - 1u;
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
+                                                                         int passes, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[4][256];
+    for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+        if (idx < n) {
+            uint32_t k = keys[idx];
+            for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c);
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, size_t n, int shift, const uint32_t* __restrict__ ghist /*256, this pass*/,
+    uint32_t* desc /* nblocks x 256, zeroed */, uint32_t* ticket /* zeroed */) {
+    constexpr int NW = SORT_THREADS / WAVE;
+    constexpr int WAVE_KEYS = SORT_TILE / NW;
+    __shared__ uint32_t wcnt[NW][256];
+    __shared__ uint32_t sbase[256];
+    __shared__ uint32_t wtot[NW];
+    __shared__ uint32_t s_bid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const size_t wbase = (size_t)bid * SORT_TILE + (size_t)wave * WAVE_KEYS;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        size_t idx = wbase + (size_t)r * WAVE + lane;
+        bool ok = idx < n;
+        key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = ok ? vals_in[idx] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        size_t idx = wbase + (size_t)r * WAVE + lane;
+        bool ok = idx < n;
+        uint32_t d = (key[r] >> shift) & 255u;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t before = __popcll(peers & lt_mask);
+        uint32_t cnt = __popcll(peers);
+        uint32_t basep = 0;
+        if (ok) basep = wcnt[wave][d];
+        wave_sync();
+        if (ok && before == 0) wcnt[wave][d] = basep + cnt;
+        wave_sync();
+        pos[r] = basep + before;
+    }
+    __syncthreads();
+    {
+        // digit = threadIdx.x
+        const int d = threadIdx.x;
+        uint32_t c[NW], total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { c[w] = wcnt[w][d]; total += c[w]; }
+        uint32_t* my = desc + (size_t)bid * 256 + d;
+        __hip_atomic_store(my, (bid == 0 ? OS_PREFIX : OS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // exclusive prefix of this digit over the preceding logical blocks (decoupled look-back)
+        // windowed: LB_WIN predecessors are fetched with independent loads, then consumed in order
+        uint32_t excl = 0;
+        constexpr int LB_WIN = 8;
+        int p = (int)bid - 1;
+        bool done_lb = p < 0;
+        while (!done_lb) {
+            uint32_t v[LB_WIN];
+#pragma unroll
+            for (int k = 0; k < LB_WIN; ++k)
+                v[k] = (p - k >= 0) ? __hip_atomic_load(desc + (size_t)(p - k) * 256 + d, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT)
+                                    : OS_PREFIX;            // virtual block -1: prefix 0
+            int used = 0;
+#pragma unroll
+            for (int k = 0; k < LB_WIN; ++k) {
+                if (done_lb || used != k) continue;
+                const uint32_t st = v[k] >> 30;
+                if (st == 0) continue;                      // not published yet: re-fetch from here
+                excl += v[k] & OS_MASK;
+                used = k + 1;
+                if (st == 2) done_lb = true;
+            }
+            p -= used;
+            if (!done_lb && used == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        if (bid != 0)
+            __hip_atomic_store(my, OS_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // exclusive scan of the global digit histogram over the 256 digits
+        uint32_t gh = ghist[d], inc = gh;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t dbase = inc - gh;
+        for (int w = 0; w < wave; ++w) dbase += wtot[w];
+        uint32_t g = dbase + excl;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { wcnt[w][d] = g; g += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        size_t idx = wbase + (size_t)r * WAVE + lane;
+        if (idx < n) {
+            uint32_t d = (key[r] >> shift) & 255u;
+            uint32_t dst = wcnt[wave][d] + pos[r];
+            keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+    (void)sbase;
+}
+
+static bool use_onesweep() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                              uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s) {
     uint32_t *ki = k0, *ko = k1, *vi = v0, *vo = v1;
-    if (n > 0) {
+    const int passes = radix_passes(nbits);
+    // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
+    // for the multi-million instance sort the plain three-kernel pass is faster on this chip
+    if (n > 0 && use_onesweep() && passes <= 4 && sort_blocks(n) <= 512) {
+        unsigned nb = (unsigned)sort_blocks(n);
+        // scratch: [ghist 4*256][ticket 64 per pass ...][desc passes * nb * 256]
+        uint32_t* ghist = scratch;
+        uint32_t* tickets = scratch + 1024;
+        uint32_t* desc = scratch + 1024 + 64;
+        size_t words = 1024 + 64 + (size_t)passes * nb * 256;
+        (void)hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), s);
+        radix_global_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, passes, ghist);
+        for (int p = 0; p < passes; ++p) {
+            radix_onesweep_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, vi, ko, vo, n, 8 * p, ghist + 256 * p,
+                                                                         desc + (size_t)p * nb * 256, tickets + p);
+            uint32_t* t = ki; ki = ko; ko = t;
+            t = vi; vi = vo; vo = t;
+        }
+    } else if (n > 0) {
         unsigned nb = (unsigned)sort_blocks(n);
         size_t hn = (size_t)nb * 256;
         uint32_t* hist = scratch;
