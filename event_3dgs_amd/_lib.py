@@ -96,6 +96,8 @@ def current_stream():
 FLAG_PREACT = 1
 FLAG_ACCUMULATE = 2
 FLAG_SH_PLANAR = 4
+FLAG_BWD_ONLY_RENDER = 8
+FLAG_BWD_ONLY_GEOM = 16
 ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [

@@ -492,7 +492,7 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     GeomState geom = GeomState::from(gp, P);
     BinningState bin = BinningState::from(bp, (size_t)num_rendered);
     ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
-    if (num_rendered > 0) {
+    if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
         tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
@@ -500,6 +500,7 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
             background, img.final_T, img.n_contrib, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");
+    if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;
     {
     ProfScope ps(PS_GEOM_BWD, s);
     if (flags & E3_FLAG_ACCUMULATE)

@@ -23,6 +23,8 @@
 #define E3_FLAG_PREACT 1      // scales = log-scales, rotations = raw quaternions, opacities = logits
 #define E3_FLAG_ACCUMULATE 2  // backward adds into its outputs (only for visible Gaussians)
 #define E3_FLAG_SH_PLANAR 4   // shs / dL_dsh are coefficient-major (M*3, P): lane-coalesced, no (P,M,3) stride
+#define E3_FLAG_BWD_ONLY_RENDER 8   // backward: run only the compositing backward (fills grad_acc)
+#define E3_FLAG_BWD_ONLY_GEOM 16    // backward: run only the per-Gaussian backward (consumes grad_acc)
 #define E3_ACC_STRIDE 12      // floats per Gaussian in the backward accumulation record
 
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))

@@ -387,6 +387,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     }
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    int live_strips = 0;      // wave-uniform (SALU): (entry, 16x4 strip) pairs that were evaluated
 
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
     float2 rc = make_float2(0, 0);
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 const float power = FMA(-0.5f, q, -(cydx * dy));
                 const bool live = (T[k] > 0.0f) && !(power > 0.0f) && (power >= c.y);
                 if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                    ++live_strips;
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     const bool valid = (T[k] > 0.0f) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
@@ -441,9 +443,11 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) T[k] = fabsf(T[k]);
     {
+        // cost model of the backward walk over this tile: a fixed part per visited entry plus a part per
+        // evaluated strip (measured: dense tiles cost ~2.4x more per entry than sparse ones)
         uint32_t mw = max(max(last[0], last[1]), max(last[2], last[3]));
         mw = wave_max_u32(mw);
-        if (lane == 0) tile_work[tile] = mw;
+        if (lane == 0) tile_work[tile] = 2u * mw + (uint32_t)live_strips;
     }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;

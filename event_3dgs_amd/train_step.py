@@ -61,7 +61,7 @@ class EventTrainer:
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
-                 track_densification_stats=False):
+                 track_densification_stats=False, multi_stream=True):
         self.device = torch.device(device)
         self.N = params["xyz"].shape[0]
         N = self.N
@@ -101,10 +101,12 @@ class EventTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.track_stats = track_densification_stats
         # reusable scratch
-        self.acc = torch.empty(N, _lib.ACC_STRIDE, dtype=torch.float32, device=self.device)
         self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if track_densification_stats else None
         self._loss_bufs = None
         self._counts = None
+        self._streams = None
+        self._accs = None
+        self.multi_stream = multi_stream
         self.last_radii = None
         self.last_scalars = None
 
@@ -124,21 +126,39 @@ class EventTrainer:
 
     def step(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
         """One event iteration (train.py:97-332 without densification).  Returns the device scalars tensor of
-        the loss kernel ([0] = loss); the only host synchronisations are the rasteriser's three
-        instance-count read-backs."""
+        the loss kernel ([0] = loss).  The three views run on three HIP streams: their many small
+        latency-bound kernels (sort passes, scans) and the drain phases of the compositing kernels overlap with
+        each other; only the accumulating per-Gaussian backward is serialised.  One host wait per iteration
+        (the three instance counts)."""
         self.iteration += 1
         it = self.iteration
-        self.flat_grad.zero_()
-        # train.py:144,159,161 -- three renders; every `begin` is enqueued first, ONE host sync reads the
-        # three instance counts, then every `finish` (tile sort + compositing) is enqueued
-        v = self.views
-        if self._counts is None:
+        main = torch.cuda.current_stream(self.device)
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(3)] if self.multi_stream else [main] * 3
             self._counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(3)]
-        pend = [rasterizer.forward_begin(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None,
-                                         self._settings(c, bg), flags=self.FWD_FLAGS, count_host=self._counts[k])
-                for k, c in enumerate((cam_int, cam_now, cam_next))]
-        torch.cuda.current_stream().synchronize()
-        raws = [rasterizer.forward_finish(p) for p in pend]
+            self._accs = [torch.empty(self.N, _lib.ACC_STRIDE, dtype=torch.float32, device=self.device) for _ in range(3)]
+        S = self._streams
+        v = self.views
+        cams = (cam_int, cam_now, cam_next)
+        self.flat_grad.zero_()
+        ev0 = main.record_event()
+        # ---- forward, first half (preprocess, depth sort, tile counting) on the three streams
+        pend = []
+        for k in range(3):
+            with torch.cuda.stream(S[k]):
+                S[k].wait_event(ev0)
+                pend.append(rasterizer.forward_begin(v["xyz"], v["features"], None, v["opacity"], v["scaling"],
+                                                     v["rotation"], None, self._settings(cams[k], bg),
+                                                     flags=self.FWD_FLAGS, count_host=self._counts[k]))
+        for k in range(3):
+            S[k].synchronize()                     # the iteration's only host waits: instance counts are back
+        # ---- forward, second half (binning, tile sort, compositing)
+        raws = []
+        for k in range(3):
+            with torch.cuda.stream(S[k]):
+                raws.append(rasterizer.forward_finish(pend[k]))
+                self._accs[k].zero_()
+                main.wait_event(S[k].record_event())
         if self._loss_bufs is None:
             img = raws[0]["color"]
             self._loss_bufs = (torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(img),
@@ -148,18 +168,32 @@ class EventTrainer:
         scalars, d_image, d_now, d_next = losses.event_loss_raw(raws[0]["color"], raws[1]["color"], raws[2]["color"],
                                                                 self.c, gt_int, gt_now, gt_next, gt_blur,
                                                                 out=self._loss_bufs)          # train.py:165-203
+        ev_loss = main.record_event()
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
-        for k, (raw, dpix) in enumerate(zip(raws, (d_image, d_now, d_next))):         # loss.backward(), train.py:211
-            self.acc.zero_()
+        dpix = (d_image, d_now, d_next)
+        # ---- loss.backward() (train.py:211): compositing backward of the three views overlaps ...
+        for k in range(3):
+            with torch.cuda.stream(S[k]):
+                S[k].wait_event(ev_loss)
+                rasterizer.backward_raw(raws[k], dpix[k], out, grad_acc=self._accs[k],
+                                        flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE | _lib.FLAG_BWD_ONLY_RENDER)
+                main.wait_event(S[k].record_event())
+        # ---- ... and the accumulating per-Gaussian stage runs in order on the main stream
+        for k in range(3):
             o = dict(out)
             if k == 0 and self.track_stats:
                 o["means2D"] = self.viewspace_grad          # densification statistics use render #1 only (train.py:145)
-            rasterizer.backward_raw(raw, dpix, o, flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE, grad_acc=self.acc)
+            rasterizer.backward_raw(raws[k], dpix[k], o, grad_acc=self._accs[k],
+                                    flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE | _lib.FLAG_BWD_ONLY_GEOM)
         self.c_grad.copy_(scalars[1:2])
         if self.world > 1 and sync_grads:
             parallel.allreduce_mean_(self.flat_grad, self.pg)      # ONE collective: 59 floats/Gaussian + c
         self._adam(it)
+        if self.multi_stream:
+            ev_end = main.record_event()
+            for k in range(3):
+                S[k].wait_event(ev_end)            # next iteration's forward reads the updated parameters
         self.last_radii = raws[0]["radii"]
         self.last_scalars = scalars
         return scalars

@@ -54,6 +54,11 @@ const char* e3dgs_last_error(void);
                                     (P,M,3): neighbouring lanes read neighbouring addresses (used by the fused
                                     trainer, which owns its parameter layout) */
 
+#define E3DGS_FLAG_BWD_ONLY_RENDER 8   /* backward: only the compositing backward (pixels -> grad_acc) */
+#define E3DGS_FLAG_BWD_ONLY_GEOM 16    /* backward: only the per-Gaussian backward (grad_acc -> parameter gradients).
+                                          Together these let a caller overlap the compositing backward of several
+                                          views on separate HIP streams and serialise only the accumulating stage. */
+
 /*
  * Forward rasterisation of P Gaussians into a (3,H,W) planar fp32 image.
  * Replaces: diff_gaussian_rasterization._C.rasterize_gaussians, called by
