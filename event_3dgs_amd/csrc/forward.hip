@@ -423,6 +423,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 const bool live = (T[k] > 0.0f) && !(power > 0.0f) && (power >= c.y);
                 if (__builtin_amdgcn_ballot_w64(live) != 0) {
                     ++live_strips;
+                    ++live_strips;
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     const bool valid = (T[k] > 0.0f) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
