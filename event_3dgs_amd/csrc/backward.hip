@@ -17,12 +17,11 @@ __global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, 
                                   uint32_t* __restrict__ order);
 __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
-    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ acc /* (P,12): mx my A B C o c0 c1 c2 - - - */) {
     __shared__ float4 sA[BWD_WAVES][WAVE];
     __shared__ float4 sB[BWD_WAVES][WAVE];
-    __shared__ float2 sC[BWD_WAVES][WAVE];
+    __shared__ float4 sC[BWD_WAVES][WAVE];
     __shared__ uint32_t sId[BWD_WAVES][WAVE];
     // Gradient staging.  Per entry the nine per-lane sums are reduced only WITHIN each row of 16 lanes, with a
     // transposed butterfly (after the xor-1 / xor-2 quad steps every lane owns two of the eight values, so the
@@ -72,26 +71,28 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     const unsigned long long t_loop = trace ? wall_clock64() : 0ull;
 
     // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
-    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
-    float2 rc = make_float2(0, 0);
-    uint32_t rid = 0;
+    // staging pipeline as in the forward kernel: ids one round early, records gathered under the math
+    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0), rc = make_float4(0, 0, 0, 0);
+    uint32_t rid = 0, id_next = 0;
     if (lane < n) {
         rid = point_list[range.x + (uint32_t)(n - 1 - lane)];
-        ra = recA[rid]; rb = recB[rid]; rc = recC[rid];
+        ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
     }
+    if (WAVE + lane < n) id_next = point_list[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = rid;
         wave_sync();
         if (base + WAVE + lane < n) {
-            rid = point_list[range.x + (uint32_t)(n - 1 - (base + WAVE + lane))];
-            ra = recA[rid]; rb = recB[rid]; rc = recC[rid];
+            rid = id_next;
+            ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
         }
+        if (base + 2 * WAVE + lane < n) id_next = point_list[range.x + (uint32_t)(n - 1 - (base + 2 * WAVE + lane))];
         unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
-            const float2 c = sC[wave][j];
+            const float4 c = sC[wave][j];
             const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
@@ -496,7 +497,7 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
         ProfScope ps(PS_RENDER_BWD, s);
         tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC,
+            g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.point_list, geom.rec,
             background, img.final_T, img.n_contrib, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");

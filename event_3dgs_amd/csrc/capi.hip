@@ -166,7 +166,7 @@ int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float*
 void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9) {
     char* p = nullptr;
     GeomState g = GeomState::from(p, (size_t)(P > 0 ? P : 0));
-    out9[0] = (size_t)g.recA; out9[1] = (size_t)g.recB; out9[2] = (size_t)g.recC; out9[3] = (size_t)g.clamped;
+    out9[0] = (size_t)g.rec; out9[1] = (size_t)g.rec + 16; out9[2] = (size_t)g.rec + 32; out9[3] = (size_t)g.clamped;
     out9[4] = (size_t)g.rect;
     p = nullptr;
     BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));

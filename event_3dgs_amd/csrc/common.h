@@ -143,11 +143,11 @@ static inline size_t sort_scratch_words(size_t n) {
 }
 
 // ---------------------------------------------------------------- scratch layouts
-// geometry state: everything sized by P.  The first five members are what backward reads.
+// geometry state: everything sized by P.  The first three members are what backward reads.
 struct GeomState {
-    float4* recA;      // (x, y, conic.x, conic.y)
-    float4* recB;      // (conic.z, opacity, r, g)
-    float2* recC;      // (b, pmin): alpha >= 1/255 needs power >= pmin = -(ln(255 o) + margin)
+    float4* rec;       // 3 x float4 per Gaussian = one 48-B record the compositing kernels gather:
+                       //   [0] (x, y, conic.x, conic.y)  [1] (conic.z, opacity, r, g)  [2] (b, pmin, -, -)
+                       //   pmin: alpha >= 1/255 needs power >= pmin = -(ln(255 o) + margin)
     uint32_t* clamped; // SH clamp bitmask (bit ch)
     uint2* rect;       // packed tile rectangle: .x = xmin | ymin<<16, .y = xmax | ymax<<16
     uint32_t* key0;    // depth keys (ping)
@@ -166,9 +166,7 @@ struct GeomState {
     static GeomState from(char*& p, size_t P) {
         GeomState g;
         size_t n = P ? P : 1;
-        g.recA = carve<float4>(p, n);
-        g.recB = carve<float4>(p, n);
-        g.recC = carve<float2>(p, n);
+        g.rec = carve<float4>(p, 3 * n);
         g.clamped = carve<uint32_t>(p, n);
         g.rect = carve<uint2>(p, n);
         g.key0 = carve<uint32_t>(p, n);

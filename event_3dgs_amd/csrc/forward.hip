@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
     const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewParams vp, int flags,
     int* __restrict__ radii,
-    float4* __restrict__ recA, float4* __restrict__ recB, float2* __restrict__ recC, uint32_t* __restrict__ clamped,
+    float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 } else {
                     rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
                 }
-                recA[i] = make_float4(px, py, conx, cony);
+                rec[3 * (size_t)i] = make_float4(px, py, conx, cony);
                 const float o_ = (flags & E3_FLAG_PREACT) ? act_sigmoid(opac[i]) : opac[i];
-                recB[i] = make_float4(conz, o_, rgb[0], rgb[1]);
+                rec[3 * (size_t)i + 1] = make_float4(conz, o_, rgb[0], rgb[1]);
                 // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
                 // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
-                recC[i] = make_float2(rgb[2], -(logf(255.0f * o_) + 1e-3f));
+                rec[3 * (size_t)i + 2] = make_float4(rgb[2], -(logf(255.0f * o_) + 1e-3f), 0.0f, 0.0f);
                 clamped[i] = cl;
                 radius_out = radius;
                 rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
@@ -223,8 +223,7 @@ constexpr int BIN_WAVES = 4;
 template <bool EMIT>
 __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint32_t* __restrict__ order,
                                                               const uint2* __restrict__ rect,
-                                                              const float4* __restrict__ recA,
-                                                              const float4* __restrict__ recB, int gx, int cull,
+                                                              const float4* __restrict__ rec, int gx, int cull,
                                                               const uint32_t* __restrict__ wave_offsets,
                                                               uint32_t* __restrict__ wave_counts,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -244,8 +243,8 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
         uint32_t w = (r.y & 0xFFFFu) - (r.x & 0xFFFFu), h = (r.y >> 16) - (r.x >> 16);
         n = w * h;
         if (n) {
-            a = recA[g];
-            float4 t = recB[g];
+            a = rec[3 * (size_t)g];
+            float4 t = rec[3 * (size_t)g + 1];
             // 2 ln(255 o) with the safety margin folded in; o <= 0 -> -inf -> nothing kept
             // margins: see tile_touched(); the Lambda term bounds the rounding of the compositing kernels'
             // own `power` at any pixel of the tile (|terms| <= 2(|terms at the minimiser| + Lambda*15^2*2))
@@ -357,12 +356,11 @@ unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries
 
 __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,
-    const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
+    const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
     __shared__ float4 sB[RENDER_WAVES][WAVE];
-    __shared__ float2 sC[RENDER_WAVES][WAVE];
+    __shared__ float4 sC[RENDER_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * RENDER_WAVES + wave;
     if (unit >= ntiles) return;
@@ -389,12 +387,15 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     const int n = (int)(range.y - range.x);
     int live_strips = 0;      // wave-uniform (SALU): (entry, 16x4 strip) pairs that were evaluated
 
-    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
-    float2 rc = make_float2(0, 0);
+    // staging pipeline: the ids of round r+1 are fetched one round early, so issuing the record gathers of the
+    // next round costs ONE memory round trip (not id -> record), and both are in flight under this round's math
+    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0), rc = make_float4(0, 0, 0, 0);
+    uint32_t id_next = 0;
     if (lane < n) {
-        uint32_t id = point_list[range.x + lane];
-        ra = recA[id]; rb = recB[id]; rc = recC[id];
+        const uint32_t id = point_list[range.x + lane];
+        ra = rec[3 * (size_t)id]; rb = rec[3 * (size_t)id + 1]; rc = rec[3 * (size_t)id + 2];
     }
+    if (WAVE + lane < n) id_next = point_list[range.x + WAVE + lane];
     for (int base = 0; base < n; base += WAVE) {
         if (__builtin_amdgcn_ballot_w64(T[0] > 0.0f || T[1] > 0.0f || T[2] > 0.0f || T[3] > 0.0f) == 0) break;
         const int cnt = min(WAVE, n - base);
@@ -402,13 +403,13 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
         wave_sync();
         if (base + WAVE + lane < n) {
-            uint32_t id = point_list[range.x + base + WAVE + lane];
-            ra = recA[id]; rb = recB[id]; rc = recC[id];
+            ra = rec[3 * (size_t)id_next]; rb = rec[3 * (size_t)id_next + 1]; rc = rec[3 * (size_t)id_next + 2];
         }
+        if (base + 2 * WAVE + lane < n) id_next = point_list[range.x + base + 2 * WAVE + lane];
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
-            const float2 c = sC[wave][j];
+            const float4 c = sC[wave][j];
             const uint32_t contributor = (uint32_t)(base + j + 1);
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
@@ -543,7 +544,7 @@ int e3_forward_begin_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, c
         {
         ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
-                                                         vp, flags, radii, geom.recA, geom.recB, geom.recC, geom.clamped,
+                                                         vp, flags, radii, geom.rec, geom.clamped,
                                                          geom.rect, geom.key0, geom.ord0);
         }
         KERNEL_OK("preprocess_kernel");
@@ -560,7 +561,7 @@ int e3_forward_begin_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, c
         HIP_OK(hipMemsetAsync(geom.offsets, 0, sizeof(uint32_t), s));
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.recA, geom.recB, vp.gx,
+        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.rec, vp.gx,
                                                                      g_tile_cull, nullptr, geom.tiles, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
@@ -595,7 +596,7 @@ int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, in
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, geom.ord0, geom.rect, geom.recA, geom.recB, gx,
+        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, geom.ord0, geom.rect, geom.rec, gx,
                                                                     g_tile_cull, geom.offsets, nullptr, k0, v0);
         }
         KERNEL_OK("bin emit");
@@ -619,7 +620,7 @@ int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, in
     KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        g_trace, ntiles, img.order, gx, W, H, img.ranges, bin.point_list, geom.recA, geom.recB, geom.recC, background,
+        g_trace, ntiles, img.order, gx, W, H, img.ranges, bin.point_list, geom.rec, background,
         out_color, img.final_T, img.n_contrib, img.work);
     KERNEL_OK("render_fwd_kernel");
     return 0;

@@ -182,9 +182,9 @@ def state_views(raw, P, W, H):
         nbytes = count * torch.empty(0, dtype=dtype).element_size()
         return buf[off:off + nbytes].view(dtype).reshape(shape)
     g, b, im = raw["geom"], raw["binning"], raw["image"]
+    rec = view(g, offs[0], torch.float32, 12 * P, (P, 12))
     return dict(
-        recA=view(g, offs[0], torch.float32, 4 * P, (P, 4)), recB=view(g, offs[1], torch.float32, 4 * P, (P, 4)),
-        recC=view(g, offs[2], torch.float32, 2 * P, (P, 2)), clamped=view(g, offs[3], torch.int32, P, (P,)),
+        recA=rec[:, 0:4], recB=rec[:, 4:8], recC=rec[:, 8:10], clamped=view(g, offs[3], torch.int32, P, (P,)),
         rect=view(g, offs[4], torch.int32, 2 * P, (P, 2)),
         point_list=view(b, offs[5], torch.int32, I, (I,)),
         ranges=view(im, offs[6], torch.int32, 2 * gx * gy, (gx * gy, 2)),

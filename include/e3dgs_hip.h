@@ -173,8 +173,9 @@ int e3dgs_get_tile_cull(void);
 /*
  * Byte offsets of the members of the three scratch buffers, for tests and tools that want to
  * inspect intermediate state (sorted lists, tile ranges, per-pixel n_contrib).
- *   out[0..4]  geom:    recA (float4: x,y,conic.x,conic.y), recB (float4: conic.z,opacity,r,g),
- *                       recC (float2: b, strip-skip bound), clamped (u32), rect (uint2 packed 16-bit xmin|ymin, xmax|ymax)
+ *   out[0..4]  geom:    one 48-byte record per Gaussian (stride 12 floats): out[0] -> (x,y,conic.x,conic.y),
+ *                       out[1] -> (conic.z,opacity,r,g), out[2] -> (b, strip-skip bound, -, -);
+ *                       clamped (u32), rect (uint2 packed 16-bit xmin|ymin, xmax|ymax)
  *   out[5]     binning: point_list (u32 Gaussian ids, tile-major, depth order)
  *   out[6..8]  image:   ranges (uint2 per tile), final_T (float per pixel), n_contrib (u32 per pixel)
  */
