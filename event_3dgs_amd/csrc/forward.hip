@@ -432,11 +432,14 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                     const float test_T = T[k] - w;
                     const bool stop = valid && (test_T < E3_T_STOP);
                     const bool apply = valid && !stop;
-                    C0[k] = apply ? FMA(b.z, w, C0[k]) : C0[k];
-                    C1[k] = apply ? FMA(b.w, w, C1[k]) : C1[k];
-                    C2[k] = apply ? FMA(c.x, w, C2[k]) : C2[k];
+                    // one select instead of five: a zero weight leaves C and T bit-unchanged (x + 0*c == x, x - 0 == x)
+                    const float we = apply ? w : 0.0f;
+                    C0[k] = FMA(b.z, we, C0[k]);
+                    C1[k] = FMA(b.w, we, C1[k]);
+                    C2[k] = FMA(c.x, we, C2[k]);
                     last[k] = apply ? contributor : last[k];
-                    T[k] = apply ? test_T : (stop ? -T[k] : T[k]);
+                    const float Tn = T[k] - we;
+                    T[k] = stop ? -Tn : Tn;
                 }
             }
         }
