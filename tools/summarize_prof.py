@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Copy the judged summaries of a gpurun_out/prof_<tag> run into profiles/<tag>/ (kernel stats + PMC traffic)."""
+import collections, csv, json, os, shutil, sys
+tag = sys.argv[1]
+src, dst = f"gpurun_out/prof_{tag}", f"profiles/{tag}"
+os.makedirs(dst, exist_ok=True)
+shutil.copy(f"{src}/trace/trace_kernel_stats.csv", f"{dst}/kernel_stats.csv")
+rows = list(csv.DictReader(open(f"{src}/trace/trace_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(f"{dst}/kernel_stats_top.txt", "w") as f:
+    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline\n")
+    f.write("(timed steps run the 3 views on 3 HIP streams, so per-kernel durations of the compositing kernels are\n"
+            " spans of overlapping launches; the serialised pass that follows in bench.py contributes isolated launches)\n\n")
+    for r in rows[:25]:
+        f.write(f"{r['Name'].split('(')[0][:60]:60s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.1f} "
+                f"min_us={float(r['MinNs'])/1e3:9.1f} tot_ms={float(r['TotalDurationNs'])/1e6:8.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%\n")
+out = {}
+for f in ("fetch", "write"):
+    p = f"{src}/{f}/{f}_counter_collection.csv"
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out.setdefault(k, {})[f"{f.upper()}_SIZE_KB_avg"] = sum(v) / len(v)
+        out[k][f"{f}_launches"] = len(v)
+for k, v in out.items():
+    v["hbm_bytes_per_launch"] = int((v.get("FETCH_SIZE_KB_avg", 0) + v.get("WRITE_SIZE_KB_avg", 0)) * 1024)
+    v["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, KB units, kernel dispatches serialised by the "
+                 "profiler; FETCH_SIZE is known to under-count wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md); "
+                 "uncorrected here because these kernels gather 16-B records")
+json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print(open(f"{dst}/kernel_stats_top.txt").read())
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "note"} for k, v in out.items()}, indent=1))
