@@ -65,6 +65,10 @@ def lib():
     L.e3dgs_event_loss_scratch_bytes.argtypes = [C.c_int, C.c_int]
     L.e3dgs_event_loss.restype = C.c_int
     L.e3dgs_event_loss.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 4 + [_cp, _vp]
+    L.e3dgs_ssim_scratch_bytes.restype = C.c_size_t
+    L.e3dgs_ssim_scratch_bytes.argtypes = [C.c_int] * 3
+    L.e3dgs_ssim.restype = C.c_int
+    L.e3dgs_ssim.argtypes = [C.c_int] * 4 + [_fp] * 4 + [_cp, _vp]
     L.e3dgs_adam_step.restype = C.c_int
     L.e3dgs_adam_step.argtypes = [C.c_size_t] + [_fp] * 4 + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_int, C.c_int, _vp]
     L.e3dgs_profile_enable.restype = None
@@ -104,5 +108,5 @@ EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
     "e3dgs_rasterize_backward",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_state_offsets", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
-    "e3dgs_event_loss", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
+    "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

@@ -353,3 +353,170 @@ int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float l
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "adam_kernel");
 }
+
+// ------------------------------------------------------------------------------------ SSIM
+// utils/loss_utils.py:359-418: 11x11 Gaussian window (sigma 1.5, normalised), zero padding 5, depthwise,
+// C1 = 0.01^2, C2 = 0.03^2, mean over the map.  `to_gray` applies rgb_to_grayscale (:18-23) to both inputs
+// first (ssim_gray :368-385).  Forward writes the three partials dm/dmu1, dm/ds11, dm/ds12 per pixel; the
+// backward pass blurs them (the window is symmetric) and applies the chain rule of mu1, E[x^2], E[xy].
+constexpr int SS_T = 16, SS_R = 5, SS_IN = SS_T + 2 * SS_R;   // 16x16 outputs from a 26x26 input patch
+__constant__ float c_ssim_w[11];
+
+__device__ __forceinline__ float ss_load(const float* __restrict__ img, int C, int to_gray, size_t HW, int ch, int x, int y,
+                                         int W, int H) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return 0.0f;     // zero padding
+    size_t p = (size_t)y * W + x;
+    if (to_gray) return FMA(0.114f, img[2 * HW + p], FMA(0.587f, img[HW + p], 0.299f * img[p]));
+    return img[ch * HW + p];
+}
+
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int to_gray, const float* __restrict__ img1,
+                                                       const float* __restrict__ img2, float* __restrict__ partial3,
+                                                       double* __restrict__ block_sums) {
+    __shared__ float s1[SS_IN][SS_IN + 1], s2[SS_IN][SS_IN + 1];
+    __shared__ float h[5][SS_IN][SS_T + 1];
+    __shared__ double wred[4];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const size_t HW = (size_t)H * W;
+    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
+        int ly = i / SS_IN, lx = i % SS_IN;
+        s1[ly][lx] = ss_load(img1, C, to_gray, HW, ch, x0 + lx - SS_R, y0 + ly - SS_R, W, H);
+        s2[ly][lx] = ss_load(img2, C, to_gray, HW, ch, x0 + lx - SS_R, y0 + ly - SS_R, W, H);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SS_IN * SS_T; i += 256) {          // horizontal pass
+        int ly = i / SS_T, lx = i % SS_T;
+        float a = 0, b = 0, aa = 0, bb = 0, ab = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float w = c_ssim_w[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
+            a = FMA(w, u, a); b = FMA(w, v, b); aa = FMA(w, u * u, aa); bb = FMA(w, v * v, bb); ab = FMA(w, u * v, ab);
+        }
+        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {                                    // vertical pass
+        float w = c_ssim_w[k];
+        mu1 = FMA(w, h[0][ly + k][lx], mu1); mu2 = FMA(w, h[1][ly + k][lx], mu2);
+        e11 = FMA(w, h[2][ly + k][lx], e11); e22 = FMA(w, h[3][ly + k][lx], e22); e12 = FMA(w, h[4][ly + k][lx], e12);
+    }
+    const int x = x0 + lx, y = y0 + ly;
+    double v = 0.0;
+    if (x < W && y < H) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+        float inv = 1.0f / (B1 * B2);
+        float m = A1 * A2 * inv;
+        v = (double)m;
+        if (partial3) {
+            size_t p = (size_t)ch * HW + (size_t)y * W + x;
+            size_t CHW = (size_t)gridDim.z * HW;
+            float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -m / B1, dB2 = -m / B2;
+            partial3[p] = dA1 * 2.0f * mu2 - dA2 * 2.0f * mu2 + dB1 * 2.0f * mu1 - dB2 * 2.0f * mu1;   // dm/dmu1
+            partial3[CHW + p] = dB2;                                                                    // dm/dE[x^2]
+            partial3[2 * CHW + p] = 2.0f * dA2;                                                          // dm/dE[xy]
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = wred[0] + wred[1] + wred[2] + wred[3];
+}
+
+__global__ __launch_bounds__(WAVE) void ssim_finalize_kernel(int nblocks, double count, const double* __restrict__ sums,
+                                                             float* __restrict__ out_mean) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += WAVE) a += sums[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (threadIdx.x == 0) out_mean[0] = (float)(a / count);
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int to_gray, const float* __restrict__ img1,
+                                                       const float* __restrict__ img2, const float* __restrict__ partial3,
+                                                       float scale, float* __restrict__ d_img1) {
+    __shared__ float sp[3][SS_IN][SS_IN + 1];
+    __shared__ float h[3][SS_IN][SS_T + 1];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const size_t HW = (size_t)H * W, CHW = (size_t)gridDim.z * HW;
+    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
+        int ly = i / SS_IN, lx = i % SS_IN;
+        int x = x0 + lx - SS_R, y = y0 + ly - SS_R;
+        bool in = x >= 0 && y >= 0 && x < W && y < H;
+        size_t p = (size_t)ch * HW + (size_t)(in ? y : 0) * W + (in ? x : 0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sp[q][ly][lx] = in ? partial3[q * CHW + p] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SS_IN * SS_T; i += 256) {
+        int ly = i / SS_T, lx = i % SS_T;
+        float a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float w = c_ssim_w[k];
+            a = FMA(w, sp[0][ly][lx + k], a); b = FMA(w, sp[1][ly][lx + k], b); c = FMA(w, sp[2][ly][lx + k], c);
+        }
+        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    float g0 = 0, g1 = 0, g2 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        float w = c_ssim_w[k];
+        g0 = FMA(w, h[0][ly + k][lx], g0); g1 = FMA(w, h[1][ly + k][lx], g1); g2 = FMA(w, h[2][ly + k][lx], g2);
+    }
+    const int x = x0 + lx, y = y0 + ly;
+    if (x < W && y < H) {
+        float u = ss_load(img1, C, to_gray, HW, ch, x, y, W, H), v = ss_load(img2, C, to_gray, HW, ch, x, y, W, H);
+        float g = scale * (g0 + 2.0f * u * g1 + v * g2);
+        size_t p = (size_t)y * W + x;
+        if (to_gray) { d_img1[p] = 0.299f * g; d_img1[HW + p] = 0.587f * g; d_img1[2 * HW + p] = 0.114f * g; }
+        else d_img1[ch * HW + p] = g;
+    }
+}
+
+static void ssim_upload_window() {
+    static bool done = false;
+    if (done) return;
+    double w[11], s = 0;
+    for (int i = 0; i < 11; ++i) { w[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += w[i]; }
+    float wf[11];
+    // the reference builds the window in fp32 (torch.Tensor of python floats, then / sum)
+    float fs = 0.0f;
+    for (int i = 0; i < 11; ++i) { wf[i] = (float)w[i]; fs += wf[i]; }
+    for (int i = 0; i < 11; ++i) wf[i] = wf[i] / fs;
+    (void)s;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_ssim_w), wf, sizeof wf);
+    done = true;
+}
+
+size_t e3_ssim_scratch_bytes(int C, int H, int W) {
+    size_t nb = (size_t)((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T) * C;
+    return nb * sizeof(double) + 3 * (size_t)C * H * W * sizeof(float) + 512;
+}
+
+int e3_ssim_impl(int C, int H, int W, int to_gray, const float* img1, const float* img2, float* out_mean, float* d_img1,
+                 char* scratch, hipStream_t s) {
+    if (to_gray && C != 3) return e3_fail(hipErrorInvalidValue, "to_gray needs 3-channel inputs");
+    ssim_upload_window();
+    const int Ceff = to_gray ? 1 : C;
+    dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, Ceff);
+    size_t nb = (size_t)grid.x * grid.y * grid.z;
+    double* sums = reinterpret_cast<double*>(scratch);
+    float* partial3 = reinterpret_cast<float*>(scratch + align_up(nb * sizeof(double), 256));
+    ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, d_img1 ? partial3 : nullptr, sums);
+    ssim_finalize_kernel<<<dim3(1), dim3(WAVE), 0, s>>>((int)nb, (double)Ceff * H * W, sums, out_mean);
+    if (d_img1)
+        ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, partial3, 1.0f / ((float)Ceff * H * W), d_img1);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "ssim kernels");
+}

@@ -59,6 +59,8 @@ int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
 size_t e3_event_scratch_bytes(int, int);
 int e3_event_loss_impl(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
                        const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
+size_t e3_ssim_scratch_bytes(int, int, int);
+int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, float, int, int,
                  hipStream_t);
 
@@ -198,6 +200,14 @@ int e3dgs_event_loss(int width, int height, const float* image, const float* img
     g_err[0] = 0;
     return e3_event_loss_impl(width, height, image, img_now, img_next, gt_int, gt_now, gt_next, gt_blur, c, gt_c,
                               d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream);
+}
+
+size_t e3dgs_ssim_scratch_bytes(int channels, int height, int width) { return e3_ssim_scratch_bytes(channels, height, width); }
+int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* img1, const float* img2, float* ssim_mean,
+               float* d_img1, char* scratch, void* stream) {
+    g_err[0] = 0;
+    if (channels <= 0 || height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
+    return e3_ssim_impl(channels, height, width, to_gray, img1, img2, ssim_mean, d_img1, scratch, (hipStream_t)stream);
 }
 
 int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,

@@ -82,3 +82,77 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.99
                                         _lib.ptr(exp_avg_sq), float(lr), beta1, beta2, eps, int(step), float(lr_b),
                                         int(period), int(split), _lib.current_stream())
     _lib.check(rc, "e3dgs_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SSIM / gray losses / PSNR: utils/loss_utils.py:18-23,40-48,359-418; utils/image_utils.py:19-21
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, to_gray):
+        L = _lib.lib()
+        if not img1.is_cuda:
+            raise RuntimeError("ssim runs on the GPU only (no CPU path)")
+        a = img1.detach().to(torch.float32).contiguous()
+        b = img2.detach().to(torch.float32).contiguous()
+        C, H, W = a.shape[-3:]
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        need = img1.requires_grad
+        d = torch.empty_like(a) if need else None
+        scratch = torch.empty(L.e3dgs_ssim_scratch_bytes(C, H, W), dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            rc = L.e3dgs_ssim(C, H, W, int(bool(to_gray)), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(d),
+                              _lib.ptr(scratch), _lib.current_stream())
+        _lib.check(rc, "e3dgs_ssim")
+        ctx.save_for_backward(d)
+        ctx.shape = img1.shape
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return (d * g).reshape(ctx.shape) if d is not None else None, None, None
+
+
+def ssim(img1, img2):
+    """utils/loss_utils.py:388-396 (size_average=True)."""
+    return _SSIM.apply(img1, img2, False)
+
+
+def ssim_gray(img1, img2):
+    """utils/loss_utils.py:368-385: 3-channel inputs are converted with rgb_to_grayscale first."""
+    if img1.shape[-3] == 3 and img2.shape[-3] == 3:
+        return _SSIM.apply(img1, img2, True)
+    return _SSIM.apply(img1, img2, False)
+
+
+def rgb_to_grayscale(image):
+    """utils/loss_utils.py:18-23"""
+    return (0.299 * image[0] + 0.587 * image[1] + 0.114 * image[2]).unsqueeze(0)
+
+
+def l1_loss_gray(network_output, gt):
+    """utils/loss_utils.py:40-48"""
+    if network_output.shape[-3] == 3 and gt.shape[-3] == 3:
+        return torch.abs(rgb_to_grayscale(network_output) - rgb_to_grayscale(gt)).mean()
+    return torch.abs(network_output - gt).mean()
+
+
+def l1_loss(network_output, gt):
+    """utils/loss_utils.py:270-271"""
+    return torch.abs(network_output - gt).mean()
+
+
+def gray_iteration_loss(image, gt_image, lambda_dssim=0.2):
+    """The --gray (no event) loss of train.py:213-223."""
+    return (1.0 - lambda_dssim) * l1_loss_gray(image, gt_image) + lambda_dssim * (1.0 - ssim_gray(image, gt_image))
+
+
+def rgb_iteration_loss(image, gt_image, lambda_dssim=0.2):
+    """The RGB loss of train.py:292-296."""
+    return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - ssim(image, gt_image))
+
+
+def psnr(img1, img2):
+    """utils/image_utils.py:19-21"""
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))

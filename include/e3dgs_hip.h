@@ -230,6 +230,17 @@ int e3dgs_event_loss(
     void* stream);
 
 /*
+ * Mean SSIM of two (C,H,W) images and (optionally) its gradient w.r.t. img1.
+ * Replaces the torch conv2d chain of utils/loss_utils.py:359-418 (`ssim`, `_ssim`, `create_window`): 11x11
+ * Gaussian window sigma 1.5, zero padding 5, C1 = 1e-4, C2 = 9e-4, mean over the map.  to_gray = 1 first applies
+ * rgb_to_grayscale (:18-23) to both 3-channel inputs (`ssim_gray` :368-385; used by the --gray loss train.py:213-223
+ * and by eval.py:146).  ssim_mean is a device scalar; d_img1 (C,H,W) may be NULL (forward only).
+ */
+size_t e3dgs_ssim_scratch_bytes(int channels, int height, int width);
+int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* img1, const float* img2,
+               float* ssim_mean, float* d_img1, char* scratch, void* stream);
+
+/*
  * Fused Adam step over one flat parameter tensor (train.py:330-332; groups
  * scene/gaussian_model.py:154-163; eps 1e-15).  Matches torch.optim.Adam
  * (no amsgrad, no weight decay): bias-corrected with step count `step`.

@@ -227,6 +227,40 @@ def event_iteration_loss(image, img_now, img_next, gt_int, gt_now, gt_next, c, g
     return loss
 
 
+def _ssim_window(channel, dtype):
+    """utils/loss_utils.py:359-367"""
+    g = torch.tensor([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, 11, 11).contiguous().to(dtype)
+
+
+def ssim(img1, img2):
+    """utils/loss_utils.py:388-418"""
+    import torch.nn.functional as F
+    C = img1.shape[-3]
+    w = _ssim_window(C, img1.dtype)
+    a, b = img1.unsqueeze(0), img2.unsqueeze(0)
+    mu1, mu2 = F.conv2d(a, w, padding=5, groups=C), F.conv2d(b, w, padding=5, groups=C)
+    s11 = F.conv2d(a * a, w, padding=5, groups=C) - mu1 * mu1
+    s22 = F.conv2d(b * b, w, padding=5, groups=C) - mu2 * mu2
+    s12 = F.conv2d(a * b, w, padding=5, groups=C) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return m.mean()
+
+
+def to_gray(img):
+    """utils/loss_utils.py:18-23"""
+    return (0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]).unsqueeze(0)
+
+
+def gray_iteration_loss(image, gt, lambda_dssim=0.2):
+    """train.py:213-223"""
+    l1 = torch.abs(to_gray(image) - to_gray(gt)).mean()
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim(to_gray(image), to_gray(gt)))
+
+
 def look_at_camera(eye, target, up, fovx, width, height, znear=0.01, zfar=100.0, dtype=torch.float32):
     """Builds (viewmatrix, projmatrix, campos, tanfovx, tanfovy) in the reference's
     row-vector layout: world_view_transform = W2C^T, full_proj = W2C^T @ P^T

@@ -136,3 +136,18 @@ def test_rgb2sh_constant():
     from event_3dgs_amd.synth import RGB2SH
     g = G("sh.npz")
     assert np.allclose(RGB2SH(torch.tensor([0.5, 0.0, 1.0])).numpy(), g["rgb2sh_of_half"], atol=1e-7)
+
+
+def test_g5_ssim_psnr_gray_loss_restatement():
+    """utils/loss_utils.py ssim / ssim_gray / l1_loss_gray, utils/image_utils.py psnr, train.py:213-223."""
+    g = G("image_metrics.npz")
+    a = torch.tensor(g["a"], requires_grad=True)
+    b = torch.tensor(g["b"])
+    assert abs(float(torch_oracle.ssim(a, b)) - float(g["ssim"])) <= 2e-6
+    assert abs(float(torch_oracle.ssim(torch_oracle.to_gray(a), torch_oracle.to_gray(b))) - float(g["ssim_gray"])) <= 2e-6
+    loss = torch_oracle.gray_iteration_loss(a, b)
+    assert abs(float(loss) - float(g["gray_loss"])) <= 2e-6
+    loss.backward()
+    assert np.abs(a.grad.numpy() - g["d_a_gray_loss"]).max() <= 1e-5 * np.abs(g["d_a_gray_loss"]).max()
+    mse = ((a.detach() - b) ** 2).reshape(3, -1).mean(1)
+    assert np.allclose((20 * torch.log10(1.0 / torch.sqrt(mse))).numpy(), g["psnr"].reshape(-1), atol=1e-4)

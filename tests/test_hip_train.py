@@ -155,3 +155,35 @@ def test_training_reduces_loss_and_tracks_reference_trainer():
     psnr = lambda x, y: 20 * math.log10(1.0 / math.sqrt(float(((x - y) ** 2).mean())))
     ia, ib = a.render_raw(cams[0], bg)["color"], b.render_raw(cams[0], bg)["color"]
     assert abs(psnr(ia, gts[0]) - psnr(ib, gts[0])) <= 0.1          # north_star: PSNR within 0.1 dB
+
+
+def test_ssim_kernel_matches_reference_golden_and_oracle():
+    """e3dgs_ssim (forward + gradient) vs the reference's values (golden G5) and the torch restatement."""
+    from event_3dgs_amd import losses
+    from oracle import torch_oracle
+    g = np.load(os.path.join(GOLDEN, "image_metrics.npz"))
+    a = torch.tensor(g["a"], device=DEV, requires_grad=True)
+    b = torch.tensor(g["b"], device=DEV)
+    assert abs(float(losses.ssim(a, b)) - float(g["ssim"])) <= 3e-6
+    assert abs(float(losses.ssim_gray(a, b)) - float(g["ssim_gray"])) <= 3e-6
+    assert abs(float(losses.l1_loss_gray(a, b)) - float(g["l1_gray"])) <= 1e-6
+    assert np.allclose(losses.psnr(a.detach(), b).cpu().numpy(), g["psnr"], atol=1e-4)
+    loss = losses.gray_iteration_loss(a, b)                         # train.py:213-223
+    assert abs(float(loss) - float(g["gray_loss"])) <= 3e-6
+    loss.backward()
+    ref = g["d_a_gray_loss"]
+    assert np.abs(a.grad.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    # ragged size, 3-channel (non-gray) path, against the CPU restatement with autograd
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 37, 53, generator=gen)
+    y = (x + 0.2 * torch.randn(3, 37, 53, generator=gen)).clamp(0, 1)
+    xc = x.clone().requires_grad_(True)
+    ref_v = torch_oracle.ssim(xc, y)
+    ref_v.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    v = losses.ssim(xg, y.to(DEV))
+    v.backward()
+    assert abs(float(v) - float(ref_v)) <= 3e-6
+    assert np.abs(xg.grad.cpu().numpy() - xc.grad.numpy()).max() <= 2e-5 * float(xc.grad.abs().max())
+    lr = losses.rgb_iteration_loss(xg, y.to(DEV))
+    assert abs(float(lr) - float(0.8 * (x - y).abs().mean() + 0.2 * (1 - ref_v))) <= 3e-6
