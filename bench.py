@@ -91,7 +91,10 @@ def main():
     gt_params = dict(params)
     gt_params["xyz"] = params["xyz"] + 0.01 * torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     gt_tr = EventTrainer(gt_params, dev)
-    gts = [gt_tr.render_raw(c, bg)["color"].clone() for c in (cam_int, cam_now, cam_next)]
+    # ground truth arrives as 8-bit images in the reference (PIL -> /255, utils/general_utils.py:21-27): quantise, so
+    # that unchanged pixels of the two event frames compare EQUAL and rho = mean(D* != 0) < 1 as on real data
+    gts = [(torch.round(gt_tr.render_raw(c, bg)["color"].clamp(0, 1) * 255.0) / 255.0).contiguous()
+           for c in (cam_int, cam_now, cam_next)]
     gt_blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
     del gt_tr
     trainer = EventTrainer(params, dev)

@@ -63,33 +63,6 @@ class EventTrainer:
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
                  track_densification_stats=False, multi_stream=True):
         self.device = torch.device(device)
-        self.N = params["xyz"].shape[0]
-        N = self.N
-        # one flat buffer each for parameters / gradients / Adam moments; the last element is the threshold c
-        nflat = N * FLOATS_PER_GAUSSIAN + 1
-        self.flat = torch.empty(nflat, dtype=torch.float32, device=self.device)
-        self.flat_grad = torch.zeros_like(self.flat)
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.views, self.grads, self.seg = {}, {}, {}
-        off = 0
-        # features are stored coefficient-major, (16*3, N) (E3DGS_FLAG_SH_PLANAR): rows 0..2 = f_dc, 3..47 = f_rest
-        shapes = {"xyz": (N, 3), "features": (48, N), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
-        feats = torch.cat((params["features_dc"], params["features_rest"]), dim=1).reshape(N, 48).t()
-        src = {"xyz": params["xyz"], "features": feats, "opacity": params["opacity"], "scaling": params["scaling"],
-               "rotation": params["rotation"]}
-        for name, per in SEGMENTS:
-            n = N * per
-            self.seg[name] = (off, n)
-            p = self.flat[off:off + n].view(shapes[name])
-            p.copy_(src[name].to(self.device))
-            self.views[name] = p
-            self.grads[name] = self.flat_grad[off:off + n].view(shapes[name])
-            off += n
-        self.seg["c"] = (off, 1)
-        self.c = self.flat[off:off + 1]
-        self.c.fill_(c_init)
-        self.c_grad = self.flat_grad[off:off + 1]
         self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
                                         lr_delay_mult=position_lr_delay_mult, max_steps=position_lr_max_steps)
@@ -100,15 +73,97 @@ class EventTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.track_stats = track_densification_stats
-        # reusable scratch
-        self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if track_densification_stats else None
+        self.multi_stream = multi_stream
+        self._streams = None
+        zeros = lambda t: torch.zeros_like(t)
+        groups = {"xyz": params["xyz"], "f_dc": params["features_dc"], "f_rest": params["features_rest"],
+                  "opacity": params["opacity"], "scaling": params["scaling"], "rotation": params["rotation"]}
+        self._build({k: [v.to(self.device), None, None] for k, v in groups.items()}, c_value=c_init)
+
+    def _build(self, groups, c_value, c_moments=None):
+        """(Re)creates the flat buffers from reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]."""
+        N = groups["xyz"][0].shape[0]
+        self.N = N
+        # one flat buffer each for parameters / gradients / Adam moments; the last element is the threshold c
+        nflat = N * FLOATS_PER_GAUSSIAN + 1
+        self.flat = torch.empty(nflat, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.views, self.grads, self.seg = {}, {}, {}
+        # features are stored coefficient-major, (16*3, N) (E3DGS_FLAG_SH_PLANAR): rows 0..2 = f_dc, 3..47 = f_rest
+        shapes = {"xyz": (N, 3), "features": (48, N), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+
+        def ref_to_flat(idx):
+            feats = torch.cat((groups["f_dc"][idx], groups["f_rest"][idx]), dim=1).reshape(N, 48).t()
+            return {"xyz": groups["xyz"][idx], "features": feats, "opacity": groups["opacity"][idx],
+                    "scaling": groups["scaling"][idx], "rotation": groups["rotation"][idx]}
+        src = ref_to_flat(0)
+        has_m = groups["xyz"][1] is not None
+        m_src, v_src = (ref_to_flat(1), ref_to_flat(2)) if has_m else (None, None)
+        off = 0
+        for name, per in SEGMENTS:
+            n = N * per
+            self.seg[name] = (off, n)
+            self.flat[off:off + n].view(shapes[name]).copy_(src[name])
+            if has_m:
+                self.exp_avg[off:off + n].view(shapes[name]).copy_(m_src[name])
+                self.exp_avg_sq[off:off + n].view(shapes[name]).copy_(v_src[name])
+            self.views[name] = self.flat[off:off + n].view(shapes[name])
+            self.grads[name] = self.flat_grad[off:off + n].view(shapes[name])
+            off += n
+        self.seg["c"] = (off, 1)
+        self.c = self.flat[off:off + 1]
+        self.c.fill_(float(c_value))
+        if c_moments is not None:
+            self.exp_avg[off] = c_moments[0]; self.exp_avg_sq[off] = c_moments[1]
+        self.c_grad = self.flat_grad[off:off + 1]
+        # scratch that depends on N
+        self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if self.track_stats else None
         self._loss_bufs = None
         self._counts = None
-        self._streams = None
         self._accs = None
-        self.multi_stream = multi_stream
+        self._streams = None
         self.last_radii = None
         self.last_scalars = None
+
+    def export_groups(self):
+        """Reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]  (scene/gaussian_model.py:154-163 groups)."""
+        N = self.N
+        out = {}
+        for idx, buf in enumerate((self.flat, self.exp_avg, self.exp_avg_sq)):
+            def seg(name, shape):
+                off, n = self.seg[name]
+                return buf[off:off + n].view(shape)
+            feats = seg("features", (48, N)).t().reshape(N, 16, 3)
+            cur = {"xyz": seg("xyz", (N, 3)).clone(), "f_dc": feats[:, :1].contiguous(), "f_rest": feats[:, 1:].contiguous(),
+                   "opacity": seg("opacity", (N, 1)).clone(), "scaling": seg("scaling", (N, 3)).clone(),
+                   "rotation": seg("rotation", (N, 4)).clone()}
+            for k, v in cur.items():
+                out.setdefault(k, [None, None, None])[idx] = v
+        return out
+
+    def import_groups(self, groups):
+        """Rebuild the flat buffers after the number of Gaussians changed (densification)."""
+        off, _ = self.seg["c"]
+        c_val = float(self.c)
+        c_mom = (float(self.exp_avg[off]), float(self.exp_avg_sq[off]))
+        self._build(groups, c_value=c_val, c_moments=c_mom)
+
+    def densify_and_prune(self, stats, max_grad=0.0002, min_opacity=0.005, extent=1.0, max_screen_size=None,
+                          percent_dense=0.01):
+        """scene/gaussian_model.py:389-403 on the trainer's buffers (densify.py holds the algorithm)."""
+        from . import densify
+        groups = self.export_groups()
+        densify.densify_and_prune(groups, stats, max_grad, min_opacity, extent, max_screen_size, percent_dense)
+        self.import_groups(groups)
+        return self.N
+
+    def reset_opacity(self):
+        from . import densify
+        groups = self.export_groups()
+        densify.reset_opacity(groups)
+        self.import_groups(groups)
 
     # ---- raster settings for one view (gaussian_renderer/__init__.py:35-51)
     def _settings(self, cam, bg, scaling_modifier=1.0):

@@ -13,6 +13,7 @@ Vectors:
   G4 event_loss.npz  utils/loss_utils.py differentialable_event_simu / l1_loss + the train.py:165-203 composition, grads
   G5 image_metrics.npz  ssim, ssim_gray, l1_loss_gray, psnr values
   G7 lr.npz          utils/general_utils.py get_expon_lr_func at steps {0,1,100,7000,30000}
+  G8 densify.npz     scene/gaussian_model.py densify_and_prune + reset_opacity on a seeded 256-Gaussian model (torch.manual_seed(77))
 """
 import os
 import sys
@@ -20,6 +21,7 @@ import types
 
 import numpy as np
 import torch
+from math import log as math_log
 
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -173,6 +175,50 @@ def main():
     fn = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=30000)
     steps = np.array([0, 1, 100, 7000, 30000])
     np.savez(os.path.join(OUT, "lr.npz"), steps=steps, lr=np.array([fn(int(s)) for s in steps], np.float64))
+    # ---- G8: one densify_and_prune + reset_opacity on a seeded 256-Gaussian model (scene/gaussian_model.py:258-403)
+    from argparse import ArgumentParser
+    from arguments import OptimizationParams
+    from scene.gaussian_model import GaussianModel
+    gm = GaussianModel(3)
+    Nn = 256
+    gg = torch.Generator().manual_seed(99)
+    P_ = lambda t: torch.nn.Parameter(t.requires_grad_(True))
+    gm._xyz = P_(torch.randn(Nn, 3, generator=gg))
+    gm._features_dc = P_(torch.randn(Nn, 1, 3, generator=gg))
+    gm._features_rest = P_(torch.randn(Nn, 15, 3, generator=gg) * 0.1)
+    gm._scaling = P_(torch.randn(Nn, 3, generator=gg) * 0.8 + math_log(0.04))
+    gm._rotation = P_(torch.randn(Nn, 4, generator=gg))
+    gm._opacity = P_(torch.randn(Nn, 1, generator=gg) * 3.0)
+    gm.max_radii2D = torch.zeros(Nn)
+    gm.spatial_lr_scale = 1.0
+    opt = OptimizationParams(ArgumentParser())
+    gm.training_setup(opt)
+    for grp in gm.optimizer.param_groups:                       # one Adam step so that the moments are non-trivial
+        grp["params"][0].grad = torch.randn(grp["params"][0].shape, generator=gg) * 1e-3
+    gm.optimizer.step()
+    gm.xyz_gradient_accum = torch.rand(Nn, 1, generator=gg) * 6e-4
+    gm.denom = torch.randint(0, 3, (Nn, 1), generator=gg).float()
+    gm.max_radii2D = torch.rand(Nn, generator=gg) * 40
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    def dump(tag, d):
+        for grp in gm.optimizer.param_groups:
+            p_ = grp["params"][0]
+            d[f"{tag}_{grp['name']}"] = p_.detach().numpy().copy()
+            st = gm.optimizer.state[p_]
+            d[f"{tag}_{grp['name']}_m"] = st["exp_avg"].numpy().copy()
+            d[f"{tag}_{grp['name']}_v"] = st["exp_avg_sq"].numpy().copy()
+        d[f"{tag}_accum"] = gm.xyz_gradient_accum.numpy().copy()
+        d[f"{tag}_denom"] = gm.denom.numpy().copy()
+        d[f"{tag}_maxr"] = gm.max_radii2D.numpy().copy()
+    dd = {}
+    dump("in", dd)
+    torch.manual_seed(77)
+    gm.densify_and_prune(0.0002, 0.005, 4.0, 20)
+    dump("out", dd)
+    gm.reset_opacity()
+    dump("reset", dd)
+    dd["args"] = np.array([0.0002, 0.005, 4.0, 20.0, 0.01])      # max_grad, min_opacity, extent, max_screen_size, percent_dense
+    np.savez(os.path.join(OUT, "densify.npz"), **dd)
     print("golden vectors written to", OUT)
 
 

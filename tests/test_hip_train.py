@@ -187,3 +187,37 @@ def test_ssim_kernel_matches_reference_golden_and_oracle():
     assert np.abs(xg.grad.cpu().numpy() - xc.grad.numpy()).max() <= 2e-5 * float(xc.grad.abs().max())
     lr = losses.rgb_iteration_loss(xg, y.to(DEV))
     assert abs(float(lr) - float(0.8 * (x - y).abs().mean() + 0.2 * (1 - ref_v))) <= 3e-6
+
+
+def test_trainer_densification_roundtrip_and_training_continues():
+    """export/import of the flat coefficient-major buffers is lossless; after densify_and_prune (N changes) the
+    trainer keeps training; opacity reset zeroes only the opacity moments."""
+    from event_3dgs_amd import densify
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene(N=3000, W=160, H=112, seed=5)
+    bg = torch.zeros(3, device=DEV)
+    gts = _gts(params, cams, bg)
+    tr = EventTrainer(params, DEV, track_densification_stats=True)
+    stats = densify.DensifyStats(tr.N, DEV)
+    # (with every GT pixel changing between the two event frames rho = 1 and the intensity term -- the only
+    #  source of gradient for render #1 -- has weight 0, train.py:190-196; the deblur term keeps it alive)
+    for _ in range(5):
+        tr.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gts[0])
+        stats.update(tr.viewspace_grad, tr.last_radii)               # train.py:319-320
+    assert float(stats.denom.max()) == 5.0 and float(stats.xyz_gradient_accum.sum()) > 0
+    flat0, m0 = tr.flat.clone(), tr.exp_avg.clone()
+    g = tr.export_groups()
+    assert torch.equal(g["f_dc"][0], torch.cat((params["features_dc"], params["features_rest"]), 1)[:, :1] * 0 + g["f_dc"][0])
+    tr.import_groups(g)
+    assert torch.equal(tr.flat, flat0) and torch.equal(tr.exp_avg, m0)
+    n0 = tr.N
+    thr = float((stats.xyz_gradient_accum / stats.denom.clamp_min(1)).median())
+    n1 = tr.densify_and_prune(stats, max_grad=thr, min_opacity=0.005, extent=4.0, max_screen_size=None)
+    assert n1 != n0 and stats.denom.shape[0] == n1 and float(stats.denom.sum()) == 0.0
+    assert tr.flat.numel() == 59 * n1 + 1
+    l = [float(tr.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)[0]) for _ in range(5)]
+    assert all(np.isfinite(l))
+    off, n = tr.seg["opacity"]
+    tr.reset_opacity()
+    assert float(torch.sigmoid(tr.views["opacity"]).max()) <= 0.01 + 1e-6
+    assert float(tr.exp_avg[off:off + n].abs().sum()) == 0.0 and float(tr.exp_avg[:100].abs().sum()) > 0.0
