@@ -14,6 +14,8 @@ Vectors:
   G5 image_metrics.npz  ssim, ssim_gray, l1_loss_gray, psnr values
   G7 lr.npz          utils/general_utils.py get_expon_lr_func at steps {0,1,100,7000,30000}
   G8 densify.npz     scene/gaussian_model.py densify_and_prune + reset_opacity on a seeded 256-Gaussian model (torch.manual_seed(77))
+  G9 colmap_tiny/ + colmap_tiny.npz   a tiny COLMAP model (bin + txt, written here) as parsed by scene/colmap_loader.py,
+                     plus the derived R/T/FoV (scene/dataset_readers.py:84-97) and getNerfppNorm (:47-68)
 """
 import os
 import sys
@@ -219,6 +221,76 @@ def main():
     dump("reset", dd)
     dd["args"] = np.array([0.0002, 0.005, 4.0, 20.0, 0.01])      # max_grad, min_opacity, extent, max_screen_size, percent_dense
     np.savez(os.path.join(OUT, "densify.npz"), **dd)
+    # ---- G9: tiny COLMAP model (binary + text) written here with struct, parsed by the reference's colmap_loader
+    import struct
+    from scene import colmap_loader as CL
+    from scene.dataset_readers import getNerfppNorm
+    from utils.graphics_utils import focal2fov
+    cdir = os.path.join(OUT, "colmap_tiny")
+    os.makedirs(cdir, exist_ok=True)
+    rs2 = np.random.RandomState(3)
+    cams_spec = [(1, 1, 640, 480, [500.0, 510.0, 320.0, 240.0]), (2, 0, 800, 600, [700.0, 400.0, 300.0])]
+    with open(os.path.join(cdir, "cameras.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(cams_spec)))
+        for cid, mid, w, h, pr in cams_spec:
+            f.write(struct.pack("<iiQQ", cid, mid, w, h)); f.write(struct.pack("<" + "d" * len(pr), *pr))
+    imgs_spec = []
+    for i in range(5):
+        q = rs2.randn(4); q /= np.linalg.norm(q)
+        imgs_spec.append((i + 1, q, rs2.randn(3) * 2, 1 + (i % 2), f"img_{4 - i:03d}.png", rs2.rand(3, 2) * 100, rs2.randint(-1, 50, 3)))
+    with open(os.path.join(cdir, "images.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(imgs_spec)))
+        for iid, q, t, cid, name, xys, pids in imgs_spec:
+            f.write(struct.pack("<idddddddi", iid, *q, *t, cid)); f.write(name.encode() + b"\x00")
+            f.write(struct.pack("<Q", len(pids)))
+            for (x, y), pid in zip(xys, pids):
+                f.write(struct.pack("<ddq", x, y, int(pid)))
+    npts = 7
+    pts = rs2.randn(npts, 3); cols = rs2.randint(0, 256, (npts, 3)); errs = rs2.rand(npts)
+    with open(os.path.join(cdir, "points3D.bin"), "wb") as f:
+        f.write(struct.pack("<Q", npts))
+        for i in range(npts):
+            f.write(struct.pack("<QdddBBBd", i + 1, *pts[i], *[int(c) for c in cols[i]], errs[i]))
+            tl = i % 3
+            f.write(struct.pack("<Q", tl)); f.write(struct.pack("<" + "ii" * tl, *([1, 2] * tl)))
+    with open(os.path.join(cdir, "cameras.txt"), "w") as f:
+        f.write("# Camera list\n")
+        for cid, mid, w, h, pr in cams_spec:           # the reference's text reader accepts PINHOLE only (colmap_loader.py:171)
+            pr4 = pr if mid == 1 else [pr[0], pr[0], pr[1], pr[2]]
+            f.write(f"{cid} PINHOLE {w} {h} " + " ".join(repr(x) for x in pr4) + "\n")
+    with open(os.path.join(cdir, "images.txt"), "w") as f:
+        f.write("# Image list with two lines of data per image\n")
+        for iid, q, t, cid, name, xys, pids in imgs_spec:
+            f.write(f"{iid} " + " ".join(repr(float(x)) for x in list(q) + list(t)) + f" {cid} {name}\n")
+            f.write(" ".join(f"{repr(float(x))} {repr(float(y))} {int(pid)}" for (x, y), pid in zip(xys, pids)) + "\n")
+    with open(os.path.join(cdir, "points3D.txt"), "w") as f:
+        f.write("# 3D point list\n")
+        for i in range(npts):
+            f.write(f"{i + 1} " + " ".join(repr(float(x)) for x in pts[i]) + " " + " ".join(str(int(c)) for c in cols[i]) + f" {repr(float(errs[i]))} 1 2\n")
+    cb, ib = CL.read_intrinsics_binary(os.path.join(cdir, "cameras.bin")), CL.read_extrinsics_binary(os.path.join(cdir, "images.bin"))
+    xb, rb, eb = CL.read_points3D_binary(os.path.join(cdir, "points3D.bin"))
+    ct, it_ = CL.read_intrinsics_text(os.path.join(cdir, "cameras.txt")), CL.read_extrinsics_text(os.path.join(cdir, "images.txt"))
+    xt, rt, et = CL.read_points3D_text(os.path.join(cdir, "points3D.txt"))
+    cg = {"xyz_bin": xb, "rgb_bin": rb, "err_bin": eb, "xyz_txt": xt, "rgb_txt": rt, "err_txt": et}
+    for tag, cc, ii in (("bin", cb, ib), ("txt", ct, it_)):
+        for k, c in cc.items():
+            cg[f"cam_{tag}_{k}"] = np.array([c.id, c.width, c.height] + list(c.params), np.float64); cg[f"cammodel_{tag}_{k}"] = np.array(c.model)
+        for k, im in ii.items():
+            cg[f"img_{tag}_{k}"] = np.concatenate([[im.id], im.qvec, im.tvec, [im.camera_id]]); cg[f"imgname_{tag}_{k}"] = np.array(im.name)
+            cg[f"imgxys_{tag}_{k}"] = im.xys; cg[f"imgpids_{tag}_{k}"] = im.point3D_ids
+    # derived view parameters (scene/dataset_readers.py:84-97) and the NeRF++ normalisation (:47-68)
+    class CI:  # minimal CameraInfo
+        pass
+    infos = []
+    for k, ex in ib.items():
+        intr = cb[ex.camera_id]
+        ci = CI(); ci.R = np.transpose(CL.qvec2rotmat(ex.qvec)); ci.T = np.array(ex.tvec)
+        fx = intr.params[0]; fy = intr.params[1] if intr.model == "PINHOLE" else intr.params[0]
+        cg[f"view_{k}"] = np.concatenate([ci.R.reshape(-1), ci.T, [focal2fov(fx, intr.width), focal2fov(fy, intr.height)]])
+        infos.append(ci)
+    nn_ = getNerfppNorm(infos)
+    cg["nerfpp_translate"], cg["nerfpp_radius"] = nn_["translate"], np.float64(nn_["radius"])
+    np.savez(os.path.join(OUT, "colmap_tiny.npz"), **cg)
     print("golden vectors written to", OUT)
 
 

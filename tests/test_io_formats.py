@@ -1,0 +1,101 @@
+"""On-disk formats: COLMAP readers against the reference's own loader (golden G9), model PLY
+layout, point-cloud PLY, checkpoint tuple."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from event_3dgs_amd import io_formats as IO
+
+CD = os.path.join(GOLDEN, "colmap_tiny")
+
+
+def test_g9_colmap_readers_match_reference_loader():
+    g = np.load(os.path.join(GOLDEN, "colmap_tiny.npz"))
+    for tag, cams, imgs, pts in (("bin", IO.read_cameras_binary(os.path.join(CD, "cameras.bin")),
+                                  IO.read_images_binary(os.path.join(CD, "images.bin")),
+                                  IO.read_points3D_binary(os.path.join(CD, "points3D.bin"))),
+                                 ("txt", IO.read_cameras_text(os.path.join(CD, "cameras.txt")),
+                                  IO.read_images_text(os.path.join(CD, "images.txt")),
+                                  IO.read_points3D_text(os.path.join(CD, "points3D.txt")))):
+        assert len(cams) == 2 and len(imgs) == 5
+        for k, c in cams.items():
+            assert np.array_equal(np.array([c.id, c.width, c.height] + list(c.params), np.float64), g[f"cam_{tag}_{k}"])
+            assert c.model == str(g[f"cammodel_{tag}_{k}"])
+        for k, im in imgs.items():
+            assert np.array_equal(np.concatenate([[im.id], im.qvec, im.tvec, [im.camera_id]]), g[f"img_{tag}_{k}"])
+            assert im.name == str(g[f"imgname_{tag}_{k}"])
+            assert np.array_equal(im.xys, g[f"imgxys_{tag}_{k}"]) and np.array_equal(im.point3D_ids, g[f"imgpids_{tag}_{k}"])
+        assert np.array_equal(pts[0], g[f"xyz_{tag}"]) and np.array_equal(pts[1], g[f"rgb_{tag}"])
+        assert np.array_equal(pts[2], g[f"err_{tag}"])
+    views = IO.colmap_cameras_to_views(IO.read_images_binary(os.path.join(CD, "images.bin")),
+                                       IO.read_cameras_binary(os.path.join(CD, "cameras.bin")))
+    assert [v["image_name"] for v in views] == sorted(v["image_name"] for v in views)      # dataset_readers.py:148
+    imgs = IO.read_images_binary(os.path.join(CD, "images.bin"))
+    by_name = {os.path.basename(im.name).split(".")[0]: k for k, im in imgs.items()}
+    for v in views:
+        ref = g[f"view_{by_name[v['image_name']]}"]
+        assert np.allclose(np.concatenate([v["R"].reshape(-1), v["T"], [v["FovX"], v["FovY"]]]), ref, rtol=0, atol=1e-12)
+    tr, rad = IO.nerf_normalization(views)
+    assert np.allclose(tr, g["nerfpp_translate"], atol=1e-6) and abs(rad - float(g["nerfpp_radius"])) <= 1e-6
+
+
+def test_model_ply_layout_and_roundtrip(tmp_path):
+    g = torch.Generator().manual_seed(0)
+    N = 37
+    p = dict(xyz=torch.randn(N, 3, generator=g), features_dc=torch.randn(N, 1, 3, generator=g),
+             features_rest=torch.randn(N, 15, 3, generator=g), opacity=torch.randn(N, 1, generator=g),
+             scaling=torch.randn(N, 3, generator=g), rotation=torch.randn(N, 4, generator=g))
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    IO.save_model_ply(path, **p)
+    raw = open(path, "rb").read()
+    header = raw[:raw.index(b"end_header\n") + 11].decode()
+    lines = header.strip().split("\n")
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", f"element vertex {N}"]
+    names = [l.split()[2] for l in lines[3:-1]]
+    assert names == (["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)]
+                     + ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"])
+    assert all(l.split()[1] == "float" for l in lines[3:-1]) and len(raw) == len(header) + N * 62 * 4
+    body = np.frombuffer(raw[len(header):], "<f4").reshape(N, 62)
+    # f_rest is channel-major on disk: (N,15,3) -> transpose -> (N,3,15) -> flatten (gaussian_model.py:197)
+    assert np.array_equal(body[:, 9:54], p["features_rest"].transpose(1, 2).flatten(1).numpy())
+    assert np.array_equal(body[:, 3:6], np.zeros((N, 3), np.float32)) and np.array_equal(body[:, 54], p["opacity"][:, 0].numpy())
+    q = IO.load_model_ply(path)
+    for k in p:
+        assert torch.equal(q[k], p[k]), k
+    assert q["active_sh_degree"] == 3
+
+
+def test_pointcloud_ply_roundtrip(tmp_path):
+    rs = np.random.RandomState(0)
+    xyz, rgb = rs.randn(20, 3).astype(np.float32), rs.randint(0, 256, (20, 3))
+    path = str(tmp_path / "points3D.ply")
+    IO.store_pointcloud_ply(path, xyz, rgb)
+    pc = IO.fetch_pointcloud_ply(path)
+    assert np.array_equal(pc.points, xyz) and np.allclose(pc.colors, rgb / 255.0) and np.all(pc.normals == 0)
+
+
+def test_checkpoint_tuple_is_loadable_by_torch_adam(tmp_path):
+    """capture -> torch.save -> torch.load -> restore; the optimizer state_dict loads into a torch Adam built
+    like training_setup (scene/gaussian_model.py:154-163)."""
+    from event_3dgs_amd.densify import DensifyStats
+    g = torch.Generator().manual_seed(1)
+    N = 11
+    shapes = {"xyz": (N, 3), "f_dc": (N, 1, 3), "f_rest": (N, 15, 3), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+    groups = {k: [torch.randn(s, generator=g), torch.randn(s, generator=g), torch.rand(s, generator=g)] for k, s in shapes.items()}
+    stats = DensifyStats(N, "cpu")
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    tup = IO.capture_checkpoint(groups, stats, 2, 1.5, lrs, step=40)
+    path = str(tmp_path / "chkpnt40.pth")
+    torch.save((tup, 40), path)                                   # train.py:334-336
+    (model_args, it) = torch.load(path, weights_only=False)
+    assert it == 40 and len(model_args) == 12 and model_args[0] == 2 and model_args[-1] == 1.5
+    params = [model_args[1], model_args[2], model_args[3], model_args[6], model_args[4], model_args[5]]
+    opt = torch.optim.Adam([{"params": [p], "lr": lrs[n], "name": n} for p, n in zip(params, lrs)], lr=0.0, eps=1e-15)
+    opt.load_state_dict(model_args[10])                           # what GaussianModel.restore does (:93)
+    assert torch.equal(opt.state[params[0]]["exp_avg"], groups["xyz"][1])
+    groups2, st2, deg, scale = IO.restore_checkpoint(model_args)
+    for k in groups:
+        for j in range(3):
+            assert torch.equal(groups2[k][j], groups[k][j]), (k, j)
