@@ -1,0 +1,51 @@
+"""The reference's `--event` training loop (train.py:45-336) on the fused trainer: camera sampling,
+SH-degree ramp, per-iteration event step, densification schedule, opacity reset.  No GUI / TensorBoard /
+argparse (SURVEY section 2 marks those out of scope); this is the loop body a user of the reference needs.
+"""
+from random import randint
+
+import torch
+
+from . import densify
+from .train_step import EventTrainer
+
+HELD_OUT = (5, 25, 45, 65, 85)       # evaluation views, train.py:129-131 / eval.py:118
+
+
+def sample_index(n_cameras, event=True, rng=randint):
+    """train.py:116-131: randint(2, n-4) in event mode (n-3 otherwise); held-out views shift down by one."""
+    index = rng(2, n_cameras - 4) if event else rng(2, n_cameras - 3)
+    if index in HELD_OUT:
+        index -= 1
+    return index
+
+
+def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations, cameras_extent=1.0,
+                    blurry_cameras=None, densify_until_iter=15000, densify_from_iter=500, densification_interval=100,
+                    opacity_reset_interval=10000, densify_grad_threshold=0.0002, percent_dense=0.01, white_background=False,
+                    sh_ramp_interval=1000, max_sh_degree=3, start_sh_degree=0, rng=randint, on_iteration=None,
+                    **trainer_kw):
+    """Returns the trained EventTrainer.  opacity_reset_interval defaults to the event-mode value the reference
+    forces at train.py:119.  `params` = pre-activation dict (synth.make_scene / scene_io.create_from_pcd)."""
+    tr = EventTrainer(params, device, spatial_lr_scale=cameras_extent, active_sh_degree=start_sh_degree,
+                      track_densification_stats=True, **trainer_kw)
+    stats = densify.DensifyStats(tr.N, device)
+    for iteration in range(1, iterations + 1):
+        if iteration % sh_ramp_interval == 0 and tr.active_sh_degree < max_sh_degree:      # train.py:99-100
+            tr.active_sh_degree += 1
+        index = sample_index(len(train_cameras), True, rng)
+        cam, now, nxt = train_cameras[index], event_cameras[index], event_cameras[index + 1]
+        blur = blurry_cameras[index].original_image if blurry_cameras else None             # train.py:197-203
+        scalars = tr.step(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image, bg, gt_blur=blur)
+        upd, dens, size_thr, reset = densify.densification_schedule(
+            iteration, densify_until_iter, densify_from_iter, densification_interval, opacity_reset_interval,
+            white_background)
+        if upd:                                                                             # train.py:317-327
+            stats.update(tr.viewspace_grad, tr.last_radii)
+            if dens:
+                tr.densify_and_prune(stats, densify_grad_threshold, 0.005, cameras_extent, size_thr, percent_dense)
+            if reset:
+                tr.reset_opacity()
+        if on_iteration is not None:
+            on_iteration(iteration, tr, scalars)
+    return tr

@@ -221,3 +221,42 @@ def test_trainer_densification_roundtrip_and_training_continues():
     tr.reset_opacity()
     assert float(torch.sigmoid(tr.views["opacity"]).max()) <= 0.01 + 1e-6
     assert float(tr.exp_avg[off:off + n].abs().sum()) == 0.0 and float(tr.exp_avg[:100].abs().sum()) > 0.0
+
+
+def test_fit_loop_with_densification_and_eval(tmp_path):
+    """End to end on the GPU: create_from_pcd (distCUDA2) -> event training loop with the densification
+    schedule -> evaluation protocol (gray PSNR/SSIM on held-out views) -> model PLY round trip."""
+    import random
+    from event_3dgs_amd import fit, io_formats, scene_io, synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    from simple_knn._C import distCUDA2
+    W, H, K = 128, 96, 96
+    bg = torch.zeros(3, device=DEV)
+    gt_params = synth.make_scene(3000, "trained", seed=9, device=DEV)
+    gt_tr = EventTrainer(gt_params, DEV)
+    q8 = lambda t: (torch.round(t.clamp(0, 1) * 255) / 255).contiguous()
+    train, events = [], []
+    for k in range(K):
+        for lst, daz in ((train, 0.0), (events, 0.002)):
+            c = orbit_camera(k, K, W, H, device=DEV, daz=daz)
+            c.original_image = q8(gt_tr.render_raw(c, bg)["color"])
+            lst.append(c)
+    pcd = io_formats.BasicPointCloud(gt_params["xyz"].cpu().numpy()[:1500], np.full((1500, 3), 0.5), np.zeros((1500, 3)))
+    params = scene_io.create_from_pcd(pcd, 1.0, distCUDA2, device=DEV)
+    assert params["scaling"].shape == (1500, 3) and float(torch.sigmoid(params["opacity"]).mean()) - 0.1 < 1e-6
+    rnd = random.Random(0)
+    sizes = []
+    tr = fit.fit_event_scene(params, train, events, bg, DEV, iterations=260, cameras_extent=4.4, densify_from_iter=50,
+                             densification_interval=100, sh_ramp_interval=100, rng=rnd.randint, densify_grad_threshold=1e-9,
+                             on_iteration=lambda it, t, s: sizes.append(t.N))
+    assert tr.active_sh_degree == 2 and sizes[0] == 1500 and sizes[-1] != 1500      # SH ramp and densification ran
+    res = scene_io.evaluate_views(lambda cam: tr.render_raw(cam, bg)["color"], train)
+    assert np.isfinite(res["psnr"]) and 0.0 < res["ssim"] <= 1.0 and len(res["per_view"]) == 5
+    g = tr.export_groups()
+    path = str(tmp_path / "point_cloud.ply")
+    io_formats.save_model_ply(path, g["xyz"][0], g["f_dc"][0], g["f_rest"][0], g["opacity"][0], g["scaling"][0], g["rotation"][0])
+    back = io_formats.load_model_ply(path, device=DEV)
+    tr2 = EventTrainer(back, DEV, active_sh_degree=tr.active_sh_degree)
+    a, b = tr.render_raw(train[3], bg)["color"], tr2.render_raw(train[3], bg)["color"]
+    assert torch.equal(a, b)                                   # the PLY holds the exact pre-activation state

@@ -99,3 +99,42 @@ def test_checkpoint_tuple_is_loadable_by_torch_adam(tmp_path):
     for k in groups:
         for j in range(3):
             assert torch.equal(groups2[k][j], groups[k][j]), (k, j)
+
+
+def _make_dataset(root):
+    """A tiny scene directory in the reference's layout, on top of the golden COLMAP model."""
+    import shutil
+    from PIL import Image
+    os.makedirs(os.path.join(root, "sparse/0"))
+    for f in ("cameras.bin", "images.bin", "points3D.bin"):
+        shutil.copy(os.path.join(CD, f), os.path.join(root, "sparse/0", f))
+    rs = np.random.RandomState(0)
+    imgs = IO.read_images_binary(os.path.join(CD, "images.bin"))
+    for d in ("images", "images_event", "images_blurry", "renders"):
+        os.makedirs(os.path.join(root, d))
+        for im in imgs.values():
+            w, h = (1920, 1080) if d == "images" else (64, 48)
+            Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, d, im.name))
+    return imgs
+
+
+def test_scene_directory_loader(tmp_path):
+    from event_3dgs_amd import scene_io
+    root = str(tmp_path / "scene")
+    imgs = _make_dataset(root)
+    sc = scene_io.load_colmap_scene(root, gray=True, event=True, deblur=False)
+    names = [c.image_name for c in sc.train_cameras]
+    assert names == sorted(os.path.basename(i.name).split(".")[0] for i in imgs.values())
+    assert len(sc.event_cameras) == 5 and len(sc.test_cameras) == 5 and sc.blurry_cameras == []
+    # -r -1 caps the width at 1600 (utils/camera_utils.py:26-36): 1920x1080 -> 1600x900
+    assert (sc.train_cameras[0].image_width, sc.train_cameras[0].image_height) == (1600, 900)
+    assert sc.event_cameras[0].original_image.shape == (3, 48, 64)
+    assert float(sc.event_cameras[0].original_image.max()) <= 1.0
+    assert os.path.exists(sc.ply_path) and np.all(sc.point_cloud.colors == 0.5)          # --gray initial colours
+    assert scene_io.target_resolution(1920, 1080, 1) == (1920, 1080)
+    assert scene_io.target_resolution(1920, 1080, 2) == (960, 540)
+    assert scene_io.target_resolution(1920, 1080, 800) == (800, 450)
+    g = np.load(os.path.join(GOLDEN, "colmap_tiny.npz"))
+    assert abs(sc.cameras_extent - float(g["nerfpp_radius"])) <= 1e-6
+    sc2 = scene_io.load_colmap_scene(root, deblur=True)
+    assert len(sc2.blurry_cameras) == 5 and not np.all(sc2.point_cloud.colors == 0.5)
