@@ -15,7 +15,7 @@ constexpr int BWD_WAVES = 4;
 extern unsigned long long* g_trace;
 __global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ work,
                                   uint32_t* __restrict__ order);
-__global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
+__global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ acc /* (P,12): mx my A B C o c0 c1 c2 - - - */) {
@@ -23,12 +23,14 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     __shared__ float4 sB[BWD_WAVES][WAVE];
     __shared__ float4 sC[BWD_WAVES][WAVE];
     __shared__ uint32_t sId[BWD_WAVES][WAVE];
-    // Gradient staging.  Per entry the nine per-lane sums are reduced only WITHIN each row of 16 lanes, with a
-    // transposed butterfly (after the xor-1 / xor-2 quad steps every lane owns two of the eight values, so the
-    // later steps move a quarter of the data): 26 DPP/select ops instead of 54.  The four row partials are parked
-    // here and every 16 entries lanes 0..15 add the rows, convert to conic / mean gradients and commit with nine
-    // 16-lane atomic instructions (instead of 9 single-lane atomics per entry).
-    __shared__ float4 sPart[BWD_WAVES][16][4][3];   // [entry & 15][row of 16 lanes][12 floats]
+    // Gradient reduction through LDS.  DPP adds cost ~9 cycles per wave-instruction on this chip (plain adds 2.7),
+    // so instead of a 54-op (or 26-op transposed) DPP butterfly the nine per-lane sums of an entry are transposed
+    // through the wave's LDS slice: 9 conflict-free ds_write_b32, then lane (v,p) = (lane>>3, lane&7) reads the 8
+    // floats [8p,8p+8) of value v as two ds_read_b128 and adds them, and three DPP steps finish the 8-lane groups.
+    // The LDS pipe is otherwise idle in this kernel.  Reduced sums are parked in sPart and committed every 16
+    // entries by lanes 0..15 with nine 16-lane atomic instructions.
+    __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][9][68];        // per-entry transpose buffer: [value][lane], rows padded to 68
+    __shared__ float4 sPart[BWD_WAVES][16][3];      // [entry & 15][12 floats]: reduced sums parked until the commit
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;
@@ -41,7 +43,6 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
     const size_t HW = (size_t)H * W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-    const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
 
     // Per-pixel state of the back-to-front walk.  With C = sum_j c_j a_j T_j + T_final bg and
     // T_j = prod_{i<j}(1 - a_i):   dC/da_g = c_g T_g - (sum_{j>g} c_j a_j T_j + T_final bg) / (1 - a_g).
@@ -135,32 +136,28 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
             }
             if (__builtin_amdgcn_ballot_w64(any) != 0) {
                 touched |= 1ull << j;
-                // V = [Sx, Sy, Sxx, Sxy | Syy, So, Sc0, Sc1]; step 1 pairs lanes l, l^1; step 2 lanes l, l^2
-                float r0, r1, r2, r3;
-                {
-                    const float k0 = odd1 ? Syy : Sx, s0 = odd1 ? Sx : Syy;
-                    const float k1 = odd1 ? So : Sy, s1 = odd1 ? Sy : So;
-                    const float k2 = odd1 ? Sc0 : Sxx, s2 = odd1 ? Sxx : Sc0;
-                    const float k3 = odd1 ? Sc1 : Sxy, s3 = odd1 ? Sxy : Sc1;
-                    r0 = k0 + dpp_f<DPP_QUAD_XOR1>(s0); r1 = k1 + dpp_f<DPP_QUAD_XOR1>(s1);
-                    r2 = k2 + dpp_f<DPP_QUAD_XOR1>(s2); r3 = k3 + dpp_f<DPP_QUAD_XOR1>(s3);
+                float* r = &sRed[wave][0][0];
+                r[0 * 68 + lane] = Sx;  r[1 * 68 + lane] = Sy;  r[2 * 68 + lane] = Sxx;
+                r[3 * 68 + lane] = Sxy; r[4 * 68 + lane] = Syy; r[5 * 68 + lane] = So;
+                r[6 * 68 + lane] = Sc0; r[7 * 68 + lane] = Sc1; r[8 * 68 + lane] = Sc2;
+                wave_sync();
+                const int rv = lane >> 3, rp = lane & 7;
+                const float4 q0 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp);
+                const float4 q1 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp + 4);
+                float s = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+                float s8 = 0.0f;
+                if (lane < 8) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(r + 8 * 68 + 8 * lane);
+                    const float4 a1 = *reinterpret_cast<const float4*>(r + 8 * 68 + 8 * lane + 4);
+                    s8 = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
                 }
-                float u0, u1;
-                {
-                    const float k0 = odd2 ? r2 : r0, s0 = odd2 ? r0 : r2;
-                    const float k1 = odd2 ? r3 : r1, s1 = odd2 ? r1 : r3;
-                    u0 = k0 + dpp_f<DPP_QUAD_XOR2>(s0); u1 = k1 + dpp_f<DPP_QUAD_XOR2>(s1);
-                }
-                // class c = lane & 3 now owns: c0 (Sx,Sy)  c1 (Syy,So)  c2 (Sxx,Sxy)  c3 (Sc0,Sc1), summed over its quad
-                u0 += dpp_f<DPP_ROW_ROR4>(u0); u1 += dpp_f<DPP_ROW_ROR4>(u1);
-                u0 += dpp_f<DPP_ROW_ROR8>(u0); u1 += dpp_f<DPP_ROW_ROR8>(u1);
-                float w8 = Sc2 + dpp_f<DPP_QUAD_XOR1>(Sc2);
-                w8 += dpp_f<DPP_QUAD_XOR2>(w8);
-                w8 += dpp_f<DPP_ROW_ROR4>(w8);
-                w8 += dpp_f<DPP_ROW_ROR8>(w8);
-                float* prow = reinterpret_cast<float*>(&sPart[wave][j & 15][lane >> 4][0]);
-                if ((lane & 12) == 0) *reinterpret_cast<float2*>(prow + 2 * (lane & 3)) = make_float2(u0, u1);
-                if ((lane & 15) == 0) prow[8] = w8;
+                s += dpp_f<DPP_QUAD_XOR1>(s);  s8 += dpp_f<DPP_QUAD_XOR1>(s8);
+                s += dpp_f<DPP_QUAD_XOR2>(s);  s8 += dpp_f<DPP_QUAD_XOR2>(s8);
+                s += dpp_f<0x141>(s);          s8 += dpp_f<0x141>(s8);            // row_half_mirror: the other quad
+                float* pe = reinterpret_cast<float*>(&sPart[wave][j & 15][0]);
+                if (rp == 0) pe[rv] = s;                 // slots 0..7 = Sx Sy Sxx Sxy Syy So Sc0 Sc1
+                if (lane == 0) pe[8] = s8;               // slot 8 = Sc2
+                wave_sync();
             }
             if ((j & 15) == 15 || j == cnt - 1) {
                 // commit the (up to) 16 entries parked since the last commit
@@ -168,26 +165,19 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE) void render_bwd_kernel(
                 wave_sync();
                 if (lane < 16 && ((touched >> (jb + lane)) & 1ull)) {
                     const int e = jb + lane;
-                    float4 p0 = sPart[wave][lane][0][0], p1 = sPart[wave][lane][0][1];
-                    float p2 = sPart[wave][lane][0][2].x;
-#pragma unroll
-                    for (int rr = 1; rr < 4; ++rr) {
-                        const float4 q0 = sPart[wave][lane][rr][0], q1 = sPart[wave][lane][rr][1];
-                        p0.x += q0.x; p0.y += q0.y; p0.z += q0.z; p0.w += q0.w;
-                        p1.x += q1.x; p1.y += q1.y; p1.z += q1.z; p1.w += q1.w;
-                        p2 += sPart[wave][lane][rr][2].x;
-                    }
-                    // slots: p0 = (Sx, Sy, Syy, So)   p1 = (Sxx, Sxy, Sc0, Sc1)   p2 = Sc2
+                    const float4 p0 = sPart[wave][lane][0], p1 = sPart[wave][lane][1];
+                    const float p2 = sPart[wave][lane][2].x;
+                    // p0 = (Sx, Sy, Sxx, Sxy)   p1 = (Syy, So, Sc0, Sc1)   p2 = Sc2
                     const float4 ea = sA[wave][e];
                     const float4 eb = sB[wave][e];
                     float* g = acc + E3_ACC_STRIDE * (size_t)sId[wave][e];   // one 48-B record: 1-2 cache lines
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
                     unsafeAtomicAdd(g + 0, -(ea.z * p0.x + ea.w * p0.y) * ddelx_dx);
                     unsafeAtomicAdd(g + 1, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy);
-                    unsafeAtomicAdd(g + 2, -0.5f * p1.x);
-                    unsafeAtomicAdd(g + 3, -p1.y);
-                    unsafeAtomicAdd(g + 4, -0.5f * p0.z);
-                    unsafeAtomicAdd(g + 5, p0.w);
+                    unsafeAtomicAdd(g + 2, -0.5f * p0.z);
+                    unsafeAtomicAdd(g + 3, -p0.w);
+                    unsafeAtomicAdd(g + 4, -0.5f * p1.x);
+                    unsafeAtomicAdd(g + 5, p1.y);
                     unsafeAtomicAdd(g + 6, p1.z);
                     unsafeAtomicAdd(g + 7, p1.w);
                     unsafeAtomicAdd(g + 8, p2);
