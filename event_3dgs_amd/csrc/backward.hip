@@ -18,17 +18,19 @@ __global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, 
 __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, float* __restrict__ acc /* (P,12): mx my A B C o c0 c1 c2 - - - */) {
+    const uint32_t* __restrict__ perm, const float* __restrict__ dL_dpix,
+    float* __restrict__ part /* (I,12) per-instance records at EMISSION positions: mx my A B C o c0 c1 c2 - - - */) {
     __shared__ float4 sA[BWD_WAVES][WAVE];
     __shared__ float4 sB[BWD_WAVES][WAVE];
     __shared__ float4 sC[BWD_WAVES][WAVE];
-    __shared__ uint32_t sId[BWD_WAVES][WAVE];
+    __shared__ uint32_t sId[BWD_WAVES][WAVE];       // emission index of the staged entries (where their record goes)
     // Gradient reduction through LDS.  DPP adds cost ~9 cycles per wave-instruction on this chip (plain adds 2.7),
     // so instead of a 54-op (or 26-op transposed) DPP butterfly the nine per-lane sums of an entry are transposed
     // through the wave's LDS slice: 9 conflict-free ds_write_b32, then lane (v,p) = (lane>>3, lane&7) reads the 8
     // floats [8p,8p+8) of value v as two ds_read_b128 and adds them, and three DPP steps finish the 8-lane groups.
     // The LDS pipe is otherwise idle in this kernel.  Reduced sums are parked in sPart and committed every 16
-    // entries by lanes 0..15 with nine 16-lane atomic instructions.
+    // entries by lanes 0..15 as three 16-byte stores into the instance's own record (no atomics: the per-Gaussian
+    // sum over its instances happens in geom_bwd_kernel, in a fixed order -> deterministic gradients).
     __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][9][68];        // per-entry transpose buffer: [value][lane], rows padded to 68
     __shared__ float4 sPart[BWD_WAVES][16][3];      // [entry & 15][12 floats]: reduced sums parked until the commit
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -74,21 +76,28 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
     // staging pipeline as in the forward kernel: ids one round early, records gathered under the math
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0), rc = make_float4(0, 0, 0, 0);
-    uint32_t rid = 0, id_next = 0;
+    uint32_t rid = 0, id_next = 0, re = 0, e_next = 0;
     if (lane < n) {
         rid = point_list[range.x + (uint32_t)(n - 1 - lane)];
+        re = perm[range.x + (uint32_t)(n - 1 - lane)];
         ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
     }
-    if (WAVE + lane < n) id_next = point_list[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
+    if (WAVE + lane < n) {
+        id_next = point_list[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
+        e_next = perm[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
+    }
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
-        sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = rid;
+        sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = re;
         wave_sync();
         if (base + WAVE + lane < n) {
-            rid = id_next;
+            rid = id_next; re = e_next;
             ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
         }
-        if (base + 2 * WAVE + lane < n) id_next = point_list[range.x + (uint32_t)(n - 1 - (base + 2 * WAVE + lane))];
+        if (base + 2 * WAVE + lane < n) {
+            id_next = point_list[range.x + (uint32_t)(n - 1 - (base + 2 * WAVE + lane))];
+            e_next = perm[range.x + (uint32_t)(n - 1 - (base + 2 * WAVE + lane))];
+        }
         unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
@@ -170,17 +179,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                     // p0 = (Sx, Sy, Sxx, Sxy)   p1 = (Syy, So, Sc0, Sc1)   p2 = Sc2
                     const float4 ea = sA[wave][e];
                     const float4 eb = sB[wave][e];
-                    float* g = acc + E3_ACC_STRIDE * (size_t)sId[wave][e];   // one 48-B record: 1-2 cache lines
+                    float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)sId[wave][e]);
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
-                    unsafeAtomicAdd(g + 0, -(ea.z * p0.x + ea.w * p0.y) * ddelx_dx);
-                    unsafeAtomicAdd(g + 1, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy);
-                    unsafeAtomicAdd(g + 2, -0.5f * p0.z);
-                    unsafeAtomicAdd(g + 3, -p0.w);
-                    unsafeAtomicAdd(g + 4, -0.5f * p1.x);
-                    unsafeAtomicAdd(g + 5, p1.y);
-                    unsafeAtomicAdd(g + 6, p1.z);
-                    unsafeAtomicAdd(g + 7, p1.w);
-                    unsafeAtomicAdd(g + 8, p2);
+                    g[0] = make_float4(-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy,
+                                       -0.5f * p0.z, -p0.w);
+                    g[1] = make_float4(-0.5f * p1.x, p1.y, p1.z, p1.w);
+                    g[2] = make_float4(p2, 0.0f, 0.0f, 0.0f);
                 }
                 wave_sync();
             }
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
     const float* __restrict__ cov_pre, ViewParams vp, int flags, const int* __restrict__ radii,
-    const uint32_t* __restrict__ clamped, const float* __restrict__ acc, float* dL_dmean2D, float* dL_dopacity,
+    const uint32_t* __restrict__ clamped, const uint2* __restrict__ run, const float* __restrict__ part,
+    float* dL_dmean2D, float* dL_dopacity,
     float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -292,7 +297,18 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     }
     const float* V = vp.view;
     const float* Pm = vp.proj;
-    const float* g12 = acc + E3_ACC_STRIDE * (size_t)i;
+    // sum this Gaussian's per-instance records (contiguous in emission order; fixed order -> deterministic)
+    float g12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const uint2 rn = run[i];
+        const float4* pr = reinterpret_cast<const float4*>(part + E3_ACC_STRIDE * (size_t)rn.x);
+        for (uint32_t k = 0; k < rn.y; ++k) {
+            const float4 q0 = pr[3 * k], q1 = pr[3 * k + 1];
+            const float q2 = pr[3 * k + 2].x;
+            g12[0] += q0.x; g12[1] += q0.y; g12[2] += q0.z; g12[3] += q0.w;
+            g12[4] += q1.x; g12[5] += q1.y; g12[6] += q1.z; g12[7] += q1.w; g12[8] += q2;
+        }
+    }
     float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     float S[6];
     if (cov_pre) {
@@ -488,7 +504,7 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
         tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
             g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.point_list, geom.rec,
-            background, img.final_T, img.n_contrib, dL_dpix, grad_acc);
+            background, img.final_T, img.n_contrib, bin.perm, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;
@@ -496,11 +512,11 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
     ProfScope ps(PS_GEOM_BWD, s);
     if (flags & E3_FLAG_ACCUMULATE)
         geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, grad_acc,
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, geom.run, grad_acc,
             dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     else
         geom_bwd_kernel<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, grad_acc,
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, geom.run, grad_acc,
             dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     }
     KERNEL_OK("geom_bwd_kernel");

@@ -172,7 +172,7 @@ void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t*
     out9[4] = (size_t)g.rect;
     p = nullptr;
     BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
-    out9[5] = (size_t)b.point_list;
+    out9[5] = (size_t)b.point_list;     // (b.perm, the emission index per sorted position, follows it)
     p = nullptr;
     int gx = (width + E3_TILE - 1) / E3_TILE, gy = (height + E3_TILE - 1) / E3_TILE;
     ImageState im = ImageState::from(p, (size_t)width * height, (size_t)gx * gy);

@@ -25,7 +25,7 @@
 #define E3_FLAG_SH_PLANAR 4   // shs / dL_dsh are coefficient-major (M*3, P): lane-coalesced, no (P,M,3) stride
 #define E3_FLAG_BWD_ONLY_RENDER 8   // backward: run only the compositing backward (fills grad_acc)
 #define E3_FLAG_BWD_ONLY_GEOM 16    // backward: run only the per-Gaussian backward (consumes grad_acc)
-#define E3_ACC_STRIDE 12      // floats per Gaussian in the backward accumulation record
+#define E3_ACC_STRIDE 12      // floats per (tile, Gaussian) instance in the backward gradient records
 
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define WAVE 64
@@ -149,6 +149,8 @@ struct GeomState {
                        //   [0] (x, y, conic.x, conic.y)  [1] (conic.z, opacity, r, g)  [2] (b, pmin, -, -)
                        //   pmin: alpha >= 1/255 needs power >= pmin = -(ln(255 o) + margin)
     uint32_t* clamped; // SH clamp bitmask (bit ch)
+    uint2* run;        // (first emission index, kept instance count) of each Gaussian: where backward finds its
+                       // per-instance gradient records
     uint2* rect;       // packed tile rectangle: .x = xmin | ymin<<16, .y = xmax | ymax<<16
     uint32_t* key0;    // depth keys (ping)
     uint32_t* key1;    // (pong)
@@ -168,6 +170,7 @@ struct GeomState {
         size_t n = P ? P : 1;
         g.rec = carve<float4>(p, 3 * n);
         g.clamped = carve<uint32_t>(p, n);
+        g.run = carve<uint2>(p, n);
         g.rect = carve<uint2>(p, n);
         g.key0 = carve<uint32_t>(p, n);
         g.key1 = carve<uint32_t>(p, n);
@@ -183,10 +186,12 @@ struct GeomState {
 
 // binning state: everything sized by the instance count I.  point_list is first (backward reads it).
 struct BinningState {
-    uint32_t* point_list; // final sorted Gaussian ids
+    uint32_t* point_list; // final sorted Gaussian ids (tile-major, depth order)           [read by fwd + bwd]
+    uint32_t* perm;       // emission index of the instance at each sorted position         [read by bwd]
     uint32_t* vals_alt;
     uint32_t* keys;       // tile ids
     uint32_t* keys_alt;
+    uint32_t* emit_gid;   // Gaussian id of each instance in EMISSION order (Gaussian-major)
     uint32_t* scratch;
     static size_t required(size_t I) {
         char* p = nullptr;
@@ -197,9 +202,11 @@ struct BinningState {
         BinningState b;
         size_t n = I ? I : 1;
         b.point_list = carve<uint32_t>(p, n);
+        b.perm = carve<uint32_t>(p, n);
         b.vals_alt = carve<uint32_t>(p, n);
         b.keys = carve<uint32_t>(p, n);
         b.keys_alt = carve<uint32_t>(p, n);
+        b.emit_gid = carve<uint32_t>(p, n);
         b.scratch = carve<uint32_t>(p, sort_scratch_words(n));
         return b;
     }

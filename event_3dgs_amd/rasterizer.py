@@ -245,8 +245,8 @@ def backward_raw(raw, grad_out_color, out, flags=None, grad_acc=None):
     if g.dtype != torch.float32:
         g = g.float()
     g = g.contiguous()
-    if grad_acc is None:
-        grad_acc = torch.zeros(P, _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
+    if grad_acc is None:      # one zero-filled record per (tile, Gaussian) instance
+        grad_acc = torch.zeros(max(int(raw["num_rendered"]), 1), _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = L.e3dgs_rasterize_backward(
             P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(bg), W, H, _lib.ptr(means3D), _lib.ptr(sh),

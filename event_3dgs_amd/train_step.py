@@ -191,7 +191,6 @@ class EventTrainer:
         if self._streams is None:
             self._streams = [torch.cuda.Stream(self.device) for _ in range(3)] if self.multi_stream else [main] * 3
             self._counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(3)]
-            self._accs = [torch.empty(self.N, _lib.ACC_STRIDE, dtype=torch.float32, device=self.device) for _ in range(3)]
         S = self._streams
         v = self.views
         cams = (cam_int, cam_now, cam_next)
@@ -208,11 +207,13 @@ class EventTrainer:
         for k in range(3):
             S[k].synchronize()                     # the iteration's only host waits: instance counts are back
         # ---- forward, second half (binning, tile sort, compositing)
-        raws = []
+        raws, accs = [], []
         for k in range(3):
             with torch.cuda.stream(S[k]):
                 raws.append(rasterizer.forward_finish(pend[k]))
-                self._accs[k].zero_()
+                # per-instance gradient records of this view's backward (zero: instances the walk never reaches)
+                accs.append(torch.zeros(max(raws[k]["num_rendered"], 1), _lib.ACC_STRIDE, dtype=torch.float32,
+                                        device=self.device))
                 main.wait_event(S[k].record_event())
         if self._loss_bufs is None:
             img = raws[0]["color"]
@@ -231,7 +232,7 @@ class EventTrainer:
         for k in range(3):
             with torch.cuda.stream(S[k]):
                 S[k].wait_event(ev_loss)
-                rasterizer.backward_raw(raws[k], dpix[k], out, grad_acc=self._accs[k],
+                rasterizer.backward_raw(raws[k], dpix[k], out, grad_acc=accs[k],
                                         flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE | _lib.FLAG_BWD_ONLY_RENDER)
                 main.wait_event(S[k].record_event())
         # ---- ... and the accumulating per-Gaussian stage runs in order on the main stream
@@ -239,7 +240,7 @@ class EventTrainer:
             o = dict(out)
             if k == 0 and self.track_stats:
                 o["means2D"] = self.viewspace_grad          # densification statistics use render #1 only (train.py:145)
-            rasterizer.backward_raw(raws[k], dpix[k], o, grad_acc=self._accs[k],
+            rasterizer.backward_raw(raws[k], dpix[k], o, grad_acc=accs[k],
                                     flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE | _lib.FLAG_BWD_ONLY_GEOM)
         self.c_grad.copy_(scalars[1:2])
         if self.world > 1 and sync_grads:

@@ -127,8 +127,10 @@ int e3dgs_rasterize_forward_finish(
  * diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
  * loss.backward() at train.py:211 through _RasterizeGaussians.backward.
  *
- * grad_acc (P,12) must be ZERO-FILLED by the caller: the compositing backward accumulates
- * into it atomically (per Gaussian: dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad).
+ * grad_acc (num_rendered,12) must be ZERO-FILLED by the caller: the compositing backward stores one record per
+ * (tile, Gaussian) instance (dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad) at the instance's emission
+ * position -- plain stores, no float atomics -- and the per-Gaussian stage sums each Gaussian's contiguous run
+ * in a fixed order, so gradients are bit-reproducible run to run (the reference's atomics are not).
  * Without E3DGS_FLAG_ACCUMULATE every other output is written in full (zeros for culled
  * Gaussians), so nothing else needs pre-zeroing.  dL_dmean2D is (P,3): first two components in
  * NDC units (consumed by scene/gaussian_model.py:405-407), third 0; always overwritten.
@@ -146,7 +148,7 @@ int e3dgs_rasterize_backward(
     const int* radii,
     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
     const float* dL_dpix,             /* (3,H,W) */
-    float* grad_acc,                  /* (P,12) zero-filled scratch */
+    float* grad_acc,                  /* (num_rendered,12) zero-filled scratch */
     float* dL_dmean2D,                /* (P,3) or NULL */
     float* dL_dopacity,               /* (P) or NULL */
     float* dL_dcolor,                 /* (P,3) or NULL */

@@ -198,3 +198,12 @@ def test_mark_visible_matches_near_plane_test():
     # fp32 fma-order differences only matter exactly at the plane
     ref = (hom[:, 2] > 0.2).numpy()
     assert (vis != ref).sum() <= 1 and 0 < vis.sum() < 500
+
+
+def test_backward_is_deterministic():
+    """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
+    act, cam = scene(3000, 192, 128, seed=13)
+    a = _run_hip(act, cam, (0.1, 0.1, 0.1), True, False)[2]
+    b = _run_hip(act, cam, (0.1, 0.1, 0.1), True, False)[2]
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
