@@ -16,7 +16,7 @@ extern unsigned long long* g_trace;
 __global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ work,
                                   uint32_t* __restrict__ order);
 __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
-    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ perm, const float* __restrict__ dL_dpix,
     float* __restrict__ part /* (I,12) per-instance records at EMISSION positions: mx my A B C o c0 c1 c2 - - - */) {
@@ -74,30 +74,29 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     const unsigned long long t_loop = trace ? wall_clock64() : 0ull;
 
     // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
-    // staging pipeline as in the forward kernel: ids one round early, records gathered under the math
+    // staging pipeline as in the forward kernel (three deep: emission index -> Gaussian id -> record)
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0), rc = make_float4(0, 0, 0, 0);
-    uint32_t rid = 0, id_next = 0, re = 0, e_next = 0;
+    uint32_t re = 0, e_next = 0, id_next = 0, e_next2 = 0;
     if (lane < n) {
-        rid = point_list[range.x + (uint32_t)(n - 1 - lane)];
         re = perm[range.x + (uint32_t)(n - 1 - lane)];
+        const uint32_t rid = emit_gid[re];
         ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
     }
     if (WAVE + lane < n) {
-        id_next = point_list[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
         e_next = perm[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
+        id_next = emit_gid[e_next];
     }
+    if (2 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (2 * WAVE + lane))];
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = re;
         wave_sync();
         if (base + WAVE + lane < n) {
-            rid = id_next; re = e_next;
-            ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
+            re = e_next;
+            ra = rec[3 * (size_t)id_next]; rb = rec[3 * (size_t)id_next + 1]; rc = rec[3 * (size_t)id_next + 2];
         }
-        if (base + 2 * WAVE + lane < n) {
-            id_next = point_list[range.x + (uint32_t)(n - 1 - (base + 2 * WAVE + lane))];
-            e_next = perm[range.x + (uint32_t)(n - 1 - (base + 2 * WAVE + lane))];
-        }
+        if (base + 2 * WAVE + lane < n) { e_next = e_next2; id_next = emit_gid[e_next2]; }
+        if (base + 3 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (base + 3 * WAVE + lane))];
         unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
@@ -503,7 +502,7 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
         ProfScope ps(PS_RENDER_BWD, s);
         tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.point_list, geom.rec,
+            g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.emit_gid, geom.rec,
             background, img.final_T, img.n_contrib, bin.perm, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");

@@ -165,6 +165,11 @@ int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float*
                             (hipStream_t)stream);
 }
 
+size_t e3dgs_state_offset_emit_gid(int num_rendered) {
+    char* p = nullptr;
+    BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
+    return (size_t)b.emit_gid;
+}
 void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9) {
     char* p = nullptr;
     GeomState g = GeomState::from(p, (size_t)(P > 0 ? P : 0));
@@ -172,7 +177,7 @@ void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t*
     out9[4] = (size_t)g.rect;
     p = nullptr;
     BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
-    out9[5] = (size_t)b.point_list;     // (b.perm, the emission index per sorted position, follows it)
+    out9[5] = (size_t)b.perm;
     p = nullptr;
     int gx = (width + E3_TILE - 1) / E3_TILE, gy = (height + E3_TILE - 1) / E3_TILE;
     ImageState im = ImageState::from(p, (size_t)width * height, (size_t)gx * gy);

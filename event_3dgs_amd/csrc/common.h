@@ -186,12 +186,12 @@ struct GeomState {
 
 // binning state: everything sized by the instance count I.  point_list is first (backward reads it).
 struct BinningState {
-    uint32_t* point_list; // final sorted Gaussian ids (tile-major, depth order)           [read by fwd + bwd]
-    uint32_t* perm;       // emission index of the instance at each sorted position         [read by bwd]
+    uint32_t* perm;       // sorted instance list (tile-major, depth order) as EMISSION indices [read by fwd + bwd]
+    uint32_t* point_list; // unused scratch (kept so that offsets stay stable)
     uint32_t* vals_alt;
     uint32_t* keys;       // tile ids
     uint32_t* keys_alt;
-    uint32_t* emit_gid;   // Gaussian id of each instance in EMISSION order (Gaussian-major)
+    uint32_t* emit_gid;   // Gaussian id of each instance in EMISSION order (Gaussian-major)   [read by fwd + bwd]
     uint32_t* scratch;
     static size_t required(size_t I) {
         char* p = nullptr;
@@ -201,8 +201,8 @@ struct BinningState {
     static BinningState from(char*& p, size_t I) {
         BinningState b;
         size_t n = I ? I : 1;
-        b.point_list = carve<uint32_t>(p, n);
         b.perm = carve<uint32_t>(p, n);
+        b.point_list = carve<uint32_t>(p, 1);
         b.vals_alt = carve<uint32_t>(p, n);
         b.keys = carve<uint32_t>(p, n);
         b.keys_alt = carve<uint32_t>(p, n);

@@ -312,22 +312,19 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
     }
 }
 
-// After the stable tile sort: tile ranges, and the Gaussian id of every sorted instance.  The sort moved
-// (tile id, emission index) pairs; the emission index is kept (`perm`) because backward stores each instance's
-// gradient record at its EMISSION position, where the records of one Gaussian are contiguous -- that turns the
-// reference's float atomics into plain stores plus a per-Gaussian run reduction (deterministic, and ~2x faster:
-// the atomics were 44 % of the compositing backward on this chip).
-__global__ __launch_bounds__(256) void finalize_lists_kernel(uint32_t I, const uint32_t* __restrict__ keys,
-                                                             const uint32_t* __restrict__ perm,
-                                                             const uint32_t* __restrict__ emit_gid,
-                                                             uint32_t* __restrict__ point_list,
-                                                             uint2* __restrict__ ranges) {
+// After the stable tile sort: [start, end) of each tile.  The sort moved (tile id, emission index) pairs; the
+// compositing kernels translate emission index -> Gaussian id themselves (`emit_gid`, a small L2-resident gather
+// that rides in their staging pipeline) and backward stores each instance's gradient record at its EMISSION
+// position, where the records of one Gaussian are contiguous -- that turns the reference's float atomics into
+// plain stores plus a per-Gaussian run reduction (deterministic, and ~2x faster: the atomics were 44 % of the
+// compositing backward on this chip).
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint32_t* __restrict__ keys,
+                                                          uint2* __restrict__ ranges) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     uint32_t t = keys[i];
     if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
     if (i == I - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
-    point_list[i] = emit_gid[perm[i]];
 }
 
 // ------------------------------------------------------------------------------------ compositing
@@ -381,7 +378,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
 unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
 
 __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
-    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ perm,
+    const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
@@ -413,15 +411,17 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     const int n = (int)(range.y - range.x);
     int live_strips = 0;      // wave-uniform (SALU): (entry, 16x4 strip) pairs that were evaluated
 
-    // staging pipeline: the ids of round r+1 are fetched one round early, so issuing the record gathers of the
-    // next round costs ONE memory round trip (not id -> record), and both are in flight under this round's math
+    // staging pipeline, three deep: round r+2's emission indices, round r+1's Gaussian ids (emit_gid gather) and
+    // round r+1's records are all in flight under round r's math, so each round costs one exposed memory round
+    // trip at most (at the tile start) instead of index -> id -> record
     float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0), rc = make_float4(0, 0, 0, 0);
-    uint32_t id_next = 0;
+    uint32_t id_next = 0, e_next2 = 0;
     if (lane < n) {
-        const uint32_t id = point_list[range.x + lane];
+        const uint32_t id = emit_gid[perm[range.x + lane]];
         ra = rec[3 * (size_t)id]; rb = rec[3 * (size_t)id + 1]; rc = rec[3 * (size_t)id + 2];
     }
-    if (WAVE + lane < n) id_next = point_list[range.x + WAVE + lane];
+    if (WAVE + lane < n) id_next = emit_gid[perm[range.x + WAVE + lane]];
+    if (2 * WAVE + lane < n) e_next2 = perm[range.x + 2 * WAVE + lane];
     for (int base = 0; base < n; base += WAVE) {
         if (__builtin_amdgcn_ballot_w64(T[0] > 0.0f || T[1] > 0.0f || T[2] > 0.0f || T[3] > 0.0f) == 0) break;
         const int cnt = min(WAVE, n - base);
@@ -431,7 +431,8 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
         if (base + WAVE + lane < n) {
             ra = rec[3 * (size_t)id_next]; rb = rec[3 * (size_t)id_next + 1]; rc = rec[3 * (size_t)id_next + 2];
         }
-        if (base + 2 * WAVE + lane < n) id_next = point_list[range.x + base + 2 * WAVE + lane];
+        if (base + 2 * WAVE + lane < n) id_next = emit_gid[e_next2];
+        if (base + 3 * WAVE + lane < n) e_next2 = perm[range.x + base + 3 * WAVE + lane];
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
@@ -640,10 +641,9 @@ int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, in
         if (vs != bin.perm) return e3_fail(hipErrorUnknown, "internal: sorted list not in perm");
         {
         ProfScope ps(PS_RANGES, s);
-        finalize_lists_kernel<<<dim3((I + 255) / 256), dim3(256), 0, s>>>(I, ks, bin.perm, bin.emit_gid, bin.point_list,
-                                                                          img.ranges);
+        tile_ranges_kernel<<<dim3((I + 255) / 256), dim3(256), 0, s>>>(I, ks, img.ranges);
         }
-        KERNEL_OK("finalize_lists_kernel");
+        KERNEL_OK("tile_ranges_kernel");
     }
     {
     ProfScope ps(PS_RANGES, s);
@@ -652,7 +652,7 @@ int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, in
     KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        g_trace, ntiles, img.order, gx, W, H, img.ranges, bin.point_list, geom.rec, background,
+        g_trace, ntiles, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
         out_color, img.final_T, img.n_contrib, img.work);
     KERNEL_OK("render_fwd_kernel");
     return 0;

@@ -186,7 +186,11 @@ def state_views(raw, P, W, H):
     return dict(
         recA=rec[:, 0:4], recB=rec[:, 4:8], recC=rec[:, 8:10], clamped=view(g, offs[3], torch.int32, P, (P,)),
         rect=view(g, offs[4], torch.int32, 2 * P, (P, 2)),
-        point_list=view(b, offs[5], torch.int32, I, (I,)),
+        perm=view(b, offs[5], torch.int32, I, (I,)),
+        emit_gid=view(b, _lib.lib().e3dgs_state_offset_emit_gid(I), torch.int32, I, (I,)),
+        # sorted Gaussian ids (what the reference calls point_list): emit_gid gathered through perm
+        point_list=view(b, _lib.lib().e3dgs_state_offset_emit_gid(I), torch.int32, I, (I,))[
+            view(b, offs[5], torch.int32, I, (I,)).long()],
         ranges=view(im, offs[6], torch.int32, 2 * gx * gy, (gx * gy, 2)),
         final_T=view(im, offs[7], torch.float32, W * H, (H, W)),
         n_contrib=view(im, offs[8], torch.int32, W * H, (H, W)))

@@ -178,10 +178,12 @@ int e3dgs_get_tile_cull(void);
  *   out[0..4]  geom:    one 48-byte record per Gaussian (stride 12 floats): out[0] -> (x,y,conic.x,conic.y),
  *                       out[1] -> (conic.z,opacity,r,g), out[2] -> (b, strip-skip bound, -, -);
  *                       clamped (u32), rect (uint2 packed 16-bit xmin|ymin, xmax|ymax)
- *   out[5]     binning: point_list (u32 Gaussian ids, tile-major, depth order)
+ *   out[5]     binning: perm (u32 EMISSION indices of the instances, tile-major, depth order); the Gaussian id of
+ *                       emission index e is emit_gid[e], at byte offset e3dgs_state_offset_emit_gid(num_rendered)
  *   out[6..8]  image:   ranges (uint2 per tile), final_T (float per pixel), n_contrib (u32 per pixel)
  */
 void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9);
+size_t e3dgs_state_offset_emit_gid(int num_rendered);
 
 /*
  * present[i] = 1 iff Gaussian i passes the near-plane test of the forward.
