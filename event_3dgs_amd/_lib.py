@@ -50,6 +50,10 @@ def lib():
     L.e3dgs_rasterize_backward.argtypes = (
         [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
         + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, C.c_int, _vp])
+    L.e3dgs_rasterize_backward_geom_multi.restype = C.c_int
+    L.e3dgs_rasterize_backward_geom_multi.argtypes = (
+        [C.c_int] * 4 + [_fp] * 4 + [C.c_float, _fp] + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_void_p)] * 3
+        + [C.POINTER(C.c_float)] * 2 + [C.POINTER(C.c_void_p)] * 3 + [_fp] * 6 + [C.c_int, C.c_int, _vp])
     L.e3dgs_set_tile_cull.restype = None
     L.e3dgs_set_tile_cull.argtypes = [C.c_int]
     L.e3dgs_get_tile_cull.restype = C.c_int
@@ -108,7 +112,7 @@ ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
-    "e3dgs_rasterize_backward",
+    "e3dgs_rasterize_backward", "e3dgs_rasterize_backward_geom_multi",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

@@ -171,10 +171,13 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 // commit the (up to) 16 entries parked since the last commit
                 const int jb = j & ~15;
                 wave_sync();
-                if (lane < 16 && ((touched >> (jb + lane)) & 1ull)) {
+                if (lane < 16 && jb + lane < cnt) {
                     const int e = jb + lane;
-                    const float4 p0 = sPart[wave][lane][0], p1 = sPart[wave][lane][1];
-                    const float p2 = sPart[wave][lane][2].x;
+                    // entries no pixel of the tile used still get a (zero) record: grad_acc needs no pre-zeroing
+                    const bool hit = ((touched >> e) & 1ull) != 0ull;
+                    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const float4 p0 = hit ? sPart[wave][lane][0] : z4, p1 = hit ? sPart[wave][lane][1] : z4;
+                    const float p2 = hit ? sPart[wave][lane][2].x : 0.0f;
                     // p0 = (Sx, Sy, Sxx, Sxy)   p1 = (Syy, So, Sc0, Sc1)   p2 = Sc2
                     const float4 ea = sA[wave][e];
                     const float4 eb = sB[wave][e];
@@ -189,6 +192,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
             }
         }
         wave_sync();
+    }
+    // list entries behind the last contributor of every pixel are never walked: zero records
+    for (uint32_t e = range.x + (uint32_t)n + (uint32_t)lane; e < range.y; e += WAVE) {
+        float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)perm[e]);
+        const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        g[0] = z4; g[1] = z4; g[2] = z4;
     }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;
@@ -262,79 +271,54 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
     gmean[2] += (ddz - z * dot) / len;
 }
 
-// One thread per Gaussian.  ACCUM=false writes every output element (zeros for culled Gaussians, so the
-// caller never has to pre-zero); ACCUM=true adds into the outputs for visible Gaussians only, which lets the
-// three renders of a training iteration accumulate straight into the flat gradient buffer.
-template <bool ACCUM>
-__global__ __launch_bounds__(256) void geom_bwd_kernel(
-    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
-    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
-    const float* __restrict__ cov_pre, ViewParams vp, int flags, const int* __restrict__ radii,
-    const uint32_t* __restrict__ clamped, const uint2* __restrict__ run, const float* __restrict__ part,
-    float* dL_dmean2D, float* dL_dopacity,
-    float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const bool preact = (flags & E3_FLAG_PREACT) != 0;
-    if (radii[i] <= 0) {
-        if (!ACCUM) {
-            if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
-            if (dL_dopacity) dL_dopacity[i] = 0.0f;
-            if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = 0.0f; dL_dcolor[3 * (size_t)i + 1] = 0.0f; dL_dcolor[3 * (size_t)i + 2] = 0.0f; }
-            dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
-            if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
-            if (dL_dsh) {
-                const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
-                float* d0 = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
-                const size_t st0 = pl ? (size_t)P : (size_t)1;
-                for (int k = 0; k < 3 * M; ++k) d0[(size_t)k * st0] = 0.0f;
-            }
-            if (dL_dscale) { dL_dscale[3 * (size_t)i] = 0.0f; dL_dscale[3 * (size_t)i + 1] = 0.0f; dL_dscale[3 * (size_t)i + 2] = 0.0f; }
-            if (dL_drot) for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = 0.0f;
-        }
-        return;
+// ---- shared pieces of the per-Gaussian backward (one view's contribution, then the view-independent tail)
+
+// Sigma3 = (R diag s)(R diag s)^T from activated scale / unit quaternion.
+struct Cov3 {
+    float R[3][3];
+    float s[3];
+    float S[6];
+};
+__device__ __forceinline__ void build_cov3(const float sact[3], float scale_modifier, float qr, float qx, float qy,
+                                           float qz, Cov3& c) {
+    const float s0 = scale_modifier * sact[0], s1 = scale_modifier * sact[1], s2 = scale_modifier * sact[2];
+    c.s[0] = s0; c.s[1] = s1; c.s[2] = s2;
+    float (*R)[3] = c.R;
+    R[0][0] = 1.0f - 2.0f * FMA(qy, qy, qz * qz); R[0][1] = 2.0f * FMA(qx, qy, -(qr * qz)); R[0][2] = 2.0f * FMA(qx, qz, qr * qy);
+    R[1][0] = 2.0f * FMA(qx, qy, qr * qz); R[1][1] = 1.0f - 2.0f * FMA(qx, qx, qz * qz); R[1][2] = 2.0f * FMA(qy, qz, -(qr * qx));
+    R[2][0] = 2.0f * FMA(qx, qz, -(qr * qy)); R[2][1] = 2.0f * FMA(qy, qz, qr * qx); R[2][2] = 1.0f - 2.0f * FMA(qx, qx, qy * qy);
+    float L[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { L[a][0] = R[a][0] * s0; L[a][1] = R[a][1] * s1; L[a][2] = R[a][2] * s2; }
+    float* S = c.S;
+    S[0] = FMA(L[0][0], L[0][0], FMA(L[0][1], L[0][1], L[0][2] * L[0][2]));
+    S[1] = FMA(L[0][0], L[1][0], FMA(L[0][1], L[1][1], L[0][2] * L[1][2]));
+    S[2] = FMA(L[0][0], L[2][0], FMA(L[0][1], L[2][1], L[0][2] * L[2][2]));
+    S[3] = FMA(L[1][0], L[1][0], FMA(L[1][1], L[1][1], L[1][2] * L[1][2]));
+    S[4] = FMA(L[1][0], L[2][0], FMA(L[1][1], L[2][1], L[1][2] * L[2][2]));
+    S[5] = FMA(L[2][0], L[2][0], FMA(L[2][1], L[2][1], L[2][2] * L[2][2]));
+}
+
+// Sum a Gaussian's per-instance records (contiguous in emission order; fixed order -> deterministic).
+__device__ __forceinline__ void sum_run(const uint2 rn, const float* __restrict__ part, float g12[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g12[k] = 0.0f;
+    const float4* pr = reinterpret_cast<const float4*>(part + E3_ACC_STRIDE * (size_t)rn.x);
+    for (uint32_t k = 0; k < rn.y; ++k) {
+        const float4 q0 = pr[3 * k], q1 = pr[3 * k + 1];
+        const float q2 = pr[3 * k + 2].x;
+        g12[0] += q0.x; g12[1] += q0.y; g12[2] += q0.z; g12[3] += q0.w;
+        g12[4] += q1.x; g12[5] += q1.y; g12[6] += q1.z; g12[7] += q1.w; g12[8] += q2;
     }
+}
+
+// One view: conic -> Sigma2 -> (Sigma3, view-space mean) and NDC mean -> world mean.
+// Writes gcov[6] (dL/dSigma3 of this view) and gmean[3] (dL/dmean3D of this view, without the SH term).
+__device__ __forceinline__ void view_geom_backward(const ViewParams& vp, float mx, float my, float mz,
+                                                   const float S[6], const float g12[9], float gcov[6],
+                                                   float gmean[3]) {
     const float* V = vp.view;
     const float* Pm = vp.proj;
-    // sum this Gaussian's per-instance records (contiguous in emission order; fixed order -> deterministic)
-    float g12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        const uint2 rn = run[i];
-        const float4* pr = reinterpret_cast<const float4*>(part + E3_ACC_STRIDE * (size_t)rn.x);
-        for (uint32_t k = 0; k < rn.y; ++k) {
-            const float4 q0 = pr[3 * k], q1 = pr[3 * k + 1];
-            const float q2 = pr[3 * k + 2].x;
-            g12[0] += q0.x; g12[1] += q0.y; g12[2] += q0.z; g12[3] += q0.w;
-            g12[4] += q1.x; g12[5] += q1.y; g12[6] += q1.z; g12[7] += q1.w; g12[8] += q2;
-        }
-    }
-    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-    float S[6];
-    if (cov_pre) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
-    }
-    float qr = 0, qx = 0, qy = 0, qz = 0, s0 = 0, s1 = 0, s2 = 0, qinv = 1.0f;
-    float sact[3] = {0, 0, 0};
-    float R[3][3];
-    if (!cov_pre) {
-        float qn[4];
-        act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, preact, sact, qn, qinv);
-        qr = qn[0]; qx = qn[1]; qy = qn[2]; qz = qn[3];
-        s0 = vp.scale_modifier * sact[0]; s1 = vp.scale_modifier * sact[1]; s2 = vp.scale_modifier * sact[2];
-        R[0][0] = 1.0f - 2.0f * FMA(qy, qy, qz * qz); R[0][1] = 2.0f * FMA(qx, qy, -(qr * qz)); R[0][2] = 2.0f * FMA(qx, qz, qr * qy);
-        R[1][0] = 2.0f * FMA(qx, qy, qr * qz); R[1][1] = 1.0f - 2.0f * FMA(qx, qx, qz * qz); R[1][2] = 2.0f * FMA(qy, qz, -(qr * qx));
-        R[2][0] = 2.0f * FMA(qx, qz, -(qr * qy)); R[2][1] = 2.0f * FMA(qy, qz, qr * qx); R[2][2] = 1.0f - 2.0f * FMA(qx, qx, qy * qy);
-        float L[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { L[a][0] = R[a][0] * s0; L[a][1] = R[a][1] * s1; L[a][2] = R[a][2] * s2; }
-        S[0] = FMA(L[0][0], L[0][0], FMA(L[0][1], L[0][1], L[0][2] * L[0][2]));
-        S[1] = FMA(L[0][0], L[1][0], FMA(L[0][1], L[1][1], L[0][2] * L[1][2]));
-        S[2] = FMA(L[0][0], L[2][0], FMA(L[0][1], L[2][1], L[0][2] * L[2][2]));
-        S[3] = FMA(L[1][0], L[1][0], FMA(L[1][1], L[1][1], L[1][2] * L[1][2]));
-        S[4] = FMA(L[1][0], L[2][0], FMA(L[1][1], L[2][1], L[1][2] * L[2][2]));
-        S[5] = FMA(L[2][0], L[2][0], FMA(L[2][1], L[2][1], L[2][2] * L[2][2]));
-    }
     // ---- recompute the EWA intermediates
     float vx = XFORM(V, 0, mx, my, mz), vy = XFORM(V, 1, mx, my, mz), vz = XFORM(V, 2, mx, my, mz);
     float limx = E3_GUARD_BAND * vp.tanfovx, limy = E3_GUARD_BAND * vp.tanfovy;
@@ -367,17 +351,12 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
         g_c = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
         g_b = d2inv * (2.0f * b * c * gA - (a * c + b * b) * gB + 2.0f * a * b * gC);
     }
-    float gcov[6];
     gcov[0] = T00 * T00 * g_a + T00 * T10 * g_b + T10 * T10 * g_c;
     gcov[3] = T01 * T01 * g_a + T01 * T11 * g_b + T11 * T11 * g_c;
     gcov[5] = T02 * T02 * g_a + T02 * T12 * g_b + T12 * T12 * g_c;
     gcov[1] = 2.0f * T00 * T01 * g_a + (T00 * T11 + T01 * T10) * g_b + 2.0f * T10 * T11 * g_c;
     gcov[2] = 2.0f * T00 * T02 * g_a + (T00 * T12 + T02 * T10) * g_b + 2.0f * T10 * T12 * g_c;
     gcov[4] = 2.0f * T02 * T01 * g_a + (T01 * T12 + T02 * T11) * g_b + 2.0f * T11 * T12 * g_c;
-    if (dL_dcov3D) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) put<ACCUM>(&dL_dcov3D[6 * (size_t)i + k], gcov[k]);
-    }
     float gT00 = 2.0f * g_a * u0 + g_b * w0, gT01 = 2.0f * g_a * u1 + g_b * w1, gT02 = 2.0f * g_a * u2 + g_b * w2;
     float gT10 = 2.0f * g_c * w0 + g_b * u0, gT11 = 2.0f * g_c * w1 + g_b * u1, gT12 = 2.0f * g_c * w2 + g_b * u2;
     float gJ00 = V[0] * gT00 + V[4] * gT01 + V[8] * gT02;
@@ -389,14 +368,108 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     float gty = ymul * (-vp.focal_y * itz2 * gJ12);
     float gtz = -vp.focal_x * itz2 * gJ00 - vp.focal_y * itz2 * gJ11 + (2.0f * vp.focal_x * tx) * itz3 * gJ02 +
                 (2.0f * vp.focal_y * ty) * itz3 * gJ12;
-    float gmean[3];
     gmean[0] = V[0] * gtx + V[1] * gty + V[2] * gtz;
     gmean[1] = V[4] * gtx + V[5] * gty + V[6] * gtz;
     gmean[2] = V[8] * gtx + V[9] * gty + V[10] * gtz;
     // ---- NDC mean gradient through the projection
     float gm2x = g12[0], gm2y = g12[1];
+    float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
+    float pw = 1.0f / (hw + E3_W_EPS);
+    float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
+    gmean[0] += (Pm[0] * pw - Pm[3] * mul1) * gm2x + (Pm[1] * pw - Pm[3] * mul2) * gm2y;
+    gmean[1] += (Pm[4] * pw - Pm[7] * mul1) * gm2x + (Pm[5] * pw - Pm[7] * mul2) * gm2y;
+    gmean[2] += (Pm[8] * pw - Pm[11] * mul1) * gm2x + (Pm[9] * pw - Pm[11] * mul2) * gm2y;
+}
+
+// dL/dSigma3 -> (scale, quaternion); with PREACT also through exp / normalize.
+__device__ __forceinline__ void cov3_backward(const Cov3& c, const float gcov[6], float scale_modifier, float qr,
+                                              float qx, float qy, float qz, bool preact, const float sact[3],
+                                              float qinv, float ds[3], float dq[4]) {
+    const float (*R)[3] = c.R;
+    const float* s = c.s;
+    const float Gs[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                            {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                            {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+    float dR[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float dl = 2.0f * (Gs[r][0] * (R[0][j] * s[j]) + Gs[r][1] * (R[1][j] * s[j]) + Gs[r][2] * (R[2][j] * s[j]));
+            t += R[r][j] * dl;
+            dR[r][j] = s[j] * dl;
+        }
+        ds[j] = scale_modifier * t;
+    }
+    dq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+    dq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - qr * dR[1][2] + qz * dR[2][0] + qr * dR[2][1] - 2.0f * qx * dR[2][2]);
+    dq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - qr * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
+    dq[3] = 2.0f * (-2.0f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+    if (preact) {
+        // scales = exp(raw): d/draw = d/dscale * scale;  rotation = raw/|raw|: project out the radial part
+        ds[0] *= sact[0]; ds[1] *= sact[1]; ds[2] *= sact[2];
+        float dot = qr * dq[0] + qx * dq[1] + qy * dq[2] + qz * dq[3];
+        dq[0] = (dq[0] - qr * dot) * qinv; dq[1] = (dq[1] - qx * dot) * qinv;
+        dq[2] = (dq[2] - qy * dot) * qinv; dq[3] = (dq[3] - qz * dot) * qinv;
+    }
+}
+
+// One thread per Gaussian.  ACCUM=false writes every output element (zeros for culled Gaussians, so the
+// caller never has to pre-zero); ACCUM=true adds into the outputs for visible Gaussians only, which lets the
+// renders of a training iteration accumulate straight into one gradient buffer.
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void geom_bwd_kernel(
+    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
+    const float* __restrict__ cov_pre, ViewParams vp, int flags, const int* __restrict__ radii,
+    const uint32_t* __restrict__ clamped, const uint2* __restrict__ run, const float* __restrict__ part,
+    float* dL_dmean2D, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool preact = (flags & E3_FLAG_PREACT) != 0;
+    if (radii[i] <= 0) {
+        if (!ACCUM) {
+            if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
+            if (dL_dopacity) dL_dopacity[i] = 0.0f;
+            if (dL_dcolor) { dL_dcolor[3 * (size_t)i] = 0.0f; dL_dcolor[3 * (size_t)i + 1] = 0.0f; dL_dcolor[3 * (size_t)i + 2] = 0.0f; }
+            dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
+            if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = 0.0f;
+            if (dL_dsh) {
+                const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
+                float* d0 = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
+                const size_t st0 = pl ? (size_t)P : (size_t)1;
+                for (int k = 0; k < 3 * M; ++k) d0[(size_t)k * st0] = 0.0f;
+            }
+            if (dL_dscale) { dL_dscale[3 * (size_t)i] = 0.0f; dL_dscale[3 * (size_t)i + 1] = 0.0f; dL_dscale[3 * (size_t)i + 2] = 0.0f; }
+            if (dL_drot) for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = 0.0f;
+        }
+        return;
+    }
+    float g12[9];
+    sum_run(run[i], part, g12);
+    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    Cov3 cv;
+    float qr = 0, qx = 0, qy = 0, qz = 0, qinv = 1.0f;
+    float sact[3] = {0, 0, 0};
+    if (cov_pre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cv.S[k] = cov_pre[6 * (size_t)i + k];
+    } else {
+        float qn[4];
+        act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, preact, sact, qn, qinv);
+        qr = qn[0]; qx = qn[1]; qy = qn[2]; qz = qn[3];
+        build_cov3(sact, vp.scale_modifier, qr, qx, qy, qz, cv);
+    }
+    float gcov[6], gmean[3];
+    view_geom_backward(vp, mx, my, mz, cv.S, g12, gcov, gmean);
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) put<ACCUM>(&dL_dcov3D[6 * (size_t)i + k], gcov[k]);
+    }
     if (dL_dmean2D) {   // NDC-unit screen-space gradient (scene/gaussian_model.py:405-407); overwritten
-        dL_dmean2D[3 * (size_t)i] = gm2x; dL_dmean2D[3 * (size_t)i + 1] = gm2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+        dL_dmean2D[3 * (size_t)i] = g12[0]; dL_dmean2D[3 * (size_t)i + 1] = g12[1]; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
     }
     {
         float go = g12[5];
@@ -407,12 +480,6 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
         put<ACCUM>(&dL_dcolor[3 * (size_t)i], g12[6]); put<ACCUM>(&dL_dcolor[3 * (size_t)i + 1], g12[7]);
         put<ACCUM>(&dL_dcolor[3 * (size_t)i + 2], g12[8]);
     }
-    float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
-    float pw = 1.0f / (hw + E3_W_EPS);
-    float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
-    gmean[0] += (Pm[0] * pw - Pm[3] * mul1) * gm2x + (Pm[1] * pw - Pm[3] * mul2) * gm2y;
-    gmean[1] += (Pm[4] * pw - Pm[7] * mul1) * gm2x + (Pm[5] * pw - Pm[7] * mul2) * gm2y;
-    gmean[2] += (Pm[8] * pw - Pm[11] * mul1) * gm2x + (Pm[9] * pw - Pm[11] * mul2) * gm2y;
     if (shs) {
         float gcol[3] = {g12[6], g12[7], g12[8]};
         const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
@@ -422,42 +489,170 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i], gmean[0]);
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i + 1], gmean[1]);
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i + 2], gmean[2]);
-    // ---- Sigma3 = (R diag s)(R diag s)^T
     if (!cov_pre) {
-        const float s[3] = {s0, s1, s2};
-        const float Gs[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
-                                {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
-                                {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
-        float dR[3][3];
-        float ds[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float t = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                float dl = 2.0f * (Gs[r][0] * (R[0][j] * s[j]) + Gs[r][1] * (R[1][j] * s[j]) + Gs[r][2] * (R[2][j] * s[j]));
-                t += R[r][j] * dl;
-                dR[r][j] = s[j] * dl;
-            }
-            ds[j] = vp.scale_modifier * t;
-        }
-        float dq[4];
-        dq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
-        dq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - qr * dR[1][2] + qz * dR[2][0] + qr * dR[2][1] - 2.0f * qx * dR[2][2]);
-        dq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - qr * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
-        dq[3] = 2.0f * (-2.0f * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
-        if (preact) {
-            // scales = exp(raw): d/draw = d/dscale * scale;  rotation = raw/|raw|: project out the radial part
-            ds[0] *= sact[0]; ds[1] *= sact[1]; ds[2] *= sact[2];
-            float dot = qr * dq[0] + qx * dq[1] + qy * dq[2] + qz * dq[3];
-            dq[0] = (dq[0] - qr * dot) * qinv; dq[1] = (dq[1] - qx * dot) * qinv;
-            dq[2] = (dq[2] - qy * dot) * qinv; dq[3] = (dq[3] - qz * dot) * qinv;
-        }
+        float ds[3], dq[4];
+        cov3_backward(cv, gcov, vp.scale_modifier, qr, qx, qy, qz, preact, sact, qinv, ds, dq);
 #pragma unroll
         for (int k = 0; k < 3; ++k) put<ACCUM>(&dL_dscale[3 * (size_t)i + k], ds[k]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) put<ACCUM>(&dL_drot[4 * (size_t)i + k], dq[k]);
     }
+}
+
+// ---- all views of one training iteration in ONE per-Gaussian pass -----------------------------------------
+// The reference's loss.backward() (train.py:211) runs the rasteriser backward once per render and autograd
+// adds the three results into .grad.  Here one thread per Gaussian loops over the views: parameters are read
+// once, the activation / Sigma3 work is shared, dL/dSigma3 and dL/dmean are summed in registers, and every
+// gradient element is written exactly once (zeros when no view saw the Gaussian), so the caller neither
+// pre-zeroes the gradient buffer nor serialises the views.
+struct MultiView {
+    ViewParams vp;
+    const int* radii;
+    const uint32_t* clamped;
+    const uint2* run;
+    const float* part;
+};
+struct MultiViews {
+    int n;
+    MultiView v[E3_MAX_VIEWS];
+};
+
+// real SH basis function k and its gradient w.r.t. the unit direction (same constants as sh_backward)
+__device__ __forceinline__ void sh_basis(int k, float x, float y, float z, float& Y, float& Yx, float& Yy, float& Yz) {
+    const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+    const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
+                C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+    const float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f,
+                C33 = 0.3731763325901154f, C34 = -0.4570457994644658f, C35 = 1.445305721320277f,
+                C36 = -0.5900435899266435f;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    switch (k) {
+    case 0: Y = SH_C0; Yx = 0.0f; Yy = 0.0f; Yz = 0.0f; break;
+    case 1: Y = -SH_C1 * y; Yx = 0.0f; Yy = -SH_C1; Yz = 0.0f; break;
+    case 2: Y = SH_C1 * z; Yx = 0.0f; Yy = 0.0f; Yz = SH_C1; break;
+    case 3: Y = -SH_C1 * x; Yx = -SH_C1; Yy = 0.0f; Yz = 0.0f; break;
+    case 4: Y = C20 * xy; Yx = C20 * y; Yy = C20 * x; Yz = 0.0f; break;
+    case 5: Y = C21 * yz; Yx = 0.0f; Yy = C21 * z; Yz = C21 * y; break;
+    case 6: Y = C22 * (2.0f * zz - xx - yy); Yx = C22 * -2.0f * x; Yy = C22 * -2.0f * y; Yz = C22 * 4.0f * z; break;
+    case 7: Y = C23 * xz; Yx = C23 * z; Yy = 0.0f; Yz = C23 * x; break;
+    case 8: Y = C24 * (xx - yy); Yx = C24 * 2.0f * x; Yy = C24 * -2.0f * y; Yz = 0.0f; break;
+    case 9: Y = C30 * y * (3.0f * xx - yy); Yx = C30 * 6.0f * xy; Yy = C30 * (3.0f * xx - 3.0f * yy); Yz = 0.0f; break;
+    case 10: Y = C31 * xy * z; Yx = C31 * yz; Yy = C31 * xz; Yz = C31 * xy; break;
+    case 11: Y = C32 * y * (4.0f * zz - xx - yy); Yx = C32 * -2.0f * xy; Yy = C32 * (4.0f * zz - xx - 3.0f * yy);
+             Yz = C32 * 8.0f * yz; break;
+    case 12: Y = C33 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); Yx = C33 * -6.0f * xz; Yy = C33 * -6.0f * yz;
+             Yz = C33 * (6.0f * zz - 3.0f * xx - 3.0f * yy); break;
+    case 13: Y = C34 * x * (4.0f * zz - xx - yy); Yx = C34 * (4.0f * zz - 3.0f * xx - yy); Yy = C34 * -2.0f * xy;
+             Yz = C34 * 8.0f * xz; break;
+    case 14: Y = C35 * z * (xx - yy); Yx = C35 * 2.0f * xz; Yy = C35 * -2.0f * yz; Yz = C35 * (xx - yy); break;
+    default: Y = C36 * x * (xx - 3.0f * yy); Yx = C36 * (3.0f * xx - 3.0f * yy); Yy = C36 * -6.0f * xy; Yz = 0.0f; break;
+    }
+}
+
+__global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
+    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
+    MultiViews mv, int flags, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmean3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+    float* __restrict__ dL_drot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool preact = (flags & E3_FLAG_PREACT) != 0;
+    const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
+    const float* sh = pl ? shs + i : shs + (size_t)i * M * 3;
+    float* dsh = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
+    const size_t st = pl ? (size_t)P : (size_t)1;
+    bool vis[E3_MAX_VIEWS];
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        vis[v] = v < mv.n && mv.v[v].radii[i] > 0;
+        any = any || vis[v];
+    }
+    if (!any) {
+        if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
+        dL_dopacity[i] = 0.0f;
+        dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
+        for (int k = 0; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+        dL_dscale[3 * (size_t)i] = 0.0f; dL_dscale[3 * (size_t)i + 1] = 0.0f; dL_dscale[3 * (size_t)i + 2] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = 0.0f;
+        return;
+    }
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float sact[3], qn[4], qinv;
+    act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, preact, sact, qn, qinv);
+    Cov3 cv;
+    build_cov3(sact, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], cv);
+    float gcov[6] = {0, 0, 0, 0, 0, 0}, gmean[3] = {0, 0, 0}, gopac = 0.0f;
+    float dx[E3_MAX_VIEWS], dy[E3_MAX_VIEWS], dz[E3_MAX_VIEWS], ilen[E3_MAX_VIEWS];
+    float gc[E3_MAX_VIEWS][3];
+    float m2x = 0.0f, m2y = 0.0f;
+#pragma unroll
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        dx[v] = dy[v] = dz[v] = ilen[v] = 0.0f;
+        gc[v][0] = gc[v][1] = gc[v][2] = 0.0f;
+        if (vis[v]) {
+            const MultiView& w = mv.v[v];
+            float g12[9], gcv[6], gmv[3];
+            sum_run(w.run[i], w.part, g12);
+            view_geom_backward(w.vp, mx, my, mz, cv.S, g12, gcv, gmv);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gcov[k] += gcv[k];
+            gmean[0] += gmv[0]; gmean[1] += gmv[1]; gmean[2] += gmv[2];
+            gopac += g12[5];
+            if (v == 0) { m2x = g12[0]; m2y = g12[1]; }
+            const uint32_t cl = w.clamped[i];
+            gc[v][0] = (cl & 1u) ? 0.0f : g12[6];
+            gc[v][1] = (cl & 2u) ? 0.0f : g12[7];
+            gc[v][2] = (cl & 4u) ? 0.0f : g12[8];
+            const float ox = mx - w.vp.campos[0], oy = my - w.vp.campos[1], oz = mz - w.vp.campos[2];
+            const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+            dx[v] = ox / len; dy[v] = oy / len; dz[v] = oz / len;
+            ilen[v] = 1.0f / len;
+        }
+    }
+    if (dL_dmean2D) {   // densification statistics use render #1 only (train.py:145)
+        dL_dmean2D[3 * (size_t)i] = m2x; dL_dmean2D[3 * (size_t)i + 1] = m2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
+    }
+    if (preact) { float o = act_sigmoid(opac_in[i]); gopac = gopac * o * (1.0f - o); }
+    dL_dopacity[i] = gopac;
+    // ---- SH coefficients: each written once; direction gradients collected per view
+    float ddx[E3_MAX_VIEWS], ddy[E3_MAX_VIEWS], ddz[E3_MAX_VIEWS];
+#pragma unroll
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) ddx[v] = ddy[v] = ddz[v] = 0.0f;
+    const int nk = (D + 1) * (D + 1);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < nk) {
+            const float c0 = sh[(size_t)(3 * k) * st], c1 = sh[(size_t)(3 * k + 1) * st], c2 = sh[(size_t)(3 * k + 2) * st];
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+            for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+                float Y, Yx, Yy, Yz;
+                sh_basis(k, dx[v], dy[v], dz[v], Y, Yx, Yy, Yz);
+                o0 = FMA(Y, gc[v][0], o0); o1 = FMA(Y, gc[v][1], o1); o2 = FMA(Y, gc[v][2], o2);
+                const float sgn = FMA(c0, gc[v][0], FMA(c1, gc[v][1], c2 * gc[v][2]));
+                ddx[v] = FMA(Yx, sgn, ddx[v]); ddy[v] = FMA(Yy, sgn, ddy[v]); ddz[v] = FMA(Yz, sgn, ddz[v]);
+            }
+            dsh[(size_t)(3 * k) * st] = o0; dsh[(size_t)(3 * k + 1) * st] = o1; dsh[(size_t)(3 * k + 2) * st] = o2;
+        }
+    }
+    for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+#pragma unroll
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        const float dot = dx[v] * ddx[v] + dy[v] * ddy[v] + dz[v] * ddz[v];
+        gmean[0] += (ddx[v] - dx[v] * dot) * ilen[v];
+        gmean[1] += (ddy[v] - dy[v] * dot) * ilen[v];
+        gmean[2] += (ddz[v] - dz[v] * dot) * ilen[v];
+    }
+    dL_dmean3D[3 * (size_t)i] = gmean[0]; dL_dmean3D[3 * (size_t)i + 1] = gmean[1]; dL_dmean3D[3 * (size_t)i + 2] = gmean[2];
+    float ds[3], dq[4];
+    cov3_backward(cv, gcov, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], preact, sact, qinv, ds, dq);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = ds[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = dq[k];
 }
 
 // ------------------------------------------------------------------------------------ host driver
@@ -519,5 +714,40 @@ int e3_backward_impl(int P, int D, int M, int num_rendered, const float* backgro
             dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     }
     KERNEL_OK("geom_bwd_kernel");
+    return 0;
+}
+
+int e3_backward_geom_multi_impl(int nviews, int P, int D, int M, const float* means3D, const float* shs,
+                                const float* opacities, const float* scales, float scale_modifier, const float* rots,
+                                const int* widths, const int* heights, const float* const* view,
+                                const float* const* proj, const float* const* campos, const float* tanfovx,
+                                const float* tanfovy, const int* const* radii, const char* const* geom_buffer,
+                                const float* const* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
+                                float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s) {
+    if (P <= 0) return 0;
+    MultiViews mv;
+    mv.n = nviews;
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        const int u = v < nviews ? v : 0;      // unused slots mirror view 0 (never dereferenced: v >= n)
+        MultiView& w = mv.v[v];
+        w.vp.view = view[u]; w.vp.proj = proj[u]; w.vp.campos = campos[u];
+        w.vp.tanfovx = tanfovx[u]; w.vp.tanfovy = tanfovy[u];
+        w.vp.focal_x = (float)widths[u] / (2.0f * tanfovx[u]);
+        w.vp.focal_y = (float)heights[u] / (2.0f * tanfovy[u]);
+        w.vp.scale_modifier = scale_modifier;
+        w.vp.W = widths[u]; w.vp.H = heights[u];
+        w.vp.gx = (widths[u] + E3_TILE - 1) / E3_TILE;
+        w.vp.gy = (heights[u] + E3_TILE - 1) / E3_TILE;
+        char* gp = const_cast<char*>(geom_buffer[u]);
+        GeomState geom = GeomState::from(gp, P);
+        w.radii = radii[u]; w.clamped = geom.clamped; w.run = geom.run; w.part = grad_acc[u];
+    }
+    {
+    ProfScope ps(PS_GEOM_BWD, s);
+    geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+        P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
+        dL_dscale, dL_drot);
+    }
+    KERNEL_OK("geom_bwd_multi_kernel");
     return 0;
 }

@@ -49,6 +49,11 @@ int e3_forward_begin_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size
                           hipStream_t);
 int e3_forward_finish_impl(char* (*)(void*, size_t), void*, int, int, int, const float*, char*, char*, int, float*, int,
                            hipStream_t);
+int e3_backward_geom_multi_impl(int, int, int, int, const float*, const float*, const float*, const float*, float,
+                                const float*, const int*, const int*, const float* const*, const float* const*,
+                                const float* const*, const float*, const float*, const int* const*, const char* const*,
+                                const float* const*, float*, float*, float*, float*, float*, float*, int, int,
+                                hipStream_t);
 int e3_backward_impl(int, int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
                      const float*, float, const float*, const float*, const float*, const float*, const float*, float,
                      float, const int*, const char*, const char*, const char*, const float*, float*, float*, float*,
@@ -152,10 +157,13 @@ int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float*
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                              float* dL_drot, int debug, int flags, void* stream) {
     g_err[0] = 0;
-    if (P > 0 && (!grad_acc || !dL_dmean3D)) return e3_fail(hipErrorInvalidValue, "grad_acc and dL_dmean3D are required");
-    if (shs && !dL_dsh) return e3_fail(hipErrorInvalidValue, "dL_dsh required when shs is given");
-    if (!cov3D_precomp && (!dL_dscale || !dL_drot))
-        return e3_fail(hipErrorInvalidValue, "dL_dscale/dL_drot required when scales+rotations are given");
+    if (P > 0 && !grad_acc) return e3_fail(hipErrorInvalidValue, "grad_acc is required");
+    if (!(flags & E3_FLAG_BWD_ONLY_RENDER)) {       // the per-Gaussian stage writes these
+        if (P > 0 && !dL_dmean3D) return e3_fail(hipErrorInvalidValue, "dL_dmean3D is required");
+        if (shs && !dL_dsh) return e3_fail(hipErrorInvalidValue, "dL_dsh required when shs is given");
+        if (!cov3D_precomp && (!dL_dscale || !dL_drot))
+            return e3_fail(hipErrorInvalidValue, "dL_dscale/dL_drot required when scales+rotations are given");
+    }
     if ((flags & E3_FLAG_PREACT) && (cov3D_precomp || !opacities))
         return e3_fail(hipErrorInvalidValue, "PREACT needs scales+rotations and opacities");
     return e3_backward_impl(P, D, M, num_rendered, background, width, height, means3D, shs, colors_precomp, opacities,
@@ -163,6 +171,33 @@ int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float*
                             tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D,
                             dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, flags,
                             (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_backward_geom_multi(int nviews, int P, int D, int M, const float* means3D, const float* shs,
+                                        const float* opacities, const float* scales, float scale_modifier,
+                                        const float* rotations, const int* widths, const int* heights,
+                                        const float* const* viewmatrix, const float* const* projmatrix,
+                                        const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy,
+                                        const int* const* radii, const char* const* geom_buffer,
+                                        const float* const* grad_acc, float* dL_dmean2D, float* dL_dopacity,
+                                        float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                                        int flags, void* stream) {
+    g_err[0] = 0;
+    if (nviews < 1 || nviews > E3_MAX_VIEWS) return e3_fail(hipErrorInvalidValue, "nviews must be 1..4");
+    if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "bad P/D/M");
+    if (!means3D || !shs || !scales || !rotations || !dL_dopacity || !dL_dmean3D || !dL_dsh || !dL_dscale || !dL_drot)
+        return e3_fail(hipErrorInvalidValue, "geom_multi needs shs + scales + rotations and all gradient outputs");
+    if ((flags & E3_FLAG_PREACT) && !opacities) return e3_fail(hipErrorInvalidValue, "PREACT needs opacities");
+    if (!widths || !heights || !viewmatrix || !projmatrix || !cam_pos || !tan_fovx || !tan_fovy || !radii ||
+        !geom_buffer || !grad_acc)
+        return e3_fail(hipErrorInvalidValue, "per-view arrays are required");
+    for (int v = 0; v < nviews; ++v)
+        if (!viewmatrix[v] || !projmatrix[v] || !cam_pos[v] || !radii[v] || !geom_buffer[v] || !grad_acc[v])
+            return e3_fail(hipErrorInvalidValue, "null per-view pointer");
+    return e3_backward_geom_multi_impl(nviews, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations,
+                                       widths, heights, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+                                       geom_buffer, grad_acc, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale,
+                                       dL_drot, debug, flags, (hipStream_t)stream);
 }
 
 size_t e3dgs_state_offset_emit_gid(int num_rendered) {

@@ -249,8 +249,8 @@ def backward_raw(raw, grad_out_color, out, flags=None, grad_acc=None):
     if g.dtype != torch.float32:
         g = g.float()
     g = g.contiguous()
-    if grad_acc is None:      # one zero-filled record per (tile, Gaussian) instance
-        grad_acc = torch.zeros(max(int(raw["num_rendered"]), 1), _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
+    if grad_acc is None:      # one record per (tile, Gaussian) instance; the kernel writes every one of them
+        grad_acc = torch.empty(max(int(raw["num_rendered"]), 1), _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = L.e3dgs_rasterize_backward(
             P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(bg), W, H, _lib.ptr(means3D), _lib.ptr(sh),
@@ -262,6 +262,39 @@ def backward_raw(raw, grad_out_color, out, flags=None, grad_acc=None):
             _lib.ptr(out.get("cov3D")), _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")), _lib.ptr(out.get("rots")),
             int(bool(rs.debug)), int(flags), _lib.current_stream())
     _lib.check(rc, "e3dgs_rasterize_backward")
+
+
+def backward_geom_multi(raws, grad_accs, out, flags):
+    """e3dgs_rasterize_backward_geom_multi: the per-Gaussian backward of all `raws` (forward results of the SAME
+    parameters under different cameras, each already through backward_raw(..., FLAG_BWD_ONLY_RENDER)) in one
+    pass.  `out` maps means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are
+    fully overwritten with the gradient summed over the views."""
+    import ctypes as C
+    L = _lib.lib()
+    n = len(raws)
+    r0 = raws[0]
+    means3D, sh, colors, scales, rots, cov = r0["inputs"]
+    if colors is not None or cov is not None:
+        raise ValueError("backward_geom_multi needs shs + scales + rotations")
+    P = means3D.shape[0]
+    if P == 0:
+        return
+    vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    Ws = (C.c_int * n)(*[int(r["settings"].image_width) for r in raws])
+    Hs = (C.c_int * n)(*[int(r["settings"].image_height) for r in raws])
+    tx = (C.c_float * n)(*[float(r["settings"].tanfovx) for r in raws])
+    ty = (C.c_float * n)(*[float(r["settings"].tanfovy) for r in raws])
+    rs = r0["settings"]
+    with torch.cuda.device(means3D.device):
+        rc = L.e3dgs_rasterize_backward_geom_multi(
+            n, P, int(rs.sh_degree), r0["M"], _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(r0.get("opacities")),
+            _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots), Ws, Hs,
+            vp([r["consts"][1] for r in raws]), vp([r["consts"][2] for r in raws]), vp([r["consts"][3] for r in raws]),
+            tx, ty, vp([r["radii"] for r in raws]), vp([r["geom"] for r in raws]), vp(grad_accs),
+            _lib.ptr(out.get("means2D")), _lib.ptr(out.get("opacities")), _lib.ptr(out.get("means3D")),
+            _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")), _lib.ptr(out.get("rots")),
+            int(bool(rs.debug)), int(flags), _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_backward_geom_multi")
 
 
 class GaussianRasterizer(nn.Module):

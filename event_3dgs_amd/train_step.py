@@ -194,7 +194,6 @@ class EventTrainer:
         S = self._streams
         v = self.views
         cams = (cam_int, cam_now, cam_next)
-        self.flat_grad.zero_()
         ev0 = main.record_event()
         # ---- forward, first half (preprocess, depth sort, tile counting) on the three streams
         pend = []
@@ -211,8 +210,8 @@ class EventTrainer:
         for k in range(3):
             with torch.cuda.stream(S[k]):
                 raws.append(rasterizer.forward_finish(pend[k]))
-                # per-instance gradient records of this view's backward (zero: instances the walk never reaches)
-                accs.append(torch.zeros(max(raws[k]["num_rendered"], 1), _lib.ACC_STRIDE, dtype=torch.float32,
+                # per-instance gradient records of this view's backward (written in full by the kernel)
+                accs.append(torch.empty(max(raws[k]["num_rendered"], 1), _lib.ACC_STRIDE, dtype=torch.float32,
                                         device=self.device))
                 main.wait_event(S[k].record_event())
         if self._loss_bufs is None:
@@ -228,20 +227,18 @@ class EventTrainer:
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         dpix = (d_image, d_now, d_next)
-        # ---- loss.backward() (train.py:211): compositing backward of the three views overlaps ...
+        # ---- loss.backward() (train.py:211): the compositing backward of the three views overlaps ...
         for k in range(3):
             with torch.cuda.stream(S[k]):
                 S[k].wait_event(ev_loss)
                 rasterizer.backward_raw(raws[k], dpix[k], out, grad_acc=accs[k],
-                                        flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE | _lib.FLAG_BWD_ONLY_RENDER)
+                                        flags=self.FWD_FLAGS | _lib.FLAG_BWD_ONLY_RENDER)
                 main.wait_event(S[k].record_event())
-        # ---- ... and the accumulating per-Gaussian stage runs in order on the main stream
-        for k in range(3):
-            o = dict(out)
-            if k == 0 and self.track_stats:
-                o["means2D"] = self.viewspace_grad          # densification statistics use render #1 only (train.py:145)
-            rasterizer.backward_raw(raws[k], dpix[k], o, grad_acc=accs[k],
-                                    flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE | _lib.FLAG_BWD_ONLY_GEOM)
+        # ---- ... and ONE per-Gaussian pass sums the three views and writes every gradient element once
+        o = dict(out)
+        if self.track_stats:
+            o["means2D"] = self.viewspace_grad              # densification statistics use render #1 only (train.py:145)
+        rasterizer.backward_geom_multi(raws, accs, o, self.FWD_FLAGS)
         self.c_grad.copy_(scalars[1:2])
         if self.world > 1 and sync_grads:
             parallel.allreduce_mean_(self.flat_grad, self.pg)      # ONE collective: 59 floats/Gaussian + c

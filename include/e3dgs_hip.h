@@ -127,10 +127,11 @@ int e3dgs_rasterize_forward_finish(
  * diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
  * loss.backward() at train.py:211 through _RasterizeGaussians.backward.
  *
- * grad_acc (num_rendered,12) must be ZERO-FILLED by the caller: the compositing backward stores one record per
- * (tile, Gaussian) instance (dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad) at the instance's emission
- * position -- plain stores, no float atomics -- and the per-Gaussian stage sums each Gaussian's contiguous run
- * in a fixed order, so gradients are bit-reproducible run to run (the reference's atomics are not).
+ * grad_acc (num_rendered,12) is caller-owned scratch and needs NO initialisation: the compositing backward
+ * stores one record per (tile, Gaussian) instance (dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad) at the
+ * instance's emission position -- every record exactly once, plain stores, no float atomics -- and the
+ * per-Gaussian stage sums each Gaussian's contiguous run in a fixed order, so gradients are bit-reproducible
+ * run to run (the reference's atomics are not).
  * Without E3DGS_FLAG_ACCUMULATE every other output is written in full (zeros for culled
  * Gaussians), so nothing else needs pre-zeroing.  dL_dmean2D is (P,3): first two components in
  * NDC units (consumed by scene/gaussian_model.py:405-407), third 0; always overwritten.
@@ -148,7 +149,7 @@ int e3dgs_rasterize_backward(
     const int* radii,
     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
     const float* dL_dpix,             /* (3,H,W) */
-    float* grad_acc,                  /* (num_rendered,12) zero-filled scratch */
+    float* grad_acc,                  /* (num_rendered,12) scratch (uninitialised is fine) */
     float* dL_dmean2D,                /* (P,3) or NULL */
     float* dL_dopacity,               /* (P) or NULL */
     float* dL_dcolor,                 /* (P,3) or NULL */
@@ -160,6 +161,31 @@ int e3dgs_rasterize_backward(
     int debug,
     int flags,
     void* stream);
+
+/*
+ * Per-Gaussian backward of SEVERAL views in one pass (1 <= nviews <= 4).
+ * Replaces: the three _RasterizeGaussians.backward calls plus autograd's gradient accumulation that
+ * loss.backward() (train.py:211) performs for the three renders of an event iteration
+ * (train.py:144,159,161).  Call e3dgs_rasterize_backward with E3DGS_FLAG_BWD_ONLY_RENDER once per view
+ * (any streams), then this entry point once: parameters are read once, every gradient element is written
+ * exactly once (sum over the views; zeros where no view saw the Gaussian) -- no pre-zeroing, no
+ * E3DGS_FLAG_ACCUMULATE read-modify-write, no serialisation of the views.
+ * Needs shs + scales + rotations (no colors_precomp / cov3D_precomp).  Flags: PREACT, SH_PLANAR.
+ * All `const T* const*` / per-view scalar arguments are HOST arrays of length nviews whose elements are the
+ * per-view values e3dgs_rasterize_backward takes.  dL_dmean2D (P,3), optional, receives view 0's
+ * screen-space gradient only (densification statistics use render #1, train.py:145).
+ */
+int e3dgs_rasterize_backward_geom_multi(
+    int nviews, int P, int D, int M,
+    const float* means3D, const float* shs, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations,
+    const int* widths, const int* heights,
+    const float* const* viewmatrix, const float* const* projmatrix, const float* const* cam_pos,
+    const float* tan_fovx, const float* tan_fovy,
+    const int* const* radii, const char* const* geom_buffer, const float* const* grad_acc,
+    float* dL_dmean2D,                /* (P,3) or NULL */
+    float* dL_dopacity, float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    int debug, int flags, void* stream);
 
 /*
  * Exact tile culling (default ON; environment E3DGS_TILE_CULL=0 turns it off at load time).

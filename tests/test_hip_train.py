@@ -260,3 +260,50 @@ def test_fit_loop_with_densification_and_eval(tmp_path):
     tr2 = EventTrainer(back, DEV, active_sh_degree=tr.active_sh_degree)
     a, b = tr.render_raw(train[3], bg)["color"], tr2.render_raw(train[3], bg)["color"]
     assert torch.equal(a, b)                                   # the PLY holds the exact pre-activation state
+
+
+@pytest.mark.parametrize("nviews", [1, 2, 4])
+def test_geom_multi_equals_sum_of_single_view_backwards(nviews):
+    """e3dgs_rasterize_backward_geom_multi == sum over views of e3dgs_rasterize_backward (what autograd's
+    accumulation of the per-render backward calls produces at train.py:211).  Views differ in resolution; the
+    gradient buffers start as NaN to prove every element is written."""
+    from event_3dgs_amd import _lib, rasterizer
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, _ = _scene(N=4000)
+    sizes = [(176, 128), (97, 61), (176, 128), (240, 135)][:nviews]
+    cams = [orbit_camera(k, 16, w, h, device=DEV, daz=0.01 * k) for k, (w, h) in enumerate(sizes)]
+    bg = torch.tensor([0.2, 0.1, 0.3], device=DEV)
+    tr = EventTrainer(params, DEV)
+    v = tr.views
+    gen = torch.Generator().manual_seed(5)
+    raws, dpix = [], []
+    for cam in cams:
+        raws.append(tr.render_raw(cam, bg))
+        dpix.append(torch.randn(raws[-1]["color"].shape, generator=gen).to(DEV))
+    names = dict(means3D=v["xyz"], sh=v["features"], opacities=v["opacity"], scales=v["scaling"], rots=v["rotation"])
+    ref = {k: torch.zeros_like(t) for k, t in names.items()}
+    m2d_ref = None
+    for k, raw in enumerate(raws):
+        single = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
+        single["means2D"] = torch.full((tr.N, 3), float("nan"), device=DEV)
+        rasterizer.backward_raw(raw, dpix[k], single, flags=tr.FWD_FLAGS)
+        for n in names:
+            ref[n] += single[n]
+        if k == 0:
+            m2d_ref = single["means2D"]
+    accs = []
+    for k, raw in enumerate(raws):
+        accs.append(torch.full((max(raw["num_rendered"], 1), _lib.ACC_STRIDE), float("nan"), device=DEV))
+        rasterizer.backward_raw(raw, dpix[k], {}, grad_acc=accs[k], flags=tr.FWD_FLAGS | _lib.FLAG_BWD_ONLY_RENDER)
+    out = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
+    out["means2D"] = torch.full((tr.N, 3), float("nan"), device=DEV)
+    rasterizer.backward_geom_multi(raws, accs, out, tr.FWD_FLAGS)
+    torch.cuda.synchronize()
+    assert torch.equal(out["means2D"], m2d_ref)
+    for n in names:
+        assert torch.isfinite(out[n]).all(), n
+        err = rel_l2(out[n].cpu(), ref[n].cpu())
+        assert err < 2e-6, (n, err)                                                # fp32 re-association only
+        scale = ref[n].abs().max().item()
+        assert (out[n] - ref[n]).abs().max().item() <= 1e-4 * scale + 1e-12, n
