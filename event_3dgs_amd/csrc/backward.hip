@@ -555,21 +555,23 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     MultiViews mv, int flags, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // per-view (unit direction, 1/len, masked colour gradient) of this thread's Gaussian.  The view loop of the
+    // geometry part is NOT unrolled (one copy of a ~90-register body); its per-view results go through this
+    // LDS slice so that the SH part can hold them in statically indexed registers.
+    __shared__ float sV[7][E3_MAX_VIEWS][256];
+    const int tid = threadIdx.x;
+    int i = blockIdx.x * blockDim.x + tid;
     if (i >= P) return;
     const bool preact = (flags & E3_FLAG_PREACT) != 0;
     const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
     const float* sh = pl ? shs + i : shs + (size_t)i * M * 3;
     float* dsh = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
     const size_t st = pl ? (size_t)P : (size_t)1;
-    bool vis[E3_MAX_VIEWS];
-    bool any = false;
+    uint32_t vis = 0;
 #pragma unroll
-    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-        vis[v] = v < mv.n && mv.v[v].radii[i] > 0;
-        any = any || vis[v];
-    }
-    if (!any) {
+    for (int v = 0; v < E3_MAX_VIEWS; ++v)
+        if (v < mv.n && mv.v[v].radii[i] > 0) vis |= 1u << v;
+    if (!vis) {
         if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
         dL_dopacity[i] = 0.0f;
         dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
@@ -585,14 +587,11 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     Cov3 cv;
     build_cov3(sact, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], cv);
     float gcov[6] = {0, 0, 0, 0, 0, 0}, gmean[3] = {0, 0, 0}, gopac = 0.0f;
-    float dx[E3_MAX_VIEWS], dy[E3_MAX_VIEWS], dz[E3_MAX_VIEWS], ilen[E3_MAX_VIEWS];
-    float gc[E3_MAX_VIEWS][3];
     float m2x = 0.0f, m2y = 0.0f;
-#pragma unroll
-    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-        dx[v] = dy[v] = dz[v] = ilen[v] = 0.0f;
-        gc[v][0] = gc[v][1] = gc[v][2] = 0.0f;
-        if (vis[v]) {
+#pragma unroll 1
+    for (int v = 0; v < mv.n; ++v) {
+        float o_dx = 0.0f, o_dy = 0.0f, o_dz = 0.0f, o_il = 0.0f, o_g0 = 0.0f, o_g1 = 0.0f, o_g2 = 0.0f;
+        if ((vis >> v) & 1u) {
             const MultiView& w = mv.v[v];
             float g12[9], gcv[6], gmv[3];
             sum_run(w.run[i], w.part, g12);
@@ -603,24 +602,42 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             gopac += g12[5];
             if (v == 0) { m2x = g12[0]; m2y = g12[1]; }
             const uint32_t cl = w.clamped[i];
-            gc[v][0] = (cl & 1u) ? 0.0f : g12[6];
-            gc[v][1] = (cl & 2u) ? 0.0f : g12[7];
-            gc[v][2] = (cl & 4u) ? 0.0f : g12[8];
+            o_g0 = (cl & 1u) ? 0.0f : g12[6];
+            o_g1 = (cl & 2u) ? 0.0f : g12[7];
+            o_g2 = (cl & 4u) ? 0.0f : g12[8];
             const float ox = mx - w.vp.campos[0], oy = my - w.vp.campos[1], oz = mz - w.vp.campos[2];
             const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
-            dx[v] = ox / len; dy[v] = oy / len; dz[v] = oz / len;
-            ilen[v] = 1.0f / len;
+            o_dx = ox / len; o_dy = oy / len; o_dz = oz / len;
+            o_il = 1.0f / len;
         }
+        sV[0][v][tid] = o_dx; sV[1][v][tid] = o_dy; sV[2][v][tid] = o_dz; sV[3][v][tid] = o_il;
+        sV[4][v][tid] = o_g0; sV[5][v][tid] = o_g1; sV[6][v][tid] = o_g2;
     }
     if (dL_dmean2D) {   // densification statistics use render #1 only (train.py:145)
         dL_dmean2D[3 * (size_t)i] = m2x; dL_dmean2D[3 * (size_t)i + 1] = m2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
     }
     if (preact) { float o = act_sigmoid(opac_in[i]); gopac = gopac * o * (1.0f - o); }
     dL_dopacity[i] = gopac;
+    {
+        float ds[3], dq[4];
+        cov3_backward(cv, gcov, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], preact, sact, qinv, ds, dq);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = ds[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = dq[k];
+    }
     // ---- SH coefficients: each written once; direction gradients collected per view
+    float dx[E3_MAX_VIEWS], dy[E3_MAX_VIEWS], dz[E3_MAX_VIEWS], gc[E3_MAX_VIEWS][3];
     float ddx[E3_MAX_VIEWS], ddy[E3_MAX_VIEWS], ddz[E3_MAX_VIEWS];
 #pragma unroll
-    for (int v = 0; v < E3_MAX_VIEWS; ++v) ddx[v] = ddy[v] = ddz[v] = 0.0f;
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        ddx[v] = ddy[v] = ddz[v] = 0.0f;
+        dx[v] = dy[v] = dz[v] = gc[v][0] = gc[v][1] = gc[v][2] = 0.0f;
+        if (v < mv.n) {
+            dx[v] = sV[0][v][tid]; dy[v] = sV[1][v][tid]; dz[v] = sV[2][v][tid];
+            gc[v][0] = sV[4][v][tid]; gc[v][1] = sV[5][v][tid]; gc[v][2] = sV[6][v][tid];
+        }
+    }
     const int nk = (D + 1) * (D + 1);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -629,11 +646,13 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
             for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-                float Y, Yx, Yy, Yz;
-                sh_basis(k, dx[v], dy[v], dz[v], Y, Yx, Yy, Yz);
-                o0 = FMA(Y, gc[v][0], o0); o1 = FMA(Y, gc[v][1], o1); o2 = FMA(Y, gc[v][2], o2);
-                const float sgn = FMA(c0, gc[v][0], FMA(c1, gc[v][1], c2 * gc[v][2]));
-                ddx[v] = FMA(Yx, sgn, ddx[v]); ddy[v] = FMA(Yy, sgn, ddy[v]); ddz[v] = FMA(Yz, sgn, ddz[v]);
+                if (v < mv.n) {
+                    float Y, Yx, Yy, Yz;
+                    sh_basis(k, dx[v], dy[v], dz[v], Y, Yx, Yy, Yz);
+                    o0 = FMA(Y, gc[v][0], o0); o1 = FMA(Y, gc[v][1], o1); o2 = FMA(Y, gc[v][2], o2);
+                    const float sgn = FMA(c0, gc[v][0], FMA(c1, gc[v][1], c2 * gc[v][2]));
+                    ddx[v] = FMA(Yx, sgn, ddx[v]); ddy[v] = FMA(Yy, sgn, ddy[v]); ddz[v] = FMA(Yz, sgn, ddz[v]);
+                }
             }
             dsh[(size_t)(3 * k) * st] = o0; dsh[(size_t)(3 * k + 1) * st] = o1; dsh[(size_t)(3 * k + 2) * st] = o2;
         }
@@ -641,18 +660,15 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
 #pragma unroll
     for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-        const float dot = dx[v] * ddx[v] + dy[v] * ddy[v] + dz[v] * ddz[v];
-        gmean[0] += (ddx[v] - dx[v] * dot) * ilen[v];
-        gmean[1] += (ddy[v] - dy[v] * dot) * ilen[v];
-        gmean[2] += (ddz[v] - dz[v] * dot) * ilen[v];
+        if (v < mv.n) {
+            const float il = sV[3][v][tid];
+            const float dot = dx[v] * ddx[v] + dy[v] * ddy[v] + dz[v] * ddz[v];
+            gmean[0] += (ddx[v] - dx[v] * dot) * il;
+            gmean[1] += (ddy[v] - dy[v] * dot) * il;
+            gmean[2] += (ddz[v] - dz[v] * dot) * il;
+        }
     }
     dL_dmean3D[3 * (size_t)i] = gmean[0]; dL_dmean3D[3 * (size_t)i + 1] = gmean[1]; dL_dmean3D[3 * (size_t)i + 2] = gmean[2];
-    float ds[3], dq[4];
-    cov3_backward(cv, gcov, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], preact, sact, qinv, ds, dq);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = ds[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = dq[k];
 }
 
 // ------------------------------------------------------------------------------------ host driver

@@ -227,9 +227,12 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
                                                               const uint32_t* __restrict__ wave_offsets,
                                                               uint32_t* __restrict__ wave_counts,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                              uint32_t* __restrict__ emit_gid, uint2* __restrict__ run) {
+                                                              uint32_t* __restrict__ emit_gid, uint2* __restrict__ run,
+                                                              uint32_t* __restrict__ cnt_out,
+                                                              const uint32_t* __restrict__ slot_start) {
     __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
-    __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per Gaussian of the wave (EMIT only)
+    __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per Gaussian of the wave
+    __shared__ uint32_t sSlot[BIN_WAVES][WAVE]; // first slot of each Gaussian of the wave (EMIT only)
     __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
     __shared__ uint32_t sIncl[BIN_WAVES][WAVE];
     __shared__ uint32_t sId[BIN_WAVES][WAVE];
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
     }
     const uint32_t total = __shfl(incl, 63, 64);
     sA[wave][lane] = a; sB[wave][lane] = b; sIncl[wave][lane] = incl; sId[wave][lane] = g;
-    if (EMIT) sCnt[wave][lane] = 0;
+    sCnt[wave][lane] = 0;
+    if (EMIT) sSlot[wave][lane] = (s < P) ? slot_start[g] : 0u;
     wave_sync();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t count = 0;
@@ -288,27 +292,27 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
         const int tx = (int)((xy0 & 0xFFFFu) + (k - row * w)), ty = (int)((xy0 >> 16) + row);
         const bool keep = active && (!cull || tile_touched(A4.x, A4.y, A4.z, A4.w, B4.x, B4.y, tx, ty));
         const uint64_t mask = __ballot(keep);
-        if (EMIT && keep) {
-            const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
-            keys[pos] = (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
-            vals[pos] = pos;                       // the sort carries the EMISSION index (see finalize_lists_kernel)
-            emit_gid[pos] = sId[wave][j];
-            atomicAdd(&sCnt[wave][j], 1u);
+        if (keep) {
+            // ordinal of this instance among its Gaussian's kept ones (any order will do: it only names a slot)
+            const uint32_t k_in = atomicAdd(&sCnt[wave][j], 1u);
+            if (EMIT) {
+                // emission position = depth order (what the stable tile sort preserves); the payload is the
+                // instance's SLOT, Gaussian-major in index order, where backward parks its gradient record
+                const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
+                const uint32_t slot = sSlot[wave][j] + k_in;
+                keys[pos] = (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+                vals[pos] = slot;
+                emit_gid[slot] = sId[wave][j];
+            }
         }
         count += (uint32_t)__popcll(mask);
     }
-    if (!EMIT && lane == 0) wave_counts[gw] = count;
-    if (EMIT) {
-        // kept instances are emitted Gaussian-major, so Gaussian j of the wave owns one contiguous run
-        wave_sync();
-        const uint32_t c = sCnt[wave][lane];
-        uint32_t inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (s < P) run[g] = make_uint2(out_base + inc - c, c);
+    wave_sync();
+    if (!EMIT) {
+        if (lane == 0) wave_counts[gw] = count;
+        if (s < P) cnt_out[g] = sCnt[wave][lane];
+    } else if (s < P) {
+        run[g] = make_uint2(sSlot[wave][lane], sCnt[wave][lane]);
     }
 }
 
@@ -593,9 +597,11 @@ int e3_forward_begin_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, c
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.rec, vp.gx,
                                                                      g_tile_cull, nullptr, geom.tiles, nullptr, nullptr,
-                                                                     nullptr, nullptr);
+                                                                     nullptr, nullptr, geom.cnt, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
+        // slots: exclusive scan of the per-Gaussian kept counts in INDEX order
+        launch_exclusive_scan_u32(geom.cnt, geom.slot, (size_t)P, geom.scratch, false, s);
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back
@@ -629,7 +635,7 @@ int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, in
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, geom.ord0, geom.rect, geom.rec, gx,
                                                                     g_tile_cull, geom.offsets, nullptr, k0, v0, bin.emit_gid,
-                                                                    geom.run);
+                                                                    geom.run, nullptr, geom.slot);
         }
         KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
