@@ -32,7 +32,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def algorithmic_bytes(slot, N, I, T, npx):
-    """SURVEY 8(d) per-render algorithmic bytes of each profiled stage."""
+    """SURVEY 8(d) algorithmic bytes of each profiled stage; a launch covers all views of the iteration, so the
+    caller passes N = Gaussians x views (splats), I = instances of all views, T / npx = tiles / pixels of all views."""
     tile_bits = max(1, math.ceil(math.log2(max(T, 2))))
     return {
         "preprocess": 132 * N,
@@ -132,27 +133,11 @@ def main():
     L.e3dgs_profile_enable(0)
     loss_val = float(loss[0].item())
 
-    # The timed region runs the three views on three HIP streams, so the event-bracketed durations above are
-    # spans of OVERLAPPING launches.  For an isolated per-launch duration the same steps are repeated with the
-    # views serialised on one stream (outside the timed region; parameters keep training, same workload).
-    iso = {}
-    trainer.multi_stream, trainer._streams = False, None
-    for _ in range(2):
-        one_step()
-    torch.cuda.synchronize()
-    L.e3dgs_profile_enable(1)
-    for _ in range(max(3, args.steps // 4)):
-        one_step()
-    torch.cuda.synchronize()
-    for slot in range(8):
-        ms, n = C.c_double(0), C.c_int(0)
-        L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
-        iso[L.e3dgs_profile_slot_name(slot).decode()] = (ms.value, n.value)
-    L.e3dgs_profile_enable(0)
-
-    # workload statistics of the intensity view
+    # workload statistics: one launch of every stage covers the three views of the iteration
+    V = 3
     vis = int((trainer.last_radii > 0).sum())
-    I = trainer.render_raw(cam_int, bg)["num_rendered"]
+    I1 = trainer.render_raw(cam_int, bg)["num_rendered"]
+    I = sum(trainer.render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
     T = ((W + 15) // 16) * ((H + 15) // 16)
     npx = W * H
 
@@ -160,14 +145,10 @@ def main():
     for name, (ms, n) in kern.items():
         if n:
             avg = ms / n
-            b = algorithmic_bytes(name, N, I, T, npx)
-            ims, inn = iso.get(name, (0.0, 0))
-            iavg = ims / inn if inn else None
-            stages[name] = {"avg_ms": round(avg, 4), "launch_groups": n, "alg_GB": round(b / 1e9, 4),
-                            "alg_GBps": round(b / 1e9 / (avg / 1e3), 1),
-                            "isolated_avg_ms": round(iavg, 4) if iavg else None,
-                            "isolated_alg_GBps": round(b / 1e9 / (iavg / 1e3), 1) if iavg else None}
-    dominant = max(stages, key=lambda k: stages[k]["avg_ms"] * stages[k]["launch_groups"]) if stages else None
+            b = algorithmic_bytes(name, N * V, I, T * V, npx * V)
+            stages[name] = {"avg_ms": round(avg, 4), "launches": n, "alg_GB": round(b / 1e9, 4),
+                            "alg_GBps": round(b / 1e9 / (avg / 1e3), 1)}
+    dominant = max(stages, key=lambda k: stages[k]["avg_ms"] * stages[k]["launches"]) if stages else None
     roofline = None
     if dominant:
         s = stages[dominant]
@@ -181,12 +162,10 @@ def main():
         roofline = {"kernel": dominant + "_kernel", "bound": "hbm", "achieved": s["alg_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(s["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": s["avg_ms"], "alg_bytes_per_launch": int(s["alg_GB"] * 1e9),
-                    "concurrent_launches": 3, "isolated_avg_launch_ms": s["isolated_avg_ms"],
-                    "isolated_achieved": s["isolated_alg_GBps"],
-                    "note": "avg_launch_ms is the HIP-event span of one launch while the launches of the 3 views overlap on "
-                            "3 streams; isolated_* = same launch serialised. Compositing is VALU/DPP-bound, not HBM-bound "
-                            "(SURVEY 8d): alpha evaluations/s (isolated) = "
-                            + f"{256.0 * I / ((s['isolated_avg_ms'] or s['avg_ms']) / 1e3) / 1e9:.1f} G/s"}
+                    "views_per_launch": V,
+                    "note": "one launch composites the 3 views of the iteration (HIP events on the launch stream, timed "
+                            "region). Compositing is VALU-bound, not HBM-bound (SURVEY 8d, DESIGN.md): alpha evaluations/s = "
+                            + f"{256.0 * I / (s['avg_ms'] / 1e3) / 1e9:.1f} G/s"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -200,7 +179,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "gaussians": N, "width": W, "height": H, "visible": vis,
-                       "tile_instances": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
+                       "tile_instances": I1, "tile_instances_3views": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
                        "parallelism": f"view-dp{world}", "grad_allreduce_bytes": 4 * FLOATS_PER_GAUSSIAN * N if world > 1 else 0,
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "cpu_baseline": cpu_baseline,

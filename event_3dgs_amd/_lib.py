@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _fp, _ip, _vp, _cp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
@@ -50,10 +50,22 @@ def lib():
     L.e3dgs_rasterize_backward.argtypes = (
         [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
         + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, C.c_int, _vp])
-    L.e3dgs_rasterize_backward_geom_multi.restype = C.c_int
-    L.e3dgs_rasterize_backward_geom_multi.argtypes = (
-        [C.c_int] * 4 + [_fp] * 4 + [C.c_float, _fp] + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_void_p)] * 3
-        + [C.POINTER(C.c_float)] * 2 + [C.POINTER(C.c_void_p)] * 3 + [_fp] * 6 + [C.c_int, C.c_int, _vp])
+    _pp, _hf = C.POINTER(C.c_void_p), C.POINTER(C.c_float)      # host arrays: per-view device pointers / floats
+    L.e3dgs_rasterize_forward_multi.restype = C.c_int
+    L.e3dgs_rasterize_forward_multi.argtypes = (
+        [ALLOC_FN, _vp] * 3 + [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 2
+        + [_pp] * 3 + [_hf] * 2 + [_fp, _ip, C.c_int, C.c_int, C.POINTER(C.c_int), _vp])
+    L.e3dgs_rasterize_forward_multi_begin.restype = C.c_int
+    L.e3dgs_rasterize_forward_multi_begin.argtypes = (
+        [ALLOC_FN, _vp] * 2 + [C.c_int] * 6 + [_fp] * 5 + [C.c_float] + [_fp] * 2 + [_pp] * 3 + [_hf] * 2
+        + [_ip, C.c_int, C.c_int, _vp, _vp])
+    L.e3dgs_rasterize_forward_multi_finish.restype = C.c_int
+    L.e3dgs_rasterize_forward_multi_finish.argtypes = [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp,
+                                                       C.c_int, _fp, C.c_int, _vp]
+    L.e3dgs_rasterize_backward_multi.restype = C.c_int
+    L.e3dgs_rasterize_backward_multi.argtypes = (
+        [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
+        + [_ip] + [_cp] * 3 + [_fp] * 8 + [C.c_int, C.c_int, _vp])
     L.e3dgs_set_tile_cull.restype = None
     L.e3dgs_set_tile_cull.argtypes = [C.c_int]
     L.e3dgs_get_tile_cull.restype = C.c_int
@@ -112,7 +124,8 @@ ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
-    "e3dgs_rasterize_backward", "e3dgs_rasterize_backward_geom_multi",
+    "e3dgs_rasterize_backward", "e3dgs_rasterize_forward_multi", "e3dgs_rasterize_forward_multi_begin",
+    "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_backward_multi",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

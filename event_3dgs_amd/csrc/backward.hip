@@ -16,10 +16,11 @@ extern unsigned long long* g_trace;
 __global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ work,
                                   uint32_t* __restrict__ order);
 __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
-    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
+    unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
+    int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ perm, const float* __restrict__ dL_dpix,
-    float* __restrict__ part /* (I,12) per-instance records at EMISSION positions: mx my A B C o c0 c1 c2 - - - */) {
+    float* __restrict__ part /* (I,12) per-instance records at their SLOTS: mx my A B C o c0 c1 c2 - - - */) {
     __shared__ float4 sA[BWD_WAVES][WAVE];
     __shared__ float4 sB[BWD_WAVES][WAVE];
     __shared__ float4 sC[BWD_WAVES][WAVE];
@@ -36,13 +37,17 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;
-    const int tile = (int)order[unit];
+    const int tile = (int)order[unit];          // global tile id: view * tiles_per_view + local tile
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
-    const int tx = tile % gx, ty = tile / gx;
+    const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
+    const int tx = ltile % gx, ty = ltile / gx;
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
     const float pfx = (float)px;
     const size_t HW = (size_t)H * W;
+    final_T += (size_t)view * HW;               // per-view planes of the batch
+    n_contrib += (size_t)view * HW;
+    dL_dpix += (size_t)view * 3 * HW;           // (nviews, 3, H, W)
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
@@ -505,16 +510,12 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
 // once, the activation / Sigma3 work is shared, dL/dSigma3 and dL/dmean are summed in registers, and every
 // gradient element is written exactly once (zeros when no view saw the Gaussian), so the caller neither
 // pre-zeroes the gradient buffer nor serialises the views.
-struct MultiView {
-    ViewParams vp;
-    const int* radii;
-    const uint32_t* clamped;
-    const uint2* run;
-    const float* part;
-};
 struct MultiViews {
-    int n;
-    MultiView v[E3_MAX_VIEWS];
+    ViewSet vs;
+    const int* radii;          // (n, P)
+    const uint32_t* clamped;   // per splat q = i * n + v
+    const uint2* run;          // per splat
+    const float* part;         // per-instance records (all views)
 };
 
 // real SH basis function k and its gradient w.r.t. the unit direction (same constants as sh_backward)
@@ -568,9 +569,10 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     float* dsh = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
     const size_t st = pl ? (size_t)P : (size_t)1;
     uint32_t vis = 0;
+    const int nv = mv.vs.n;
 #pragma unroll
     for (int v = 0; v < E3_MAX_VIEWS; ++v)
-        if (v < mv.n && mv.v[v].radii[i] > 0) vis |= 1u << v;
+        if (v < nv && mv.radii[(size_t)v * P + i] > 0) vis |= 1u << v;
     if (!vis) {
         if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
         dL_dopacity[i] = 0.0f;
@@ -585,27 +587,28 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     float sact[3], qn[4], qinv;
     act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, preact, sact, qn, qinv);
     Cov3 cv;
-    build_cov3(sact, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], cv);
+    build_cov3(sact, mv.vs.v[0].scale_modifier, qn[0], qn[1], qn[2], qn[3], cv);
     float gcov[6] = {0, 0, 0, 0, 0, 0}, gmean[3] = {0, 0, 0}, gopac = 0.0f;
     float m2x = 0.0f, m2y = 0.0f;
 #pragma unroll 1
-    for (int v = 0; v < mv.n; ++v) {
+    for (int v = 0; v < nv; ++v) {
         float o_dx = 0.0f, o_dy = 0.0f, o_dz = 0.0f, o_il = 0.0f, o_g0 = 0.0f, o_g1 = 0.0f, o_g2 = 0.0f;
         if ((vis >> v) & 1u) {
-            const MultiView& w = mv.v[v];
+            const ViewParams& vp = mv.vs.v[v];
+            const size_t q = (size_t)i * nv + v;
             float g12[9], gcv[6], gmv[3];
-            sum_run(w.run[i], w.part, g12);
-            view_geom_backward(w.vp, mx, my, mz, cv.S, g12, gcv, gmv);
+            sum_run(mv.run[q], mv.part, g12);
+            view_geom_backward(vp, mx, my, mz, cv.S, g12, gcv, gmv);
 #pragma unroll
             for (int k = 0; k < 6; ++k) gcov[k] += gcv[k];
             gmean[0] += gmv[0]; gmean[1] += gmv[1]; gmean[2] += gmv[2];
             gopac += g12[5];
             if (v == 0) { m2x = g12[0]; m2y = g12[1]; }
-            const uint32_t cl = w.clamped[i];
+            const uint32_t cl = mv.clamped[q];
             o_g0 = (cl & 1u) ? 0.0f : g12[6];
             o_g1 = (cl & 2u) ? 0.0f : g12[7];
             o_g2 = (cl & 4u) ? 0.0f : g12[8];
-            const float ox = mx - w.vp.campos[0], oy = my - w.vp.campos[1], oz = mz - w.vp.campos[2];
+            const float ox = mx - vp.campos[0], oy = my - vp.campos[1], oz = mz - vp.campos[2];
             const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
             o_dx = ox / len; o_dy = oy / len; o_dz = oz / len;
             o_il = 1.0f / len;
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     dL_dopacity[i] = gopac;
     {
         float ds[3], dq[4];
-        cov3_backward(cv, gcov, mv.v[0].vp.scale_modifier, qn[0], qn[1], qn[2], qn[3], preact, sact, qinv, ds, dq);
+        cov3_backward(cv, gcov, mv.vs.v[0].scale_modifier, qn[0], qn[1], qn[2], qn[3], preact, sact, qinv, ds, dq);
 #pragma unroll
         for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = ds[k];
 #pragma unroll
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     for (int v = 0; v < E3_MAX_VIEWS; ++v) {
         ddx[v] = ddy[v] = ddz[v] = 0.0f;
         dx[v] = dy[v] = dz[v] = gc[v][0] = gc[v][1] = gc[v][2] = 0.0f;
-        if (v < mv.n) {
+        if (v < nv) {
             dx[v] = sV[0][v][tid]; dy[v] = sV[1][v][tid]; dz[v] = sV[2][v][tid];
             gc[v][0] = sV[4][v][tid]; gc[v][1] = sV[5][v][tid]; gc[v][2] = sV[6][v][tid];
         }
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
             for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-                if (v < mv.n) {
+                if (v < nv) {
                     float Y, Yx, Yy, Yz;
                     sh_basis(k, dx[v], dy[v], dz[v], Y, Yx, Yy, Yz);
                     o0 = FMA(Y, gc[v][0], o0); o1 = FMA(Y, gc[v][1], o1); o2 = FMA(Y, gc[v][2], o2);
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
 #pragma unroll
     for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-        if (v < mv.n) {
+        if (v < nv) {
             const float il = sV[3][v][tid];
             const float dot = dx[v] * ddx[v] + dy[v] * ddy[v] + dz[v] * ddz[v];
             gmean[0] += (ddx[v] - dx[v] * dot) * il;
@@ -683,87 +686,55 @@ int e3_fail(hipError_t e, const char* what);
         }                                                     \
     } while (0)
 
-int e3_backward_impl(int P, int D, int M, int num_rendered, const float* background, int W, int H,
-                     const float* means3D, const float* shs, const float* colors, const float* opacities,
+int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_rendered, const float* background, int W,
+                     int H, const float* means3D, const float* shs, const float* colors, const float* opacities,
                      const float* scales, float scale_modifier, const float* rots, const float* cov_pre,
-                     const float* view, const float* proj, const float* campos, float tanfovx, float tanfovy,
-                     const int* radii, const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
-                     const float* dL_dpix, float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
-                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                     int flags, hipStream_t s) {
+                     const int* radii, const char* geom_buffer, const char* binning_buffer,
+                     const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
+                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                     float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s) {
     (void)colors;
     if (P <= 0) return 0;
-    ViewParams vp;
-    vp.view = view; vp.proj = proj; vp.campos = campos;
-    vp.tanfovx = tanfovx; vp.tanfovy = tanfovy;
-    vp.focal_x = (float)W / (2.0f * tanfovx);
-    vp.focal_y = (float)H / (2.0f * tanfovy);
-    vp.scale_modifier = scale_modifier;
-    vp.W = W; vp.H = H;
-    vp.gx = (W + E3_TILE - 1) / E3_TILE;
-    vp.gy = (H + E3_TILE - 1) / E3_TILE;
-    const int ntiles = vp.gx * vp.gy;
+    const ViewSet vs = make_view_set(views, W, H, scale_modifier);
+    const int nv = vs.n;
+    const int gx = vs.v[0].gx;
+    const int tiles_per_view = gx * vs.v[0].gy;
+    const int ntiles = tiles_per_view * nv;
+    const size_t Q = (size_t)P * nv;
     char* gp = const_cast<char*>(geom_buffer);
     char* bp = const_cast<char*>(binning_buffer);
     char* ip = const_cast<char*>(image_buffer);
-    GeomState geom = GeomState::from(gp, P);
+    GeomState geom = GeomState::from(gp, Q);
     BinningState bin = BinningState::from(bp, (size_t)num_rendered);
-    ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
+    ImageState img = ImageState::from(ip, (size_t)W * H * nv, ntiles);
     if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
         tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, ntiles, img.order_bwd, vp.gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+            g_trace, ntiles, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
             background, img.final_T, img.n_contrib, bin.perm, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;
     {
     ProfScope ps(PS_GEOM_BWD, s);
-    if (flags & E3_FLAG_ACCUMULATE)
+    if (nv == 1 && (flags & E3_FLAG_ACCUMULATE))
         geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, geom.run, grad_acc,
-            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
-    else
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, geom.run,
+            grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else if (nv == 1)
         geom_bwd_kernel<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vp, flags, radii, geom.clamped, geom.run, grad_acc,
-            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, geom.run,
+            grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else {
+        // several views: one pass, every gradient element written once (capi.hip checked the argument subset)
+        MultiViews mv;
+        mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.run = geom.run; mv.part = grad_acc;
+        geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
+            dL_dscale, dL_drot);
+    }
     }
     KERNEL_OK("geom_bwd_kernel");
-    return 0;
-}
-
-int e3_backward_geom_multi_impl(int nviews, int P, int D, int M, const float* means3D, const float* shs,
-                                const float* opacities, const float* scales, float scale_modifier, const float* rots,
-                                const int* widths, const int* heights, const float* const* view,
-                                const float* const* proj, const float* const* campos, const float* tanfovx,
-                                const float* tanfovy, const int* const* radii, const char* const* geom_buffer,
-                                const float* const* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
-                                float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s) {
-    if (P <= 0) return 0;
-    MultiViews mv;
-    mv.n = nviews;
-    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
-        const int u = v < nviews ? v : 0;      // unused slots mirror view 0 (never dereferenced: v >= n)
-        MultiView& w = mv.v[v];
-        w.vp.view = view[u]; w.vp.proj = proj[u]; w.vp.campos = campos[u];
-        w.vp.tanfovx = tanfovx[u]; w.vp.tanfovy = tanfovy[u];
-        w.vp.focal_x = (float)widths[u] / (2.0f * tanfovx[u]);
-        w.vp.focal_y = (float)heights[u] / (2.0f * tanfovy[u]);
-        w.vp.scale_modifier = scale_modifier;
-        w.vp.W = widths[u]; w.vp.H = heights[u];
-        w.vp.gx = (widths[u] + E3_TILE - 1) / E3_TILE;
-        w.vp.gy = (heights[u] + E3_TILE - 1) / E3_TILE;
-        char* gp = const_cast<char*>(geom_buffer[u]);
-        GeomState geom = GeomState::from(gp, P);
-        w.radii = radii[u]; w.clamped = geom.clamped; w.run = geom.run; w.part = grad_acc[u];
-    }
-    {
-    ProfScope ps(PS_GEOM_BWD, s);
-    geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
-        dL_dscale, dL_drot);
-    }
-    KERNEL_OK("geom_bwd_multi_kernel");
     return 0;
 }

@@ -43,21 +43,6 @@ void prof_end(int slot, hipStream_t s) {
     g_open[slot] = false;
 }
 
-int e3_forward_begin_impl(char* (*)(void*, size_t), void*, char* (*)(void*, size_t), void*, int, int, int, int, int,
-                          const float*, const float*, const float*, const float*, const float*, float, const float*,
-                          const float*, const float*, const float*, const float*, float, float, int*, int, int, int*,
-                          hipStream_t);
-int e3_forward_finish_impl(char* (*)(void*, size_t), void*, int, int, int, const float*, char*, char*, int, float*, int,
-                           hipStream_t);
-int e3_backward_geom_multi_impl(int, int, int, int, const float*, const float*, const float*, const float*, float,
-                                const float*, const int*, const int*, const float* const*, const float* const*,
-                                const float* const*, const float*, const float*, const int* const*, const char* const*,
-                                const float* const*, float*, float*, float*, float*, float*, float*, int, int,
-                                hipStream_t);
-int e3_backward_impl(int, int, int, int, const float*, int, int, const float*, const float*, const float*, const float*,
-                     const float*, float, const float*, const float*, const float*, const float*, const float*, float,
-                     float, const int*, const char*, const char*, const char*, const float*, float*, float*, float*,
-                     float*, float*, float*, float*, float*, float*, int, int, hipStream_t);
 int e3_mark_visible_impl(int, const float*, const float*, uint8_t*, hipStream_t);
 size_t e3_knn_scratch_bytes(int);
 int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
@@ -71,40 +56,33 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
-static int check_forward_args(int P, int D, int M, int width, int height, const float* shs, const float* colors_precomp,
-                              const float* scales, const float* rotations, const float* cov3D_precomp, int flags);
-int e3dgs_abi_version(void) { return 2; }
+int e3dgs_abi_version(void) { return 3; }
 const char* e3dgs_last_error(void) { return g_err; }
 
-int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
-                            void* binning_user, e3dgs_alloc_fn image_alloc, void* image_user, int P, int D, int M,
-                            const float* background, int width, int height, const float* means3D, const float* shs,
-                            const float* colors_precomp, const float* opacities, const float* scales,
-                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                            float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, int flags,
-                            int* num_rendered_host, void* stream) {
-    g_err[0] = 0;
-    {
-        int rc0 = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
-        if (rc0) return rc0;
+static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                          float tan_fovy) {
+    ViewBatch b;
+    b.n = 1;
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        b.view[v] = viewmatrix; b.proj[v] = projmatrix; b.campos[v] = cam_pos;
+        b.tanfovx[v] = tan_fovx; b.tanfovy[v] = tan_fovy;
     }
-    struct Keep { e3dgs_alloc_fn fn; void* user; char* ptr; };
-    // remember the two buffers handed out in `begin` so that `finish` can be fed without a second callback
-    static thread_local Keep kg, ki;
-    kg = Keep{geom_alloc, geom_user, nullptr};
-    ki = Keep{image_alloc, image_user, nullptr};
-    auto grab_g = [](void* u, size_t n) -> char* { Keep* k = (Keep*)u; k->ptr = k->fn(k->user, n); return k->ptr; };
-    int count = 0;
-    int rc = e3_forward_begin_impl(grab_g, &kg, grab_g, &ki, P, D, M, width, height, means3D, shs, colors_precomp,
-                                   opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
-                                   cam_pos, tan_fovx, tan_fovy, radii, debug, flags, &count, (hipStream_t)stream);
-    if (rc) return rc;
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);   // the op's single device->host synchronisation
-    if (e != hipSuccess) return e3_fail(e, "hipStreamSynchronize (instance count)");
-    *num_rendered_host = count;
-    return e3_forward_finish_impl(binning_alloc, binning_user, P, width, height, background, kg.ptr, ki.ptr, count,
-                                  out_color, debug, (hipStream_t)stream);
+    return b;
+}
+static int make_batch(int nviews, int P, const float* const* viewmatrix, const float* const* projmatrix,
+                      const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy, ViewBatch& b) {
+    if (nviews < 1 || nviews > E3_MAX_VIEWS) return e3_fail(hipErrorInvalidValue, "nviews must be 1..4");
+    if (!viewmatrix || !projmatrix || !cam_pos || !tan_fovx || !tan_fovy)
+        return e3_fail(hipErrorInvalidValue, "per-view arrays are required");
+    if ((long long)P * nviews > 0x7FFFFFFFll) return e3_fail(hipErrorInvalidValue, "P * nviews exceeds 2^31-1");
+    b.n = nviews;
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        const int u = v < nviews ? v : 0;
+        if (!viewmatrix[u] || !projmatrix[u] || !cam_pos[u]) return e3_fail(hipErrorInvalidValue, "null per-view pointer");
+        b.view[v] = viewmatrix[u]; b.proj[v] = projmatrix[u]; b.campos[v] = cam_pos[u];
+        b.tanfovx[v] = tan_fovx[u]; b.tanfovy[v] = tan_fovy[u];
+    }
+    return 0;
 }
 
 static int check_forward_args(int P, int D, int M, int width, int height, const float* shs, const float* colors_precomp,
@@ -122,6 +100,71 @@ static int check_forward_args(int P, int D, int M, int width, int height, const 
     return 0;
 }
 
+static int check_backward_args(int nviews, int P, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* cov3D_precomp, float* grad_acc,
+                               float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                               float* dL_dsh, float* dL_dscale, float* dL_drot, int flags) {
+    if (P > 0 && !grad_acc) return e3_fail(hipErrorInvalidValue, "grad_acc is required");
+    if ((flags & E3_FLAG_PREACT) && (cov3D_precomp || !opacities))
+        return e3_fail(hipErrorInvalidValue, "PREACT needs scales+rotations and opacities");
+    if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;      // the per-Gaussian stage writes the rest
+    if (P > 0 && !dL_dmean3D) return e3_fail(hipErrorInvalidValue, "dL_dmean3D is required");
+    if (shs && !dL_dsh) return e3_fail(hipErrorInvalidValue, "dL_dsh required when shs is given");
+    if (!cov3D_precomp && (!dL_dscale || !dL_drot))
+        return e3_fail(hipErrorInvalidValue, "dL_dscale/dL_drot required when scales+rotations are given");
+    if (nviews > 1) {
+        if (!shs || colors_precomp || cov3D_precomp || dL_dcolor || dL_dcov3D)
+            return e3_fail(hipErrorInvalidValue, "multi-view backward needs shs + scales + rotations (no precomputed inputs)");
+        if (!dL_dopacity) return e3_fail(hipErrorInvalidValue, "multi-view backward needs dL_dopacity");
+        if (flags & E3_FLAG_ACCUMULATE)
+            return e3_fail(hipErrorInvalidValue, "multi-view backward overwrites its outputs (no ACCUMULATE)");
+    }
+    return 0;
+}
+
+// one-call forward: begin + the single stream synchronisation + finish
+static int forward_sync(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc, void* binning_user,
+                        e3dgs_alloc_fn image_alloc, void* image_user, const ViewBatch& vb, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, float* out_color, int* radii, int debug,
+                        int flags, int* num_rendered_host, void* stream) {
+    struct Keep { e3dgs_alloc_fn fn; void* user; char* ptr; };
+    // remember the two buffers handed out in `begin` so that `finish` can be fed without a second callback
+    static thread_local Keep kg, ki;
+    kg = Keep{geom_alloc, geom_user, nullptr};
+    ki = Keep{image_alloc, image_user, nullptr};
+    auto grab_g = [](void* u, size_t n) -> char* { Keep* k = (Keep*)u; k->ptr = k->fn(k->user, n); return k->ptr; };
+    int count = 0;
+    int rc = e3_forward_begin_impl(grab_g, &kg, grab_g, &ki, vb, P, D, M, width, height, means3D, shs, colors_precomp,
+                                   opacities, scales, scale_modifier, rotations, cov3D_precomp, radii, debug, flags,
+                                   &count, (hipStream_t)stream);
+    if (rc) return rc;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);   // the op's single device->host synchronisation
+    if (e != hipSuccess) return e3_fail(e, "hipStreamSynchronize (instance count)");
+    *num_rendered_host = count;
+    return e3_forward_finish_impl(binning_alloc, binning_user, vb.n, P, width, height, background, kg.ptr, ki.ptr,
+                                  count, out_color, debug, (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
+                            void* binning_user, e3dgs_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                            float tan_fovy, int prefiltered, float* out_color, int* radii, int debug, int flags,
+                            int* num_rendered_host, void* stream) {
+    (void)prefiltered;
+    g_err[0] = 0;
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+    if (rc) return rc;
+    return forward_sync(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user,
+                        one_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy), P, D, M, background, width,
+                        height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, out_color, radii, debug, flags, num_rendered_host, stream);
+}
+
 int e3dgs_rasterize_forward_begin(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn image_alloc,
                                   void* image_user, int P, int D, int M, int width, int height, const float* means3D,
                                   const float* shs, const float* colors_precomp, const float* opacities,
@@ -132,10 +175,10 @@ int e3dgs_rasterize_forward_begin(e3dgs_alloc_fn geom_alloc, void* geom_user, e3
     g_err[0] = 0;
     int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
     if (rc) return rc;
-    return e3_forward_begin_impl(geom_alloc, geom_user, image_alloc, image_user, P, D, M, width, height, means3D, shs,
-                                 colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
-                                 projmatrix, cam_pos, tan_fovx, tan_fovy, radii, debug, flags, num_rendered_host,
-                                 (hipStream_t)stream);
+    return e3_forward_begin_impl(geom_alloc, geom_user, image_alloc, image_user,
+                                 one_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy), P, D, M, width, height,
+                                 means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                 cov3D_precomp, radii, debug, flags, num_rendered_host, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_forward_finish(e3dgs_alloc_fn binning_alloc, void* binning_user, int P, int width, int height,
@@ -143,8 +186,8 @@ int e3dgs_rasterize_forward_finish(e3dgs_alloc_fn binning_alloc, void* binning_u
                                    float* out_color, int debug, void* stream) {
     g_err[0] = 0;
     if (P < 0 || num_rendered < 0 || !geom_buffer || !image_buffer) return e3_fail(hipErrorInvalidValue, "bad arguments");
-    return e3_forward_finish_impl(binning_alloc, binning_user, P, width, height, background, geom_buffer, image_buffer,
-                                  num_rendered, out_color, debug, (hipStream_t)stream);
+    return e3_forward_finish_impl(binning_alloc, binning_user, 1, P, width, height, background, geom_buffer,
+                                  image_buffer, num_rendered, out_color, debug, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
@@ -157,47 +200,90 @@ int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float*
                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                              float* dL_drot, int debug, int flags, void* stream) {
     g_err[0] = 0;
-    if (P > 0 && !grad_acc) return e3_fail(hipErrorInvalidValue, "grad_acc is required");
-    if (!(flags & E3_FLAG_BWD_ONLY_RENDER)) {       // the per-Gaussian stage writes these
-        if (P > 0 && !dL_dmean3D) return e3_fail(hipErrorInvalidValue, "dL_dmean3D is required");
-        if (shs && !dL_dsh) return e3_fail(hipErrorInvalidValue, "dL_dsh required when shs is given");
-        if (!cov3D_precomp && (!dL_dscale || !dL_drot))
-            return e3_fail(hipErrorInvalidValue, "dL_dscale/dL_drot required when scales+rotations are given");
-    }
-    if ((flags & E3_FLAG_PREACT) && (cov3D_precomp || !opacities))
-        return e3_fail(hipErrorInvalidValue, "PREACT needs scales+rotations and opacities");
-    return e3_backward_impl(P, D, M, num_rendered, background, width, height, means3D, shs, colors_precomp, opacities,
-                            scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                            tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D,
-                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, flags,
-                            (hipStream_t)stream);
+    int rc = check_backward_args(1, P, shs, colors_precomp, opacities, cov3D_precomp, grad_acc, dL_dopacity, dL_dcolor,
+                                 dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, flags);
+    if (rc) return rc;
+    return e3_backward_impl(one_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy), P, D, M, num_rendered,
+                            background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                            rotations, cov3D_precomp, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
+                            grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                            dL_drot, debug, flags, (hipStream_t)stream);
 }
 
-int e3dgs_rasterize_backward_geom_multi(int nviews, int P, int D, int M, const float* means3D, const float* shs,
+// ---- several views of the same Gaussians in one pass (see ViewSet in common.h)
+int e3dgs_rasterize_forward_multi(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
+                                  void* binning_user, e3dgs_alloc_fn image_alloc, void* image_user, int nviews, int P,
+                                  int D, int M, const float* background, int width, int height, const float* means3D,
+                                  const float* shs, const float* colors_precomp, const float* opacities,
+                                  const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* const* viewmatrix,
+                                  const float* const* projmatrix, const float* const* cam_pos, const float* tan_fovx,
+                                  const float* tan_fovy, float* out_color, int* radii, int debug, int flags,
+                                  int* num_rendered_host, void* stream) {
+    g_err[0] = 0;
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+    if (rc) return rc;
+    ViewBatch vb;
+    rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
+    if (rc) return rc;
+    return forward_sync(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, vb, P, D, M,
+                        background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                        rotations, cov3D_precomp, out_color, radii, debug, flags, num_rendered_host, stream);
+}
+
+int e3dgs_rasterize_forward_multi_begin(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn image_alloc,
+                                        void* image_user, int nviews, int P, int D, int M, int width, int height,
+                                        const float* means3D, const float* shs, const float* colors_precomp,
                                         const float* opacities, const float* scales, float scale_modifier,
-                                        const float* rotations, const int* widths, const int* heights,
+                                        const float* rotations, const float* cov3D_precomp,
                                         const float* const* viewmatrix, const float* const* projmatrix,
                                         const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy,
-                                        const int* const* radii, const char* const* geom_buffer,
-                                        const float* const* grad_acc, float* dL_dmean2D, float* dL_dopacity,
-                                        float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                                        int flags, void* stream) {
+                                        int* radii, int debug, int flags, int* num_rendered_host, void* stream) {
     g_err[0] = 0;
-    if (nviews < 1 || nviews > E3_MAX_VIEWS) return e3_fail(hipErrorInvalidValue, "nviews must be 1..4");
-    if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "bad P/D/M");
-    if (!means3D || !shs || !scales || !rotations || !dL_dopacity || !dL_dmean3D || !dL_dsh || !dL_dscale || !dL_drot)
-        return e3_fail(hipErrorInvalidValue, "geom_multi needs shs + scales + rotations and all gradient outputs");
-    if ((flags & E3_FLAG_PREACT) && !opacities) return e3_fail(hipErrorInvalidValue, "PREACT needs opacities");
-    if (!widths || !heights || !viewmatrix || !projmatrix || !cam_pos || !tan_fovx || !tan_fovy || !radii ||
-        !geom_buffer || !grad_acc)
-        return e3_fail(hipErrorInvalidValue, "per-view arrays are required");
-    for (int v = 0; v < nviews; ++v)
-        if (!viewmatrix[v] || !projmatrix[v] || !cam_pos[v] || !radii[v] || !geom_buffer[v] || !grad_acc[v])
-            return e3_fail(hipErrorInvalidValue, "null per-view pointer");
-    return e3_backward_geom_multi_impl(nviews, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations,
-                                       widths, heights, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
-                                       geom_buffer, grad_acc, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale,
-                                       dL_drot, debug, flags, (hipStream_t)stream);
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+    if (rc) return rc;
+    ViewBatch vb;
+    rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
+    if (rc) return rc;
+    return e3_forward_begin_impl(geom_alloc, geom_user, image_alloc, image_user, vb, P, D, M, width, height, means3D,
+                                 shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, radii,
+                                 debug, flags, num_rendered_host, (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_forward_multi_finish(e3dgs_alloc_fn binning_alloc, void* binning_user, int nviews, int P, int width,
+                                         int height, const float* background, char* geom_buffer, char* image_buffer,
+                                         int num_rendered, float* out_color, int debug, void* stream) {
+    g_err[0] = 0;
+    if (nviews < 1 || nviews > E3_MAX_VIEWS || P < 0 || num_rendered < 0 || !geom_buffer || !image_buffer)
+        return e3_fail(hipErrorInvalidValue, "bad arguments");
+    return e3_forward_finish_impl(binning_alloc, binning_user, nviews, P, width, height, background, geom_buffer,
+                                  image_buffer, num_rendered, out_color, debug, (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,
+                                   int width, int height, const float* means3D, const float* shs,
+                                   const float* opacities, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* const* viewmatrix,
+                                   const float* const* projmatrix, const float* const* cam_pos, const float* tan_fovx,
+                                   const float* tan_fovy, const int* radii, const char* geom_buffer,
+                                   const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
+                                   float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
+                                   float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, int flags,
+                                   void* stream) {
+    g_err[0] = 0;
+    ViewBatch vb;
+    int rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
+    if (rc) return rc;
+    if (P > 0 && (!shs || !scales || !rotations)) return e3_fail(hipErrorInvalidValue, "shs + scales + rotations are required");
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
+    // nviews == 1 runs the general single-view kernel, so pass 2 to apply the multi-view argument rules always
+    rc = check_backward_args(2, P, shs, nullptr, opacities, nullptr, grad_acc, dL_dopacity, nullptr, dL_dmean3D,
+                             nullptr, dL_dsh, dL_dscale, dL_drot, flags);
+    if (rc) return rc;
+    return e3_backward_impl(vb, P, D, M, num_rendered, background, width, height, means3D, shs, nullptr, opacities,
+                            scales, scale_modifier, rotations, nullptr, radii, geom_buffer, binning_buffer, image_buffer,
+                            dL_dpix, grad_acc, dL_dmean2D, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_dsh, dL_dscale,
+                            dL_drot, debug, flags, (hipStream_t)stream);
 }
 
 size_t e3dgs_state_offset_emit_gid(int num_rendered) {

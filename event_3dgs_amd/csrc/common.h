@@ -251,6 +251,60 @@ struct ViewParams {
     int W, H, gx, gy;
 };
 
+// A call renders n <= E3_MAX_VIEWS views of the SAME Gaussians at the SAME resolution (the three renders of
+// an event iteration, train.py:144,159,161; n = 1 for the plain operator).  Everything per (Gaussian, view)
+// -- a "splat" -- is indexed  q = i * n + v  (Gaussian-major, so one Gaussian's splats and gradient-record
+// runs are adjacent), tiles are numbered  v * ntiles + ty * gx + tx,  and every kernel of the pipeline runs
+// ONCE over all views: n times fewer launches, n times larger (better filled) grids, parameters read once.
+struct ViewSet {
+    int n;
+    ViewParams v[E3_MAX_VIEWS];
+};
+
+// host-side description of the views of one call (arrays of per-view values)
+struct ViewBatch {
+    int n;
+    const float* view[E3_MAX_VIEWS];
+    const float* proj[E3_MAX_VIEWS];
+    const float* campos[E3_MAX_VIEWS];
+    float tanfovx[E3_MAX_VIEWS], tanfovy[E3_MAX_VIEWS];
+};
+static inline ViewSet make_view_set(const ViewBatch& b, int W, int H, float scale_modifier) {
+    ViewSet vs;
+    vs.n = b.n;
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        const int u = v < b.n ? v : 0;         // unused slots mirror view 0 (never used: v >= n)
+        ViewParams& w = vs.v[v];
+        w.view = b.view[u]; w.proj = b.proj[u]; w.campos = b.campos[u];
+        w.tanfovx = b.tanfovx[u]; w.tanfovy = b.tanfovy[u];
+        w.focal_x = (float)W / (2.0f * b.tanfovx[u]);
+        w.focal_y = (float)H / (2.0f * b.tanfovy[u]);
+        w.scale_modifier = scale_modifier;
+        w.W = W; w.H = H;
+        w.gx = (W + E3_TILE - 1) / E3_TILE;
+        w.gy = (H + E3_TILE - 1) / E3_TILE;
+    }
+    return vs;
+}
+
+// host drivers (forward.hip / backward.hip), called by the C ABI wrappers in capi.hip
+typedef char* (*e3_alloc_fn)(void*, size_t);
+int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn img_alloc, void* img_user,
+                          const ViewBatch& views, int P, int D, int M, int W, int H, const float* means3D,
+                          const float* shs, const float* colors, const float* opac, const float* scales,
+                          float scale_modifier, const float* rots, const float* cov_pre, int* radii, int debug,
+                          int flags, int* count_host, hipStream_t s);
+int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
+                           const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
+                           float* out_color, int debug, hipStream_t s);
+int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_rendered, const float* background, int W,
+                     int H, const float* means3D, const float* shs, const float* colors, const float* opacities,
+                     const float* scales, float scale_modifier, const float* rots, const float* cov_pre,
+                     const int* radii, const char* geom_buffer, const char* binning_buffer,
+                     const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
+                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                     float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s);
+
 // launchers implemented in scan_sort.hip
 void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
                                hipStream_t s);

@@ -82,99 +82,107 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod,
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------ preprocess
+// One thread per Gaussian, looping over the views of the call: the mean, Sigma3, the opacity activation and
+// (through L1) the SH coefficients are fetched once for all views.  Splat q = i * n + v.
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
-    const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewParams vp, int flags,
+    const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewSet vs, int flags,
     int* __restrict__ radii,
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const float* V = vp.view;
-    const float* Pm = vp.proj;
-    int radius_out = 0;
-    uint2 rect_out = make_uint2(0u, 0u);
-    uint32_t key_out = 0xFFFFFFFFu;
-    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-    float vx = XFORM(V, 0, mx, my, mz), vy = XFORM(V, 1, mx, my, mz), vz = XFORM(V, 2, mx, my, mz);
-    if (vz > E3_NEAR_CULL_Z) {
-        float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
-        float pw = 1.0f / (hw + E3_W_EPS);
-        float ndcx = hx * pw, ndcy = hy * pw;
-        float S[6];
-        if (cov_pre) {
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float S[6];
+    if (cov_pre) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
-        } else {
-            float sc[3], qn[4], qinv;
-            act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, (flags & E3_FLAG_PREACT) != 0, sc, qn, qinv);
-            cov3d_from_scale_rot(sc, vp.scale_modifier, qn, S);
-        }
-        // EWA: T = J * Wr, Sigma2 = T Sigma3 T^T
-        float limx = E3_GUARD_BAND * vp.tanfovx, limy = E3_GUARD_BAND * vp.tanfovy;
-        float txtz = vx / vz, tytz = vy / vz;
-        float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
-        float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
-        float tz = vz;
-        float J00 = vp.focal_x / tz, J02 = -(vp.focal_x * tx) / (tz * tz);
-        float J11 = vp.focal_y / tz, J12 = -(vp.focal_y * ty) / (tz * tz);
-        float T00 = FMA(J00, V[0], J02 * V[2]), T01 = FMA(J00, V[4], J02 * V[6]), T02 = FMA(J00, V[8], J02 * V[10]);
-        float T10 = FMA(J11, V[1], J12 * V[2]), T11 = FMA(J11, V[5], J12 * V[6]), T12 = FMA(J11, V[9], J12 * V[10]);
-        float u0 = FMA(S[0], T00, FMA(S[1], T01, S[2] * T02));
-        float u1 = FMA(S[1], T00, FMA(S[3], T01, S[4] * T02));
-        float u2 = FMA(S[2], T00, FMA(S[4], T01, S[5] * T02));
-        float w0 = FMA(S[0], T10, FMA(S[1], T11, S[2] * T12));
-        float w1 = FMA(S[1], T10, FMA(S[3], T11, S[4] * T12));
-        float w2 = FMA(S[2], T10, FMA(S[4], T11, S[5] * T12));
-        float a = FMA(T00, u0, FMA(T01, u1, T02 * u2));
-        float b = FMA(T10, u0, FMA(T11, u1, T12 * u2));
-        float c = FMA(T10, w0, FMA(T11, w1, T12 * w2));
-        a = a + E3_DILATION;
-        c = c + E3_DILATION;
-        float det = FMA(a, c, -(b * b));
-        if (det != 0.0f) {
-            float det_inv = 1.0f / det;
-            float conx = c * det_inv, cony = -b * det_inv, conz = a * det_inv;
-            float mid = 0.5f * (a + c);
-            float disc = __builtin_sqrtf(fmaxf(E3_EIGEN_FLOOR, FMA(mid, mid, -det)));
-            float lam1 = mid + disc, lam2 = mid - disc;
-            int radius = (int)__builtin_ceilf(3.0f * __builtin_sqrtf(fmaxf(lam1, lam2)));
-            // ndc2Pix in double, single final rounding (gaussian_renderer/__init__.py:238-241)
-            float px = (float)((((double)ndcx + 1.0) * (double)vp.W - 1.0) * 0.5);
-            float py = (float)((((double)ndcy + 1.0) * (double)vp.H - 1.0) * 0.5);
-            float fr = (float)radius;
-            int xmin = clampi((int)((px - fr) / (float)E3_TILE), 0, vp.gx);
-            int ymin = clampi((int)((py - fr) / (float)E3_TILE), 0, vp.gy);
-            int xmax = clampi((int)((((px + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gx);
-            int ymax = clampi((int)((((py + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gy);
-            if ((xmax - xmin) * (ymax - ymin) != 0) {
-                float rgb[3];
-                uint32_t cl = 0;
-                if (shs) {
-                    const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
-                    sh_to_rgb(D, planar ? shs + i : shs + (size_t)i * M * 3, planar ? (size_t)P : (size_t)1, mx, my, mz,
-                              vp.campos, rgb, cl);
-                } else {
-                    rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
+        for (int k = 0; k < 6; ++k) S[k] = cov_pre[6 * (size_t)i + k];
+    } else {
+        float sc[3], qn[4], qinv;
+        act_load_scale_rot(scales + 3 * (size_t)i, rots + 4 * (size_t)i, (flags & E3_FLAG_PREACT) != 0, sc, qn, qinv);
+        cov3d_from_scale_rot(sc, vs.v[0].scale_modifier, qn, S);
+    }
+    const float o_ = (flags & E3_FLAG_PREACT) ? act_sigmoid(opac[i]) : opac[i];
+    // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
+    // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
+    const float pmin = -(logf(255.0f * o_) + 1e-3f);
+#pragma unroll 1
+    for (int v = 0; v < vs.n; ++v) {
+        const ViewParams& vp = vs.v[v];
+        const size_t q = (size_t)i * vs.n + v;
+        const float* V = vp.view;
+        const float* Pm = vp.proj;
+        int radius_out = 0;
+        uint2 rect_out = make_uint2(0u, 0u);
+        uint32_t key_out = 0xFFFFFFFFu;
+        float vx = XFORM(V, 0, mx, my, mz), vy = XFORM(V, 1, mx, my, mz), vz = XFORM(V, 2, mx, my, mz);
+        if (vz > E3_NEAR_CULL_Z) {
+            float hx = XFORM(Pm, 0, mx, my, mz), hy = XFORM(Pm, 1, mx, my, mz), hw = XFORM(Pm, 3, mx, my, mz);
+            float pw = 1.0f / (hw + E3_W_EPS);
+            float ndcx = hx * pw, ndcy = hy * pw;
+            // EWA: T = J * Wr, Sigma2 = T Sigma3 T^T
+            float limx = E3_GUARD_BAND * vp.tanfovx, limy = E3_GUARD_BAND * vp.tanfovy;
+            float txtz = vx / vz, tytz = vy / vz;
+            float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+            float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+            float tz = vz;
+            float J00 = vp.focal_x / tz, J02 = -(vp.focal_x * tx) / (tz * tz);
+            float J11 = vp.focal_y / tz, J12 = -(vp.focal_y * ty) / (tz * tz);
+            float T00 = FMA(J00, V[0], J02 * V[2]), T01 = FMA(J00, V[4], J02 * V[6]), T02 = FMA(J00, V[8], J02 * V[10]);
+            float T10 = FMA(J11, V[1], J12 * V[2]), T11 = FMA(J11, V[5], J12 * V[6]), T12 = FMA(J11, V[9], J12 * V[10]);
+            float u0 = FMA(S[0], T00, FMA(S[1], T01, S[2] * T02));
+            float u1 = FMA(S[1], T00, FMA(S[3], T01, S[4] * T02));
+            float u2 = FMA(S[2], T00, FMA(S[4], T01, S[5] * T02));
+            float w0 = FMA(S[0], T10, FMA(S[1], T11, S[2] * T12));
+            float w1 = FMA(S[1], T10, FMA(S[3], T11, S[4] * T12));
+            float w2 = FMA(S[2], T10, FMA(S[4], T11, S[5] * T12));
+            float a = FMA(T00, u0, FMA(T01, u1, T02 * u2));
+            float b = FMA(T10, u0, FMA(T11, u1, T12 * u2));
+            float c = FMA(T10, w0, FMA(T11, w1, T12 * w2));
+            a = a + E3_DILATION;
+            c = c + E3_DILATION;
+            float det = FMA(a, c, -(b * b));
+            if (det != 0.0f) {
+                float det_inv = 1.0f / det;
+                float conx = c * det_inv, cony = -b * det_inv, conz = a * det_inv;
+                float mid = 0.5f * (a + c);
+                float disc = __builtin_sqrtf(fmaxf(E3_EIGEN_FLOOR, FMA(mid, mid, -det)));
+                float lam1 = mid + disc, lam2 = mid - disc;
+                int radius = (int)__builtin_ceilf(3.0f * __builtin_sqrtf(fmaxf(lam1, lam2)));
+                // ndc2Pix in double, single final rounding (gaussian_renderer/__init__.py:238-241)
+                float px = (float)((((double)ndcx + 1.0) * (double)vp.W - 1.0) * 0.5);
+                float py = (float)((((double)ndcy + 1.0) * (double)vp.H - 1.0) * 0.5);
+                float fr = (float)radius;
+                int xmin = clampi((int)((px - fr) / (float)E3_TILE), 0, vp.gx);
+                int ymin = clampi((int)((py - fr) / (float)E3_TILE), 0, vp.gy);
+                int xmax = clampi((int)((((px + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gx);
+                int ymax = clampi((int)((((py + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gy);
+                if ((xmax - xmin) * (ymax - ymin) != 0) {
+                    float rgb[3];
+                    uint32_t cl = 0;
+                    if (shs) {
+                        const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
+                        sh_to_rgb(D, planar ? shs + i : shs + (size_t)i * M * 3, planar ? (size_t)P : (size_t)1, mx, my,
+                                  mz, vp.campos, rgb, cl);
+                    } else {
+                        rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
+                    }
+                    rec[3 * q] = make_float4(px, py, conx, cony);
+                    rec[3 * q + 1] = make_float4(conz, o_, rgb[0], rgb[1]);
+                    rec[3 * q + 2] = make_float4(rgb[2], pmin, 0.0f, 0.0f);
+                    clamped[q] = cl;
+                    radius_out = radius;
+                    rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
+                    key_out = __float_as_uint(vz);
                 }
-                rec[3 * (size_t)i] = make_float4(px, py, conx, cony);
-                const float o_ = (flags & E3_FLAG_PREACT) ? act_sigmoid(opac[i]) : opac[i];
-                rec[3 * (size_t)i + 1] = make_float4(conz, o_, rgb[0], rgb[1]);
-                // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
-                // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
-                rec[3 * (size_t)i + 2] = make_float4(rgb[2], -(logf(255.0f * o_) + 1e-3f), 0.0f, 0.0f);
-                clamped[i] = cl;
-                radius_out = radius;
-                rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
-                key_out = __float_as_uint(vz);
             }
         }
+        radii[(size_t)v * P + i] = radius_out;
+        rect[q] = rect_out;
+        key[q] = key_out;
+        ord[q] = (uint32_t)q;
     }
-    radii[i] = radius_out;
-    rect[i] = rect_out;
-    key[i] = key_out;
-    ord[i] = (uint32_t)i;
 }
 
 __device__ __forceinline__ uint32_t rect_area(uint2 r) {
@@ -221,7 +229,8 @@ __device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float 
 // produces, so a stable sort on the tile id alone finishes the job.
 constexpr int BIN_WAVES = 4;
 template <bool EMIT>
-__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews, int ntiles,
+                                                              const uint32_t* __restrict__ order,
                                                               const uint2* __restrict__ rect,
                                                               const float4* __restrict__ rec, int gx, int cull,
                                                               const uint32_t* __restrict__ wave_offsets,
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
     __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
     __shared__ uint32_t sIncl[BIN_WAVES][WAVE];
     __shared__ uint32_t sId[BIN_WAVES][WAVE];
+    __shared__ uint32_t sBase[BIN_WAVES][WAVE];  // first tile id of the splat's view
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * BIN_WAVES + wave;
     const int s = gw * WAVE + lane;
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
     }
     const uint32_t total = __shfl(incl, 63, 64);
     sA[wave][lane] = a; sB[wave][lane] = b; sIncl[wave][lane] = incl; sId[wave][lane] = g;
+    sBase[wave][lane] = nviews > 1 ? (g % (uint32_t)nviews) * (uint32_t)ntiles : 0u;
     sCnt[wave][lane] = 0;
     if (EMIT) sSlot[wave][lane] = (s < P) ? slot_start[g] : 0u;
     wave_sync();
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, const uint
                 // instance's SLOT, Gaussian-major in index order, where backward parks its gradient record
                 const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
                 const uint32_t slot = sSlot[wave][j] + k_in;
-                keys[pos] = (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+                keys[pos] = sBase[wave][j] + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
                 vals[pos] = slot;
                 emit_gid[slot] = sId[wave][j];
             }
@@ -382,7 +393,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
 unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
 
 __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
-    unsigned long long* __restrict__ trace, int ntiles, const uint32_t* __restrict__ order, int gx, int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ perm,
+    unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
+    int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ perm,
     const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work) {
@@ -392,10 +404,11 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * RENDER_WAVES + wave;
     if (unit >= ntiles) return;
-    const int tile = (int)order[unit];
+    const int tile = (int)order[unit];          // global tile id: view * tiles_per_view + local tile
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     int processed = 0;
-    const int tx = tile % gx, ty = tile / gx;
+    const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
+    const int tx = ltile % gx, ty = ltile / gx;
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
     const float pfx = (float)px;
@@ -494,6 +507,9 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
+    out += (size_t)view * 3 * HW;               // (nviews, 3, H, W)
+    final_T += (size_t)view * HW;
+    n_contrib += (size_t)view * HW;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (inside[k]) {
@@ -545,63 +561,57 @@ static int ceil_log2(uint32_t v) {
     return b;
 }
 
-// Forward is split in two enqueue-only halves around the instance count so that a caller rendering
-// several views can issue every `begin`, synchronise ONCE, and then issue every `finish`
-// (EventTrainer.step does; the one-call e3dgs_rasterize_forward = begin + stream sync + finish).
-int e3_forward_begin_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, char* (*img_alloc)(void*, size_t),
-                          void* img_user, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
-                          const float* colors, const float* opac, const float* scales, float scale_modifier,
-                          const float* rots, const float* cov_pre, const float* view, const float* proj,
-                          const float* campos, float tanfovx, float tanfovy, int* radii, int debug, int flags,
-                          int* count_host, hipStream_t s) {
-    ViewParams vp;
-    vp.view = view; vp.proj = proj; vp.campos = campos;
-    vp.tanfovx = tanfovx; vp.tanfovy = tanfovy;
-    vp.focal_x = (float)W / (2.0f * tanfovx);
-    vp.focal_y = (float)H / (2.0f * tanfovy);
-    vp.scale_modifier = scale_modifier;
-    vp.W = W; vp.H = H;
-    vp.gx = (W + E3_TILE - 1) / E3_TILE;
-    vp.gy = (H + E3_TILE - 1) / E3_TILE;
-    const int ntiles = vp.gx * vp.gy;
+// Forward is split in two enqueue-only halves around the instance count: `begin` ends with an async copy
+// of the count to host memory, the caller synchronises and `finish` sizes the binning buffers with it
+// (the one-call e3dgs_rasterize_forward = begin + stream sync + finish).
+int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn img_alloc, void* img_user,
+                          const ViewBatch& views, int P, int D, int M, int W, int H, const float* means3D,
+                          const float* shs, const float* colors, const float* opac, const float* scales,
+                          float scale_modifier, const float* rots, const float* cov_pre, int* radii, int debug,
+                          int flags, int* count_host, hipStream_t s) {
+    const ViewSet vs = make_view_set(views, W, H, scale_modifier);
+    const int nv = vs.n;
+    const int ntiles = vs.v[0].gx * vs.v[0].gy;
     const size_t npix = (size_t)W * H;
+    const size_t Q = (size_t)P * nv;             // splats
 
-    char* gp = geom_alloc(geom_user, GeomState::required(P));
-    char* ip = img_alloc(img_user, ImageState::required(npix, ntiles));
+    char* gp = geom_alloc(geom_user, GeomState::required(Q));
+    char* ip = img_alloc(img_user, ImageState::required(npix * nv, (size_t)ntiles * nv));
     if (!gp || !ip) return e3_fail(hipErrorOutOfMemory, "scratch allocation callback returned NULL");
-    GeomState geom = GeomState::from(gp, P);
-    ImageState img = ImageState::from(ip, npix, ntiles);
-    HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * sizeof(uint2), s));
+    GeomState geom = GeomState::from(gp, Q);
+    ImageState img = ImageState::from(ip, npix * nv, (size_t)ntiles * nv);
+    HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
     *count_host = 0;
     if (P > 0) {
         const unsigned pb = (unsigned)((P + 255) / 256);
         {
         ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
-                                                         vp, flags, radii, geom.rec, geom.clamped,
+                                                         vs, flags, radii, geom.rec, geom.clamped,
                                                          geom.rect, geom.key0, geom.ord0);
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
         {
         ProfScope ps(PS_SORT_DEPTH, s);
-        launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, (size_t)P, 32, geom.scratch, &keys_sorted,
+        launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, 32, geom.scratch, &keys_sorted,
                                 &order, s);
         }
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
-        const unsigned nwaves = (unsigned)((P + WAVE - 1) / WAVE);
+        const unsigned nwaves = (unsigned)((Q + WAVE - 1) / WAVE);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         HIP_OK(hipMemsetAsync(geom.offsets, 0, sizeof(uint32_t), s));
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, order, geom.rect, geom.rec, vp.gx,
-                                                                     g_tile_cull, nullptr, geom.tiles, nullptr, nullptr,
-                                                                     nullptr, nullptr, geom.cnt, nullptr);
+        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nv, ntiles, order, geom.rect, geom.rec,
+                                                                     vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
+                                                                     nullptr, nullptr, nullptr, nullptr, geom.cnt,
+                                                                     nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
-        // slots: exclusive scan of the per-Gaussian kept counts in INDEX order
-        launch_exclusive_scan_u32(geom.cnt, geom.slot, (size_t)P, geom.scratch, false, s);
+        // slots: exclusive scan of the per-splat kept counts in INDEX order
+        launch_exclusive_scan_u32(geom.cnt, geom.slot, Q, geom.scratch, false, s);
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back
@@ -610,32 +620,35 @@ int e3_forward_begin_impl(char* (*geom_alloc)(void*, size_t), void* geom_user, c
     return 0;
 }
 
-int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, int P, int W, int H,
+int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
                            float* out_color, int debug, hipStream_t s) {
     const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
-    const int ntiles = gx * gy;
+    const int tiles_per_view = gx * gy;
+    const int ntiles = tiles_per_view * nviews;
+    const size_t Q = (size_t)P * nviews;
     const uint32_t I = (uint32_t)num_rendered;
     char* gp = geom_buffer;
     char* ip = image_buffer;
-    GeomState geom = GeomState::from(gp, P);
-    ImageState img = ImageState::from(ip, (size_t)W * H, ntiles);
+    GeomState geom = GeomState::from(gp, Q);
+    ImageState img = ImageState::from(ip, (size_t)W * H * nviews, ntiles);
     char* bp = bin_alloc(bin_user, BinningState::required(I));
     if (!bp) return e3_fail(hipErrorOutOfMemory, "binning allocation callback returned NULL");
     BinningState bin = BinningState::from(bp, I);
     if (I > 0) {
         const int tile_bits = ceil_log2((uint32_t)ntiles);
         const int passes = radix_passes(tile_bits);
-        // choose the emit target so that the final sorted values (emission indices) land in bin.perm
+        // choose the emit target so that the final sorted values (slot indices) land in bin.perm
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.perm, *v1 = bin.vals_alt;
         if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
-        const unsigned nwaves = (unsigned)((P + WAVE - 1) / WAVE);
+        const unsigned nwaves = (unsigned)((Q + WAVE - 1) / WAVE);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(P, geom.ord0, geom.rect, geom.rec, gx,
-                                                                    g_tile_cull, geom.offsets, nullptr, k0, v0, bin.emit_gid,
-                                                                    geom.run, nullptr, geom.slot);
+        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nviews, tiles_per_view, geom.ord0,
+                                                                    geom.rect, geom.rec, gx, g_tile_cull, geom.offsets,
+                                                                    nullptr, k0, v0, bin.emit_gid, geom.run, nullptr,
+                                                                    geom.slot);
         }
         KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
@@ -658,7 +671,7 @@ int e3_forward_finish_impl(char* (*bin_alloc)(void*, size_t), void* bin_user, in
     KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        g_trace, ntiles, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
+        g_trace, ntiles, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
         out_color, img.final_T, img.n_contrib, img.work);
     KERNEL_OK("render_fwd_kernel");
     return 0;

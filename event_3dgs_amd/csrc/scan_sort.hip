@@ -335,6 +335,11 @@ static bool use_onesweep() {
     if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
+static size_t onesweep_max_blocks() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP_MAX_BLOCKS"); v = e ? atol(e) : 1024; }
+    return (size_t)v;
+}
 
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                              uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s) {
@@ -342,7 +347,7 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
     const int passes = radix_passes(nbits);
     // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
     // for the multi-million instance sort the plain three-kernel pass is faster on this chip
-    if (n > 0 && use_onesweep() && passes <= 4 && sort_blocks(n) <= 512) {
+    if (n > 0 && use_onesweep() && passes <= 4 && sort_blocks(n) <= onesweep_max_blocks() && nbits == 32) {
         unsigned nb = (unsigned)sort_blocks(n);
         // scratch: [ghist 4*256][ticket 64 per pass ...][desc passes * nb * 256]
         uint32_t* ghist = scratch;

@@ -264,37 +264,121 @@ def backward_raw(raw, grad_out_color, out, flags=None, grad_acc=None):
     _lib.check(rc, "e3dgs_rasterize_backward")
 
 
-def backward_geom_multi(raws, grad_accs, out, flags):
-    """e3dgs_rasterize_backward_geom_multi: the per-Gaussian backward of all `raws` (forward results of the SAME
-    parameters under different cameras, each already through backward_raw(..., FLAG_BWD_ONLY_RENDER)) in one
-    pass.  `out` maps means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are
-    fully overwritten with the gradient summed over the views."""
+# ---------------------------------------------------------------- several views of the same Gaussians in one pass
+def _view_arrays(settings_list):
+    """Host arrays for the multi-view entry points + the tensors that must stay alive."""
     import ctypes as C
+    n = len(settings_list)
+    views = [_prep(rs.viewmatrix, "viewmatrix") for rs in settings_list]
+    projs = [_prep(rs.projmatrix, "projmatrix") for rs in settings_list]
+    camps = [_prep(rs.campos, "campos") for rs in settings_list]
+    pp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    tx = (C.c_float * n)(*[float(rs.tanfovx) for rs in settings_list])
+    ty = (C.c_float * n)(*[float(rs.tanfovy) for rs in settings_list])
+    return (pp(views), pp(projs), pp(camps), tx, ty), (views, projs, camps)
+
+
+def _check_same_frame(settings_list):
+    r0 = settings_list[0]
+    for rs in settings_list[1:]:
+        if (int(rs.image_height), int(rs.image_width)) != (int(r0.image_height), int(r0.image_width)) or \
+                float(rs.scale_modifier) != float(r0.scale_modifier) or int(rs.sh_degree) != int(r0.sh_degree):
+            raise ValueError("the views of one multi-view call share resolution, scale_modifier and SH degree")
+
+
+def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags=0, count_host=None):
+    """Enqueue-only first half of e3dgs_rasterize_forward_multi for len(settings_list) cameras (same frame size,
+    background of settings_list[0]).  `count_host`: pinned int32[1] receiving the total instance count."""
     L = _lib.lib()
-    n = len(raws)
-    r0 = raws[0]
-    means3D, sh, colors, scales, rots, cov = r0["inputs"]
-    if colors is not None or cov is not None:
-        raise ValueError("backward_geom_multi needs shs + scales + rotations")
+    _check_same_frame(settings_list)
+    rs = settings_list[0]
+    n = len(settings_list)
+    dev = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D_c, sh_c, opac_c = _prep(means3D, "means3D"), _prep(sh, "shs"), _prep(opacities, "opacities")
+    scales_c, rots_c = _prep(scales, "scales"), _prep(rotations, "rotations")
+    bg = _prep(rs.bg, "bg")
+    M = sh_c.shape[0] // 3 if (flags & _lib.FLAG_SH_PLANAR) else sh_c.shape[1]
+    if count_host is None:
+        count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    arrays, keep = _view_arrays(settings_list)
+    radii = torch.empty(n, P, dtype=torch.int32, device=dev)
+    geom, img = _Scratch(dev), _Scratch(dev)
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_rasterize_forward_multi_begin(
+            geom.cb, None, img.cb, None, n, P, int(rs.sh_degree), M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), None,
+            _lib.ptr(opac_c), _lib.ptr(scales_c), float(rs.scale_modifier), _lib.ptr(rots_c), None, *arrays,
+            _lib.ptr(radii), int(bool(rs.debug)), int(flags), count_host.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_forward_multi_begin")
+    return PendingForward(rs=rs, settings_list=list(settings_list), n=n, flags=int(flags), P=P, W=W, H=H, M=M,
+                          radii=radii, geom=geom.tensor, image=img.tensor,
+                          inputs=(means3D_c, sh_c, None, scales_c, rots_c, None), opacities=opac_c, bg=bg, keep=keep,
+                          count_host=count_host, device=dev)
+
+
+def forward_multi_finish(pending):
+    """Second half; the caller has synchronised the stream since forward_multi_begin().  Returns a dict like
+    forward_raw's with color (n,3,H,W) and radii (n,P)."""
+    L = _lib.lib()
+    p = pending
+    I = int(p.count_host[0])
+    out_color = torch.empty(p.n, 3, p.H, p.W, dtype=torch.float32, device=p.device)
+    binning = _Scratch(p.device)
+    with torch.cuda.device(p.device):
+        rc = L.e3dgs_rasterize_forward_multi_finish(binning.cb, None, p.n, p.P, p.W, p.H, _lib.ptr(p.bg),
+                                                    _lib.ptr(p.geom), _lib.ptr(p.image), I, _lib.ptr(out_color),
+                                                    int(bool(p.rs.debug)), _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_forward_multi_finish")
+    return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, settings_list=p.settings_list,
+                flags=p.flags, inputs=p.inputs, opacities=p.opacities, bg=p.bg, keep=p.keep, geom=p.geom,
+                binning=binning.tensor, image=p.image)
+
+
+def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flags=0):
+    """begin + synchronise + finish."""
+    pend = forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags)
+    torch.cuda.current_stream(means3D.device).synchronize()
+    return forward_multi_finish(pend)
+
+
+def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
+    """e3dgs_rasterize_backward_multi for a forward_multi result.  grad_out_color is (n,3,H,W); `out` maps
+    means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are fully overwritten
+    with the gradient summed over the views."""
+    L = _lib.lib()
+    rs = raw["settings"]
+    sl = raw["settings_list"]
+    flags = raw["flags"] if flags is None else flags
+    means3D, sh, _, scales, rots, _ = raw["inputs"]
+    dev = means3D.device
     P = means3D.shape[0]
     if P == 0:
+        for t in out.values():
+            if t is not None:
+                t.zero_()
         return
-    vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-    Ws = (C.c_int * n)(*[int(r["settings"].image_width) for r in raws])
-    Hs = (C.c_int * n)(*[int(r["settings"].image_height) for r in raws])
-    tx = (C.c_float * n)(*[float(r["settings"].tanfovx) for r in raws])
-    ty = (C.c_float * n)(*[float(r["settings"].tanfovy) for r in raws])
-    rs = r0["settings"]
-    with torch.cuda.device(means3D.device):
-        rc = L.e3dgs_rasterize_backward_geom_multi(
-            n, P, int(rs.sh_degree), r0["M"], _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(r0.get("opacities")),
-            _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots), Ws, Hs,
-            vp([r["consts"][1] for r in raws]), vp([r["consts"][2] for r in raws]), vp([r["consts"][3] for r in raws]),
-            tx, ty, vp([r["radii"] for r in raws]), vp([r["geom"] for r in raws]), vp(grad_accs),
-            _lib.ptr(out.get("means2D")), _lib.ptr(out.get("opacities")), _lib.ptr(out.get("means3D")),
-            _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")), _lib.ptr(out.get("rots")),
-            int(bool(rs.debug)), int(flags), _lib.current_stream())
-    _lib.check(rc, "e3dgs_rasterize_backward_geom_multi")
+    H, W = int(rs.image_height), int(rs.image_width)
+    g = grad_out_color
+    if g.dtype != torch.float32:
+        g = g.float()
+    g = g.contiguous()
+    if tuple(g.shape) != (len(sl), 3, H, W):
+        raise ValueError("grad_out_color must be (nviews,3,H,W)")
+    if grad_acc is None:
+        grad_acc = torch.empty(max(int(raw["num_rendered"]), 1), _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
+    arrays, keep = _view_arrays(sl)
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_rasterize_backward_multi(
+            len(sl), P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(raw["bg"]), W, H, _lib.ptr(means3D),
+            _lib.ptr(sh), _lib.ptr(raw.get("opacities")), _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots),
+            *arrays, _lib.ptr(raw["radii"]), _lib.ptr(raw["geom"]), _lib.ptr(raw["binning"]), _lib.ptr(raw["image"]),
+            _lib.ptr(g), _lib.ptr(grad_acc), _lib.ptr(out.get("means2D")), _lib.ptr(out.get("opacities")),
+            _lib.ptr(out.get("means3D")), _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")),
+            _lib.ptr(out.get("rots")), int(bool(rs.debug)), int(flags), _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_backward_multi")
 
 
 class GaussianRasterizer(nn.Module):

@@ -61,7 +61,7 @@ class EventTrainer:
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
-                 track_densification_stats=False, multi_stream=True):
+                 track_densification_stats=False):
         self.device = torch.device(device)
         self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
@@ -73,8 +73,6 @@ class EventTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.track_stats = track_densification_stats
-        self.multi_stream = multi_stream
-        self._streams = None
         zeros = lambda t: torch.zeros_like(t)
         groups = {"xyz": params["xyz"], "f_dc": params["features_dc"], "f_rest": params["features_rest"],
                   "opacity": params["opacity"], "scaling": params["scaling"], "rotation": params["rotation"]}
@@ -122,8 +120,6 @@ class EventTrainer:
         self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if self.track_stats else None
         self._loss_bufs = None
         self._counts = None
-        self._accs = None
-        self._streams = None
         self.last_radii = None
         self.last_scalars = None
 
@@ -181,73 +177,40 @@ class EventTrainer:
 
     def step(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
         """One event iteration (train.py:97-332 without densification).  Returns the device scalars tensor of
-        the loss kernel ([0] = loss).  The three views run on three HIP streams: their many small
-        latency-bound kernels (sort passes, scans) and the drain phases of the compositing kernels overlap with
-        each other; only the accumulating per-Gaussian backward is serialised.  One host wait per iteration
-        (the three instance counts)."""
+        the loss kernel ([0] = loss).  The three renders are ONE multi-view pass of the rasteriser (every kernel
+        of the pipeline runs once over the three cameras), forward and backward; one host wait per iteration
+        (the instance count)."""
         self.iteration += 1
         it = self.iteration
         main = torch.cuda.current_stream(self.device)
-        if self._streams is None:
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(3)] if self.multi_stream else [main] * 3
-            self._counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(3)]
-        S = self._streams
+        if self._counts is None:
+            self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
         v = self.views
-        cams = (cam_int, cam_now, cam_next)
-        ev0 = main.record_event()
-        # ---- forward, first half (preprocess, depth sort, tile counting) on the three streams
-        pend = []
-        for k in range(3):
-            with torch.cuda.stream(S[k]):
-                S[k].wait_event(ev0)
-                pend.append(rasterizer.forward_begin(v["xyz"], v["features"], None, v["opacity"], v["scaling"],
-                                                     v["rotation"], None, self._settings(cams[k], bg),
-                                                     flags=self.FWD_FLAGS, count_host=self._counts[k]))
-        for k in range(3):
-            S[k].synchronize()                     # the iteration's only host waits: instance counts are back
-        # ---- forward, second half (binning, tile sort, compositing)
-        raws, accs = [], []
-        for k in range(3):
-            with torch.cuda.stream(S[k]):
-                raws.append(rasterizer.forward_finish(pend[k]))
-                # per-instance gradient records of this view's backward (written in full by the kernel)
-                accs.append(torch.empty(max(raws[k]["num_rendered"], 1), _lib.ACC_STRIDE, dtype=torch.float32,
-                                        device=self.device))
-                main.wait_event(S[k].record_event())
-        if self._loss_bufs is None:
-            img = raws[0]["color"]
-            self._loss_bufs = (torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(img),
-                               torch.empty_like(img), torch.empty_like(img),
-                               torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(img.shape[2], img.shape[1]),
+        settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
+        # ---- the three renders (train.py:144,159,161)
+        pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                              settings, flags=self.FWD_FLAGS, count_host=self._counts)
+        main.synchronize()                         # the iteration's only host wait: the instance count is back
+        raw = rasterizer.forward_multi_finish(pend)
+        imgs = raw["color"]
+        if self._loss_bufs is None or self._loss_bufs[1].shape != imgs.shape:
+            self._loss_bufs = (torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(imgs),
+                               torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(imgs.shape[3], imgs.shape[2]),
                                            dtype=torch.uint8, device=self.device))
-        scalars, d_image, d_now, d_next = losses.event_loss_raw(raws[0]["color"], raws[1]["color"], raws[2]["color"],
-                                                                self.c, gt_int, gt_now, gt_next, gt_blur,
-                                                                out=self._loss_bufs)          # train.py:165-203
-        ev_loss = main.record_event()
+        sc, dpix, scratch = self._loss_bufs
+        scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[1], imgs[2], self.c, gt_int, gt_now, gt_next, gt_blur,
+                                                 out=(sc, dpix[0], dpix[1], dpix[2], scratch))     # train.py:165-203
+        # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
-        dpix = (d_image, d_now, d_next)
-        # ---- loss.backward() (train.py:211): the compositing backward of the three views overlaps ...
-        for k in range(3):
-            with torch.cuda.stream(S[k]):
-                S[k].wait_event(ev_loss)
-                rasterizer.backward_raw(raws[k], dpix[k], out, grad_acc=accs[k],
-                                        flags=self.FWD_FLAGS | _lib.FLAG_BWD_ONLY_RENDER)
-                main.wait_event(S[k].record_event())
-        # ---- ... and ONE per-Gaussian pass sums the three views and writes every gradient element once
-        o = dict(out)
         if self.track_stats:
-            o["means2D"] = self.viewspace_grad              # densification statistics use render #1 only (train.py:145)
-        rasterizer.backward_geom_multi(raws, accs, o, self.FWD_FLAGS)
+            out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
+        rasterizer.backward_multi(raw, dpix, out)
         self.c_grad.copy_(scalars[1:2])
         if self.world > 1 and sync_grads:
             parallel.allreduce_mean_(self.flat_grad, self.pg)      # ONE collective: 59 floats/Gaussian + c
         self._adam(it)
-        if self.multi_stream:
-            ev_end = main.record_event()
-            for k in range(3):
-                S[k].wait_event(ev_end)            # next iteration's forward reads the updated parameters
-        self.last_radii = raws[0]["radii"]
+        self.last_radii = raw["radii"][0]
         self.last_scalars = scalars
         return scalars
 

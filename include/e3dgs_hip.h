@@ -163,27 +163,73 @@ int e3dgs_rasterize_backward(
     void* stream);
 
 /*
- * Per-Gaussian backward of SEVERAL views in one pass (1 <= nviews <= 4).
- * Replaces: the three _RasterizeGaussians.backward calls plus autograd's gradient accumulation that
- * loss.backward() (train.py:211) performs for the three renders of an event iteration
- * (train.py:144,159,161).  Call e3dgs_rasterize_backward with E3DGS_FLAG_BWD_ONLY_RENDER once per view
- * (any streams), then this entry point once: parameters are read once, every gradient element is written
- * exactly once (sum over the views; zeros where no view saw the Gaussian) -- no pre-zeroing, no
- * E3DGS_FLAG_ACCUMULATE read-modify-write, no serialisation of the views.
- * Needs shs + scales + rotations (no colors_precomp / cov3D_precomp).  Flags: PREACT, SH_PLANAR.
- * All `const T* const*` / per-view scalar arguments are HOST arrays of length nviews whose elements are the
- * per-view values e3dgs_rasterize_backward takes.  dL_dmean2D (P,3), optional, receives view 0's
- * screen-space gradient only (densification statistics use render #1, train.py:145).
+ * SEVERAL VIEWS OF THE SAME GAUSSIANS IN ONE PASS (1 <= nviews <= 4, same width x height, same background).
+ *
+ * Replaces: the three rasterize_gaussians calls of one event iteration (train.py:144,159,161 ->
+ * gaussian_renderer/__init__.py:89-97) and, for backward, the three rasterize_gaussians_backward calls plus
+ * autograd's accumulation of their results into .grad that loss.backward() (train.py:211) performs.
+ *
+ * Every stage of the pipeline runs ONCE over all views ("splat" q = i * nviews + v, tile id
+ * v * tiles + ty * gx + tx): nviews times fewer launches, parameters read once, one instance-count
+ * read-back, and the backward writes every gradient element exactly once (sum over the views; zero
+ * where no view saw the Gaussian) -- no pre-zeroing and no E3DGS_FLAG_ACCUMULATE.  Per view the
+ * arithmetic is the single-view arithmetic: image v, radii[v] and the per-view gradients are
+ * bit-identical to nviews separate e3dgs_rasterize_forward / _backward calls.
+ *
+ * viewmatrix / projmatrix / cam_pos are HOST arrays of nviews DEVICE pointers; tan_fovx / tan_fovy are
+ * host arrays of nviews floats.  out_color is (nviews,3,H,W), radii (nviews,P), dL_dpix (nviews,3,H,W).
+ * num_rendered counts the instances of all views.  The scratch buffers of a multi call are laid out for
+ * nviews * P splats (see e3dgs_state_offsets with P * nviews / height * nviews for nviews > 1).
+ * Backward needs shs + scales + rotations (no colors_precomp / cov3D_precomp); flags: PREACT, SH_PLANAR,
+ * BWD_ONLY_RENDER, BWD_ONLY_GEOM.  dL_dmean2D (P,3), optional, receives view 0's screen-space gradient
+ * (densification statistics use render #1 only, train.py:145).
  */
-int e3dgs_rasterize_backward_geom_multi(
+int e3dgs_rasterize_forward_multi(
+    e3dgs_alloc_fn geom_alloc, void* geom_user,
+    e3dgs_alloc_fn binning_alloc, void* binning_user,
+    e3dgs_alloc_fn image_alloc, void* image_user,
     int nviews, int P, int D, int M,
-    const float* means3D, const float* shs, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations,
-    const int* widths, const int* heights,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* opacities, const float* scales, float scale_modifier,
+    const float* rotations, const float* cov3D_precomp,
     const float* const* viewmatrix, const float* const* projmatrix, const float* const* cam_pos,
     const float* tan_fovx, const float* tan_fovy,
-    const int* const* radii, const char* const* geom_buffer, const float* const* grad_acc,
-    float* dL_dmean2D,                /* (P,3) or NULL */
+    float* out_color, int* radii, int debug, int flags,
+    int* num_rendered_host, void* stream);
+
+/* enqueue-only halves (as e3dgs_rasterize_forward_begin / _finish) */
+int e3dgs_rasterize_forward_multi_begin(
+    e3dgs_alloc_fn geom_alloc, void* geom_user,
+    e3dgs_alloc_fn image_alloc, void* image_user,
+    int nviews, int P, int D, int M, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* opacities, const float* scales, float scale_modifier,
+    const float* rotations, const float* cov3D_precomp,
+    const float* const* viewmatrix, const float* const* projmatrix, const float* const* cam_pos,
+    const float* tan_fovx, const float* tan_fovy,
+    int* radii, int debug, int flags,
+    int* num_rendered_host,           /* HOST memory, valid after the stream is synchronised */
+    void* stream);
+
+int e3dgs_rasterize_forward_multi_finish(
+    e3dgs_alloc_fn binning_alloc, void* binning_user,
+    int nviews, int P, int width, int height, const float* background,
+    char* geom_buffer, char* image_buffer, int num_rendered,
+    float* out_color, int debug, void* stream);
+
+int e3dgs_rasterize_backward_multi(
+    int nviews, int P, int D, int M, int num_rendered,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations,
+    const float* const* viewmatrix, const float* const* projmatrix, const float* const* cam_pos,
+    const float* tan_fovx, const float* tan_fovy,
+    const int* radii,
+    const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    const float* dL_dpix,             /* (nviews,3,H,W) */
+    float* grad_acc,                  /* (num_rendered,12) scratch (uninitialised is fine) */
+    float* dL_dmean2D,                /* (P,3) or NULL: view 0 */
     float* dL_dopacity, float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
     int debug, int flags, void* stream);
 

@@ -262,29 +262,32 @@ def test_fit_loop_with_densification_and_eval(tmp_path):
     assert torch.equal(a, b)                                   # the PLY holds the exact pre-activation state
 
 
-@pytest.mark.parametrize("nviews", [1, 2, 4])
-def test_geom_multi_equals_sum_of_single_view_backwards(nviews):
-    """e3dgs_rasterize_backward_geom_multi == sum over views of e3dgs_rasterize_backward (what autograd's
-    accumulation of the per-render backward calls produces at train.py:211).  Views differ in resolution; the
-    gradient buffers start as NaN to prove every element is written."""
+@pytest.mark.parametrize("nviews", [1, 2, 3, 4])
+def test_multi_view_pass_equals_single_view_calls(nviews):
+    """e3dgs_rasterize_forward_multi / _backward_multi against nviews separate single-view calls: images and
+    radii bit-identical; gradients == the sum of the per-view gradients (what autograd's accumulation of the
+    per-render backward calls produces at train.py:211).  Gradient buffers start as NaN to prove every element
+    is written; a second multi pass must reproduce the first bit for bit (no atomics anywhere)."""
     from event_3dgs_amd import _lib, rasterizer
     from event_3dgs_amd.cameras import orbit_camera
     from event_3dgs_amd.train_step import EventTrainer
     params, _ = _scene(N=4000)
-    sizes = [(176, 128), (97, 61), (176, 128), (240, 135)][:nviews]
-    cams = [orbit_camera(k, 16, w, h, device=DEV, daz=0.01 * k) for k, (w, h) in enumerate(sizes)]
+    W, H = 183, 131                                       # not multiples of 16: partial tiles in every view
+    cams = [orbit_camera(k, 16, W, H, device=DEV, daz=0.01 * k) for k in range(nviews)]
     bg = torch.tensor([0.2, 0.1, 0.3], device=DEV)
     tr = EventTrainer(params, DEV)
     v = tr.views
+    settings = [tr._settings(c, bg) for c in cams]
     gen = torch.Generator().manual_seed(5)
-    raws, dpix = [], []
-    for cam in cams:
-        raws.append(tr.render_raw(cam, bg))
-        dpix.append(torch.randn(raws[-1]["color"].shape, generator=gen).to(DEV))
+    dpix = torch.randn(nviews, 3, H, W, generator=gen).to(DEV)
     names = dict(means3D=v["xyz"], sh=v["features"], opacities=v["opacity"], scales=v["scaling"], rots=v["rotation"])
+    # ---- reference: one call per view
     ref = {k: torch.zeros_like(t) for k, t in names.items()}
-    m2d_ref = None
-    for k, raw in enumerate(raws):
+    singles, m2d_ref, total = [], None, 0
+    for k, cam in enumerate(cams):
+        raw = tr.render_raw(cam, bg)
+        singles.append(raw)
+        total += raw["num_rendered"]
         single = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
         single["means2D"] = torch.full((tr.N, 3), float("nan"), device=DEV)
         rasterizer.backward_raw(raw, dpix[k], single, flags=tr.FWD_FLAGS)
@@ -292,14 +295,20 @@ def test_geom_multi_equals_sum_of_single_view_backwards(nviews):
             ref[n] += single[n]
         if k == 0:
             m2d_ref = single["means2D"]
-    accs = []
-    for k, raw in enumerate(raws):
-        accs.append(torch.full((max(raw["num_rendered"], 1), _lib.ACC_STRIDE), float("nan"), device=DEV))
-        rasterizer.backward_raw(raw, dpix[k], {}, grad_acc=accs[k], flags=tr.FWD_FLAGS | _lib.FLAG_BWD_ONLY_RENDER)
-    out = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
-    out["means2D"] = torch.full((tr.N, 3), float("nan"), device=DEV)
-    rasterizer.backward_geom_multi(raws, accs, out, tr.FWD_FLAGS)
-    torch.cuda.synchronize()
+    # ---- one multi-view pass
+    def multi():
+        raw = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
+                                       flags=tr.FWD_FLAGS)
+        out = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
+        out["means2D"] = torch.full((tr.N, 3), float("nan"), device=DEV)
+        rasterizer.backward_multi(raw, dpix, out)
+        torch.cuda.synchronize()
+        return raw, out
+    raw, out = multi()
+    assert raw["num_rendered"] == total
+    for k in range(nviews):
+        assert torch.equal(raw["color"][k], singles[k]["color"]), k
+        assert torch.equal(raw["radii"][k], singles[k]["radii"]), k
     assert torch.equal(out["means2D"], m2d_ref)
     for n in names:
         assert torch.isfinite(out[n]).all(), n
@@ -307,3 +316,24 @@ def test_geom_multi_equals_sum_of_single_view_backwards(nviews):
         assert err < 2e-6, (n, err)                                                # fp32 re-association only
         scale = ref[n].abs().max().item()
         assert (out[n] - ref[n]).abs().max().item() <= 1e-4 * scale + 1e-12, n
+    raw2, out2 = multi()
+    for n in out:
+        assert torch.equal(out[n], out2[n]), n                                     # deterministic gradients
+
+
+def test_multi_view_argument_checks():
+    from event_3dgs_amd import rasterizer
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, _ = _scene(N=500)
+    tr = EventTrainer(params, DEV)
+    v = tr.views
+    bg = torch.zeros(3, device=DEV)
+    cams = [orbit_camera(0, 16, 64, 48, device=DEV), orbit_camera(1, 16, 80, 48, device=DEV)]
+    with pytest.raises(ValueError):        # different frame sizes in one batch
+        rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                 [tr._settings(c, bg) for c in cams], flags=tr.FWD_FLAGS)
+    five = [tr._settings(orbit_camera(k, 16, 64, 48, device=DEV), bg) for k in range(5)]
+    with pytest.raises(Exception, match="nviews"):
+        rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], five,
+                                 flags=tr.FWD_FLAGS)
