@@ -123,6 +123,64 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Final phase shared by both scatter kernels.  On entry wcnt[w][d] holds the per-wave digit counts, pos[r] the
+// rank of each key inside its (wave, digit) group, and thread d knows `gfirst`, the global position of this
+// workgroup's first key with digit d.  Keys are first placed at their workgroup-local sorted position in LDS
+// and then streamed out by consecutive threads, so the lanes of a store instruction write consecutive
+// addresses inside each digit's segment (avg 16 keys = 64 B) instead of 4-key fragments per (wave, digit).
+struct StageLds {
+    uint32_t key[SORT_TILE];
+    uint32_t val[SORT_TILE];
+    uint32_t glob[256];     // global position minus local position, per digit
+    uint32_t wtot[SORT_THREADS / WAVE];
+};
+__device__ __forceinline__ void staged_scatter(const uint32_t (&key)[SORT_ITEMS], const uint32_t (&val)[SORT_ITEMS],
+                                               const uint32_t (&pos)[SORT_ITEMS],
+                                               uint32_t (*wcnt)[256], uint32_t gfirst, size_t block_first, size_t wbase,
+                                               size_t n, int shift, uint32_t* __restrict__ keys_out,
+                                               uint32_t* __restrict__ vals_out, StageLds& L) {
+    constexpr int NW = SORT_THREADS / WAVE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = threadIdx.x;
+    uint32_t c[NW], total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { c[w] = wcnt[w][d]; total += c[w]; }
+    // workgroup-local exclusive scan of the digit totals
+    uint32_t inc = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) L.wtot[wave] = inc;
+    __syncthreads();
+    uint32_t lbase = inc - total;
+    for (int w = 0; w < wave; ++w) lbase += L.wtot[w];
+    L.glob[d] = gfirst - lbase;
+    uint32_t l = lbase;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { wcnt[w][d] = l; l += c[w]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        size_t idx = wbase + (size_t)r * WAVE + lane;
+        if (idx < n) {
+            uint32_t dg = (key[r] >> shift) & 255u;
+            uint32_t lp = wcnt[wave][dg] + pos[r];
+            L.key[lp] = key[r];
+            L.val[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = (uint32_t)((n - block_first) < (size_t)SORT_TILE ? (n - block_first) : (size_t)SORT_TILE);
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        uint32_t lp = (uint32_t)j * SORT_THREADS + threadIdx.x;
+        if (lp < nvalid) {
+            uint32_t k = L.key[lp];
+            uint32_t dst = L.glob[(k >> shift) & 255u] + lp;
+            keys_out[dst] = k;
+            vals_out[dst] = L.val[lp];
+        }
+    }
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
@@ -132,6 +190,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     constexpr int NW = SORT_THREADS / WAVE;          // 4 waves
     constexpr int WAVE_KEYS = SORT_TILE / NW;        // 1024 consecutive keys per wave
     __shared__ uint32_t wcnt[NW][256];
+    __shared__ StageLds stage;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < NW; ++w) wcnt[w][threadIdx.x] = 0;
@@ -168,26 +227,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         pos[r] = basep + before;
     }
     __syncthreads();
-    {   // digit = threadIdx.x: turn per-wave counts into global bases
-        uint32_t g = offs[(size_t)threadIdx.x * nblocks + blockIdx.x];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            uint32_t c = wcnt[w][threadIdx.x];
-            wcnt[w][threadIdx.x] = g;
-            g += c;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        size_t idx = wbase + (size_t)r * WAVE + lane;
-        if (idx < n) {
-            uint32_t d = (key[r] >> shift) & 255u;
-            uint32_t dst = wcnt[wave][d] + pos[r];
-            keys_out[dst] = key[r];
-            vals_out[dst] = val[r];
-        }
-    }
+    // digit = threadIdx.x: offs holds the global position of this workgroup's first key of each digit
+    staged_scatter(key, val, pos, wcnt, offs[(size_t)threadIdx.x * nblocks + blockIdx.x],
+                   (size_t)blockIdx.x * SORT_TILE, wbase, n, shift, keys_out, vals_out, stage);
 }
 
 // ------------------------------------------------------------------------------------ onesweep variant
@@ -228,9 +270,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
     constexpr int NW = SORT_THREADS / WAVE;
     constexpr int WAVE_KEYS = SORT_TILE / NW;
     __shared__ uint32_t wcnt[NW][256];
-    __shared__ uint32_t sbase[256];
     __shared__ uint32_t wtot[NW];
     __shared__ uint32_t s_bid;
+    __shared__ StageLds stage;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
 #pragma unroll
@@ -268,6 +310,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
         pos[r] = basep + before;
     }
     __syncthreads();
+    uint32_t gfirst;
     {
         // digit = threadIdx.x
         const int d = threadIdx.x;
@@ -312,22 +355,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
         __syncthreads();
         uint32_t dbase = inc - gh;
         for (int w = 0; w < wave; ++w) dbase += wtot[w];
-        uint32_t g = dbase + excl;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { wcnt[w][d] = g; g += c[w]; }
+        gfirst = dbase + excl;
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        size_t idx = wbase + (size_t)r * WAVE + lane;
-        if (idx < n) {
-            uint32_t d = (key[r] >> shift) & 255u;
-            uint32_t dst = wcnt[wave][d] + pos[r];
-            keys_out[dst] = key[r];
-            vals_out[dst] = val[r];
-        }
-    }
-    (void)sbase;
+    staged_scatter(key, val, pos, wcnt, gfirst, (size_t)bid * SORT_TILE, wbase, n, shift, keys_out, vals_out, stage);
 }
 
 static bool use_onesweep() {
