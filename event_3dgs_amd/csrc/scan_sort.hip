@@ -366,6 +366,11 @@ static bool use_onesweep() {
     if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
+static bool onesweep_small_keys() {     // tile-id sort (few bits, millions of pairs): classic passes by default
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP_TILE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v != 0;
+}
 static size_t onesweep_max_blocks() {
     static long v = -1;
     if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP_MAX_BLOCKS"); v = e ? atol(e) : 1024; }
@@ -378,7 +383,7 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
     const int passes = radix_passes(nbits);
     // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
     // for the multi-million instance sort the plain three-kernel pass is faster on this chip
-    if (n > 0 && use_onesweep() && passes <= 4 && sort_blocks(n) <= onesweep_max_blocks() && nbits == 32) {
+    if (n > 0 && use_onesweep() && passes <= 4 && (nbits == 32 ? sort_blocks(n) <= onesweep_max_blocks() : onesweep_small_keys())) {
         unsigned nb = (unsigned)sort_blocks(n);
         // scratch: [ghist 4*256][ticket 64 per pass ...][desc passes * nb * 256]
         uint32_t* ghist = scratch;
