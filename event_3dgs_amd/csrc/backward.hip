@@ -304,17 +304,51 @@ __device__ __forceinline__ void build_cov3(const float sact[3], float scale_modi
     S[5] = FMA(L[2][0], L[2][0], FMA(L[2][1], L[2][1], L[2][2] * L[2][2]));
 }
 
-// Sum a Gaussian's per-instance records (contiguous in emission order; fixed order -> deterministic).
-__device__ __forceinline__ void sum_run(const uint2 rn, const float* __restrict__ part, float g12[9]) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) g12[k] = 0.0f;
-    const float4* pr = reinterpret_cast<const float4*>(part + E3_ACC_STRIDE * (size_t)rn.x);
-    for (uint32_t k = 0; k < rn.y; ++k) {
-        const float4 q0 = pr[3 * k], q1 = pr[3 * k + 1];
-        const float q2 = pr[3 * k + 2].x;
-        g12[0] += q0.x; g12[1] += q0.y; g12[2] += q0.z; g12[3] += q0.w;
-        g12[4] += q1.x; g12[5] += q1.y; g12[6] += q1.z; g12[7] += q1.w; g12[8] += q2;
+// Per-splat sums of the per-instance gradient records.  Slots are Gaussian-major in index order, so the 256
+// splats of a workgroup own ONE contiguous slot range: it is streamed through LDS with fully coalesced 16-byte
+// loads (256 records per chunk) and every thread adds the records of its own run from LDS, in slot order
+// (fixed order -> deterministic).  Output: 3 float4 per splat, (mx my A B | C o c0 c1 | c2 - - -).
+constexpr int RR_CHUNK = 256;
+__global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint2* __restrict__ run,
+                                                         const float* __restrict__ part, float4* __restrict__ gsum) {
+    __shared__ float4 sbuf[3 * RR_CHUNK];
+    __shared__ uint32_t sRange[2];
+    const uint32_t t = threadIdx.x, q0 = blockIdx.x * 256u, q = q0 + t;
+    const uint32_t qlast = (Q < q0 + 256u ? Q : q0 + 256u) - 1u;
+    const uint2 rn = q < Q ? run[q] : make_uint2(0u, 0u);
+    if (t == 0) sRange[0] = rn.x;
+    if (q == qlast) sRange[1] = rn.x + rn.y;
+    __syncthreads();
+    const uint32_t S0 = sRange[0], S1 = sRange[1];
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = make_float4(0, 0, 0, 0);
+    float a2 = 0.0f;
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part);
+    for (uint32_t c0 = S0; c0 < S1; c0 += RR_CHUNK) {
+        const uint32_t nrec = (S1 - c0 < (uint32_t)RR_CHUNK) ? S1 - c0 : (uint32_t)RR_CHUNK;
+        for (uint32_t i = t; i < 3u * nrec; i += 256u) sbuf[i] = p4[3 * (size_t)c0 + i];
+        __syncthreads();
+        const uint32_t lo = rn.x > c0 ? rn.x : c0;
+        const uint32_t end = rn.x + rn.y, cend = c0 + nrec;
+        const uint32_t hi = end < cend ? end : cend;
+        for (uint32_t r = lo; r < hi; ++r) {
+            const float4 s0 = sbuf[3 * (r - c0)], s1 = sbuf[3 * (r - c0) + 1];
+            const float s2 = sbuf[3 * (r - c0) + 2].x;
+            a0.x += s0.x; a0.y += s0.y; a0.z += s0.z; a0.w += s0.w;
+            a1.x += s1.x; a1.y += s1.y; a1.z += s1.z; a1.w += s1.w;
+            a2 += s2;
+        }
+        __syncthreads();
     }
+    if (q < Q) {
+        gsum[3 * (size_t)q] = a0; gsum[3 * (size_t)q + 1] = a1; gsum[3 * (size_t)q + 2] = make_float4(a2, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+__device__ __forceinline__ void load_sums(const float4* __restrict__ gsum, size_t q, float g12[9]) {
+    const float4 s0 = gsum[3 * q], s1 = gsum[3 * q + 1];
+    const float s2 = gsum[3 * q + 2].x;
+    g12[0] = s0.x; g12[1] = s0.y; g12[2] = s0.z; g12[3] = s0.w;
+    g12[4] = s1.x; g12[5] = s1.y; g12[6] = s1.z; g12[7] = s1.w; g12[8] = s2;
 }
 
 // One view: conic -> Sigma2 -> (Sigma3, view-space mean) and NDC mean -> world mean.
@@ -428,7 +462,7 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
     const float* __restrict__ cov_pre, ViewParams vp, int flags, const int* __restrict__ radii,
-    const uint32_t* __restrict__ clamped, const uint2* __restrict__ run, const float* __restrict__ part,
+    const uint32_t* __restrict__ clamped, const float4* __restrict__ gsum,
     float* dL_dmean2D, float* dL_dopacity,
     float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,7 +487,7 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
         return;
     }
     float g12[9];
-    sum_run(run[i], part, g12);
+    load_sums(gsum, (size_t)i, g12);
     float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     Cov3 cv;
     float qr = 0, qx = 0, qy = 0, qz = 0, qinv = 1.0f;
@@ -514,8 +548,7 @@ struct MultiViews {
     ViewSet vs;
     const int* radii;          // (n, P)
     const uint32_t* clamped;   // per splat q = i * n + v
-    const uint2* run;          // per splat
-    const float* part;         // per-instance records (all views)
+    const float4* gsum;        // per splat: summed gradient records (run_reduce_kernel)
 };
 
 // real SH basis function k and its gradient w.r.t. the unit direction (same constants as sh_backward)
@@ -597,7 +630,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             const ViewParams& vp = mv.vs.v[v];
             const size_t q = (size_t)i * nv + v;
             float g12[9], gcv[6], gmv[3];
-            sum_run(mv.run[q], mv.part, g12);
+            load_sums(mv.gsum, q, g12);
             view_geom_backward(vp, mx, my, mz, cv.S, g12, gcv, gmv);
 #pragma unroll
             for (int k = 0; k < 6; ++k) gcov[k] += gcv[k];
@@ -718,18 +751,22 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;
     {
     ProfScope ps(PS_GEOM_BWD, s);
+    // per-splat sums live behind the instance records in the caller's scratch: grad_acc is (num_rendered + Q, 12)
+    float4* gsum = reinterpret_cast<float4*>(grad_acc + E3_ACC_STRIDE * (size_t)num_rendered);
+    if (num_rendered > 0)
+        run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.run, grad_acc, gsum);
     if (nv == 1 && (flags & E3_FLAG_ACCUMULATE))
         geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, geom.run,
-            grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,
+            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     else if (nv == 1)
         geom_bwd_kernel<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, geom.run,
-            grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,
+            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     else {
         // several views: one pass, every gradient element written once (capi.hip checked the argument subset)
         MultiViews mv;
-        mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.run = geom.run; mv.part = grad_acc;
+        mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.gsum = gsum;
         geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
             dL_dscale, dL_drot);

@@ -249,8 +249,8 @@ def backward_raw(raw, grad_out_color, out, flags=None, grad_acc=None):
     if g.dtype != torch.float32:
         g = g.float()
     g = g.contiguous()
-    if grad_acc is None:      # one record per (tile, Gaussian) instance; the kernel writes every one of them
-        grad_acc = torch.empty(max(int(raw["num_rendered"]), 1), _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
+    if grad_acc is None:      # one record per (tile, Gaussian) instance + one sum per Gaussian; all written by the op
+        grad_acc = torch.empty(int(raw["num_rendered"]) + P, _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = L.e3dgs_rasterize_backward(
             P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(bg), W, H, _lib.ptr(means3D), _lib.ptr(sh),
@@ -368,7 +368,8 @@ def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
     if tuple(g.shape) != (len(sl), 3, H, W):
         raise ValueError("grad_out_color must be (nviews,3,H,W)")
     if grad_acc is None:
-        grad_acc = torch.empty(max(int(raw["num_rendered"]), 1), _lib.ACC_STRIDE, dtype=torch.float32, device=dev)
+        grad_acc = torch.empty(int(raw["num_rendered"]) + len(sl) * P, _lib.ACC_STRIDE, dtype=torch.float32,
+                               device=dev)
     arrays, keep = _view_arrays(sl)
     with torch.cuda.device(dev):
         rc = L.e3dgs_rasterize_backward_multi(

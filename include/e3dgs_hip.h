@@ -127,11 +127,12 @@ int e3dgs_rasterize_forward_finish(
  * diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
  * loss.backward() at train.py:211 through _RasterizeGaussians.backward.
  *
- * grad_acc (num_rendered,12) is caller-owned scratch and needs NO initialisation: the compositing backward
- * stores one record per (tile, Gaussian) instance (dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad) at the
- * instance's emission position -- every record exactly once, plain stores, no float atomics -- and the
- * per-Gaussian stage sums each Gaussian's contiguous run in a fixed order, so gradients are bit-reproducible
- * run to run (the reference's atomics are not).
+ * grad_acc (num_rendered + P,12) floats is caller-owned scratch and needs NO initialisation (for the multi-view
+ * entry point: (num_rendered + nviews*P,12)): the compositing backward stores one record per (tile, Gaussian)
+ * instance (dmean2D.xy, dconic.xyz, dopacity, dcolor.rgb, 3 pad) at the instance's slot -- every record exactly
+ * once, plain stores, no float atomics; a streaming pass then sums each Gaussian's contiguous run of records
+ * in a fixed order into the P trailing rows, so gradients are bit-reproducible run to run (the reference's
+ * atomics are not).  With BWD_ONLY_RENDER / BWD_ONLY_GEOM the same buffer must be passed to both calls.
  * Without E3DGS_FLAG_ACCUMULATE every other output is written in full (zeros for culled
  * Gaussians), so nothing else needs pre-zeroing.  dL_dmean2D is (P,3): first two components in
  * NDC units (consumed by scene/gaussian_model.py:405-407), third 0; always overwritten.
@@ -149,7 +150,7 @@ int e3dgs_rasterize_backward(
     const int* radii,
     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
     const float* dL_dpix,             /* (3,H,W) */
-    float* grad_acc,                  /* (num_rendered,12) scratch (uninitialised is fine) */
+    float* grad_acc,                  /* (num_rendered + P,12) scratch (uninitialised is fine) */
     float* dL_dmean2D,                /* (P,3) or NULL */
     float* dL_dopacity,               /* (P) or NULL */
     float* dL_dcolor,                 /* (P,3) or NULL */
@@ -228,7 +229,7 @@ int e3dgs_rasterize_backward_multi(
     const int* radii,
     const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
     const float* dL_dpix,             /* (nviews,3,H,W) */
-    float* grad_acc,                  /* (num_rendered,12) scratch (uninitialised is fine) */
+    float* grad_acc,                  /* (num_rendered + nviews*P,12) scratch (uninitialised is fine) */
     float* dL_dmean2D,                /* (P,3) or NULL: view 0 */
     float* dL_dopacity, float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
     int debug, int flags, void* stream);
