@@ -90,8 +90,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewSet vs, int flags,
     int* __restrict__ radii,
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
-    uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord) {
+    uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord,
+    uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // housekeeping that would otherwise be two memset commands (each costs a barrier packet on the queue)
+    for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
+    if (i == 0) *offsets0 = 0u;
     if (i >= P) return;
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     float S[6];
@@ -580,7 +584,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     if (!gp || !ip) return e3_fail(hipErrorOutOfMemory, "scratch allocation callback returned NULL");
     GeomState geom = GeomState::from(gp, Q);
     ImageState img = ImageState::from(ip, npix * nv, (size_t)ntiles * nv);
-    HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
+    if (P <= 0) HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
     *count_host = 0;
     if (P > 0) {
         const unsigned pb = (unsigned)((P + 255) / 256);
@@ -588,7 +592,8 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
                                                          vs, flags, radii, geom.rec, geom.clamped,
-                                                         geom.rect, geom.key0, geom.ord0);
+                                                         geom.rect, geom.key0, geom.ord0, img.ranges, ntiles * nv,
+                                                         geom.offsets);
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
@@ -601,7 +606,6 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
         const unsigned nwaves = (unsigned)((Q + WAVE - 1) / WAVE);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
-        HIP_OK(hipMemsetAsync(geom.offsets, 0, sizeof(uint32_t), s));
         {
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nv, ntiles, order, geom.rect, geom.rec,

@@ -162,12 +162,28 @@ class EventTrainer:
         self.import_groups(groups)
 
     # ---- raster settings for one view (gaussian_renderer/__init__.py:35-51)
+    @staticmethod
+    def _camera_tensors(cam):
+        """Contiguous copies of the camera's (strided, scene/cameras.py:54-57) matrices, made once per camera
+        instead of once per step (three tiny copy kernels per rasteriser call otherwise)."""
+        src = (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        cached = getattr(cam, "_e3dgs_contig", None)
+        if cached is None or cached[0] != key:
+            cached = (key, tuple(t.contiguous() for t in src))
+            try:
+                cam._e3dgs_contig = cached
+            except AttributeError:       # cameras with __slots__ / namedtuples: no caching
+                pass
+        return cached[1]
+
     def _settings(self, cam, bg, scaling_modifier=1.0):
+        view, proj, campos = self._camera_tensors(cam)
         return GaussianRasterizationSettings(
             image_height=int(cam.image_height), image_width=int(cam.image_width),
             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg,
-            scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
-            sh_degree=self.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+            scale_modifier=scaling_modifier, viewmatrix=view, projmatrix=proj,
+            sh_degree=self.active_sh_degree, campos=campos, prefiltered=False, debug=False)
 
     def render_raw(self, cam, bg):
         """Forward only, fused activations.  Returns the forward_raw dict (image in ["color"])."""
