@@ -202,7 +202,10 @@ __device__ __forceinline__ uint32_t rect_area(uint2 r) {
 // minimum exceeds the bound by a safety margin (1e-4 of the summed |terms| + an absolute slack folded
 // into `thr` by the caller, orders of magnitude above fp32 rounding) contribute to no pixel, so dropping them leaves image and gradients
 // bit-identical while shrinking the sorted lists (~1.8x on the benchmark scene).
-__device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float B, float C, float thr, int tx, int ty) {
+__device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float B, float C, float thr, float iC,
+                                             float iA, int tx, int ty) {
+    // iC = -B / C, iA = -B / A: computed once per Gaussian by the caller (three IEEE divisions per candidate
+    // tile were a third of the binning kernels' instruction count)
     if (!(A > 0.0f) || !(C > 0.0f)) return true;   // degenerate / NaN conic: never cull
     const float pxl = (float)(tx * E3_TILE), pyl = (float)(ty * E3_TILE);
     const float dxlo = x0 - (pxl + (float)(E3_TILE - 1)), dxhi = x0 - pxl;
@@ -214,7 +217,6 @@ __device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float 
             float t0 = A * dx * dx, t1 = B2 * dx * dy, t2 = C * dy * dy;
             return (t0 + t1 + t2) - 1e-4f * (fabsf(t0) + fabsf(t1) + fabsf(t2));
         };
-        const float iC = -B / C, iA = -B / A;
         float q0 = qadj(dxlo, fminf(dyhi, fmaxf(dylo, iC * dxlo)));
         float q1 = qadj(dxhi, fminf(dyhi, fmaxf(dylo, iC * dxhi)));
         float q2 = qadj(fminf(dxhi, fmaxf(dxlo, iA * dylo)), dylo);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
     __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
     __shared__ uint32_t sIncl[BIN_WAVES][WAVE];
     __shared__ uint32_t sId[BIN_WAVES][WAVE];
-    __shared__ uint32_t sBase[BIN_WAVES][WAVE];  // first tile id of the splat's view
+    __shared__ float4 sD[BIN_WAVES][WAVE];       // -B/C, -B/A, 1/width, first tile id of the splat's view
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * BIN_WAVES + wave;
     const int s = gw * WAVE + lane;
@@ -280,7 +282,12 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
     }
     const uint32_t total = __shfl(incl, 63, 64);
     sA[wave][lane] = a; sB[wave][lane] = b; sIncl[wave][lane] = incl; sId[wave][lane] = g;
-    sBase[wave][lane] = nviews > 1 ? (g % (uint32_t)nviews) * (uint32_t)ntiles : 0u;
+    {
+        const uint32_t tbase = nviews > 1 ? (g % (uint32_t)nviews) * (uint32_t)ntiles : 0u;
+        const float fw = (float)__float_as_uint(b.w);
+        sD[wave][lane] = n ? make_float4(-a.w / b.x, -a.w / a.z, 1.0f / fw, __uint_as_float(tbase))
+                           : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     sCnt[wave][lane] = 0;
     if (EMIT) sSlot[wave][lane] = (s < P) ? slot_start[g] : 0u;
     wave_sync();
@@ -299,13 +306,13 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
         }
         const int j = lo;
         const uint32_t excl = j ? sIncl[wave][j - 1] : 0u;
-        const float4 A4 = sA[wave][j], B4 = sB[wave][j];
+        const float4 A4 = sA[wave][j], B4 = sB[wave][j], D4 = sD[wave][j];
         const uint32_t k = m - excl, w = __float_as_uint(B4.w), xy0 = __float_as_uint(B4.z);
-        uint32_t row = (uint32_t)(((float)k + 0.5f) / (float)w);   // w, k < 2^24: exact after the fix-up
+        uint32_t row = (uint32_t)(((float)k + 0.5f) * D4.z);       // w, k < 2^24: exact after the fix-up
         if (row * w > k) --row;
         if ((row + 1) * w <= k) ++row;
         const int tx = (int)((xy0 & 0xFFFFu) + (k - row * w)), ty = (int)((xy0 >> 16) + row);
-        const bool keep = active && (!cull || tile_touched(A4.x, A4.y, A4.z, A4.w, B4.x, B4.y, tx, ty));
+        const bool keep = active && (!cull || tile_touched(A4.x, A4.y, A4.z, A4.w, B4.x, B4.y, D4.x, D4.y, tx, ty));
         const uint64_t mask = __ballot(keep);
         if (keep) {
             // ordinal of this instance among its Gaussian's kept ones (any order will do: it only names a slot)
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
                 // instance's SLOT, Gaussian-major in index order, where backward parks its gradient record
                 const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
                 const uint32_t slot = sSlot[wave][j] + k_in;
-                keys[pos] = sBase[wave][j] + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+                keys[pos] = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
                 vals[pos] = slot;
                 emit_gid[slot] = sId[wave][j];
             }
