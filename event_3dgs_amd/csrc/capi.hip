@@ -17,6 +17,7 @@ int g_tile_cull = [] { const char* e = getenv("E3DGS_TILE_CULL"); return (e && e
 
 // ---- event profiler
 bool g_prof_on = false;
+unsigned g_prof_mask = 0;
 namespace {
 struct ProfPair { hipEvent_t a, b; };
 constexpr int PROF_MAX = 4096;
@@ -348,8 +349,9 @@ void e3dgs_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }   
 void e3dgs_set_tile_cull(int on) { g_tile_cull = on ? 1 : 0; }
 int e3dgs_get_tile_cull(void) { return g_tile_cull; }
 
-void e3dgs_profile_enable(int on) {
-    g_prof_on = on != 0;
+void e3dgs_profile_enable(int slot_mask) {
+    g_prof_mask = (unsigned)slot_mask;
+    g_prof_on = slot_mask != 0;
     for (int i = 0; i < PS_COUNT; ++i) { g_used[i] = 0; g_open[i] = false; }
 }
 int e3dgs_profile_query(int slot, double* total_ms, int* launches) {

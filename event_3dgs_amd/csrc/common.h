@@ -318,10 +318,11 @@ static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 enum ProfSlot { PS_PREPROCESS = 0, PS_SORT_DEPTH, PS_SCAN_EMIT, PS_SORT_TILE, PS_RANGES, PS_RENDER_FWD, PS_RENDER_BWD,
                 PS_GEOM_BWD, PS_COUNT };
 extern bool g_prof_on;
+extern unsigned g_prof_mask;
 void prof_begin(int slot, hipStream_t s);
 void prof_end(int slot, hipStream_t s);
 struct ProfScope {
     int slot; hipStream_t s;
-    ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_) { if (g_prof_on) prof_begin(slot, s); }
-    ~ProfScope() { if (g_prof_on) prof_end(slot, s); }
+    ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_) { if (g_prof_on && ((g_prof_mask >> slot) & 1u)) prof_begin(slot, s); }
+    ~ProfScope() { if (g_prof_on && ((g_prof_mask >> slot) & 1u)) prof_end(slot, s); }
 };

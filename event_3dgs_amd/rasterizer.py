@@ -47,16 +47,54 @@ def _prep(t, name, device=None):
     return t.contiguous()
 
 
-class _Scratch:
-    """One growable uint8 torch tensor handed to the C ABI through an allocation callback."""
+class ScratchPool:
+    """Persistent, geometrically growing device buffers keyed by name.  A training loop that re-renders every
+    iteration asks for slightly different scratch sizes each time (the instance count moves with the scene);
+    going through the allocator for every size means hipMalloc / hipFree traffic whose latency is at the mercy
+    of the driver.  A pool buffer is reused as long as it is large enough and grows by 25 % when it is not.
+    Buffers handed out are only valid until the next request of the same name (one iteration in flight)."""
+
+    GROWTH = 1.25
 
     def __init__(self, device):
         self.device = device
+        self._bufs = {}
+
+    def get(self, name, nbytes):
+        nbytes = int(nbytes)
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._bufs.pop(name, None)           # release the old block before asking for the bigger one
+            buf = torch.empty(max(int(nbytes * self.GROWTH), 256), dtype=torch.uint8, device=self.device)
+            self._bufs[name] = buf
+        return buf
+
+    def typed(self, name, shape, dtype=torch.float32):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        item = torch.empty(0, dtype=dtype).element_size()
+        return self.get(name, max(n * item, 1))[:n * item].view(dtype).view(*shape)
+
+    def clear(self):
+        self._bufs.clear()
+
+
+class _Scratch:
+    """One growable uint8 torch tensor handed to the C ABI through an allocation callback."""
+
+    def __init__(self, device, pool=None, name=None):
+        self.device = device
+        self.pool, self.name = pool, name
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
         self.cb = _lib.ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, nbytes):
-        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        if self.pool is not None:
+            self.tensor = self.pool.get(self.name, nbytes)
+        else:
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self.tensor.data_ptr()
 
 
@@ -286,7 +324,7 @@ def _check_same_frame(settings_list):
             raise ValueError("the views of one multi-view call share resolution, scale_modifier and SH degree")
 
 
-def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags=0, count_host=None):
+def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags=0, count_host=None, pool=None):
     """Enqueue-only first half of e3dgs_rasterize_forward_multi for len(settings_list) cameras (same frame size,
     background of settings_list[0]).  `count_host`: pinned int32[1] receiving the total instance count."""
     L = _lib.lib()
@@ -305,8 +343,11 @@ def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list
     if count_host is None:
         count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
     arrays, keep = _view_arrays(settings_list)
-    radii = torch.empty(n, P, dtype=torch.int32, device=dev)
-    geom, img = _Scratch(dev), _Scratch(dev)
+    if pool is not None:
+        radii = pool.typed("radii", (n, P), torch.int32)
+    else:
+        radii = torch.empty(n, P, dtype=torch.int32, device=dev)
+    geom, img = _Scratch(dev, pool, "geom"), _Scratch(dev, pool, "image")
     with torch.cuda.device(dev):
         rc = L.e3dgs_rasterize_forward_multi_begin(
             geom.cb, None, img.cb, None, n, P, int(rs.sh_degree), M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), None,
@@ -316,7 +357,7 @@ def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list
     return PendingForward(rs=rs, settings_list=list(settings_list), n=n, flags=int(flags), P=P, W=W, H=H, M=M,
                           radii=radii, geom=geom.tensor, image=img.tensor,
                           inputs=(means3D_c, sh_c, None, scales_c, rots_c, None), opacities=opac_c, bg=bg, keep=keep,
-                          count_host=count_host, device=dev)
+                          count_host=count_host, device=dev, pool=pool)
 
 
 def forward_multi_finish(pending):
@@ -325,8 +366,11 @@ def forward_multi_finish(pending):
     L = _lib.lib()
     p = pending
     I = int(p.count_host[0])
-    out_color = torch.empty(p.n, 3, p.H, p.W, dtype=torch.float32, device=p.device)
-    binning = _Scratch(p.device)
+    if p.pool is not None:
+        out_color = p.pool.typed("out_color", (p.n, 3, p.H, p.W))
+    else:
+        out_color = torch.empty(p.n, 3, p.H, p.W, dtype=torch.float32, device=p.device)
+    binning = _Scratch(p.device, p.pool, "binning")
     with torch.cuda.device(p.device):
         rc = L.e3dgs_rasterize_forward_multi_finish(binning.cb, None, p.n, p.P, p.W, p.H, _lib.ptr(p.bg),
                                                     _lib.ptr(p.geom), _lib.ptr(p.image), I, _lib.ptr(out_color),
@@ -334,12 +378,12 @@ def forward_multi_finish(pending):
     _lib.check(rc, "e3dgs_rasterize_forward_multi_finish")
     return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, settings_list=p.settings_list,
                 flags=p.flags, inputs=p.inputs, opacities=p.opacities, bg=p.bg, keep=p.keep, geom=p.geom,
-                binning=binning.tensor, image=p.image)
+                binning=binning.tensor, image=p.image, pool=p.pool)
 
 
-def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flags=0):
+def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flags=0, pool=None):
     """begin + synchronise + finish."""
-    pend = forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags)
+    pend = forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags, pool=pool)
     torch.cuda.current_stream(means3D.device).synchronize()
     return forward_multi_finish(pend)
 
@@ -367,7 +411,9 @@ def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
     g = g.contiguous()
     if tuple(g.shape) != (len(sl), 3, H, W):
         raise ValueError("grad_out_color must be (nviews,3,H,W)")
-    if grad_acc is None:
+    if grad_acc is None and raw.get("pool") is not None:
+        grad_acc = raw["pool"].typed("grad_acc", (int(raw["num_rendered"]) + len(sl) * P, _lib.ACC_STRIDE))
+    elif grad_acc is None:
         grad_acc = torch.empty(int(raw["num_rendered"]) + len(sl) * P, _lib.ACC_STRIDE, dtype=torch.float32,
                                device=dev)
     arrays, keep = _view_arrays(sl)

@@ -120,6 +120,8 @@ class EventTrainer:
         self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if self.track_stats else None
         self._loss_bufs = None
         self._counts = None
+        # scratch of the rasteriser calls of step(): persistent, grows geometrically (no allocator traffic per step)
+        self._pool = rasterizer.ScratchPool(self.device)
         self.last_radii = None
         self.last_scalars = None
 
@@ -205,7 +207,8 @@ class EventTrainer:
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
         # ---- the three renders (train.py:144,159,161)
         pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
-                                              settings, flags=self.FWD_FLAGS, count_host=self._counts)
+                                              settings, flags=self.FWD_FLAGS, count_host=self._counts,
+                                              pool=self._pool)
         main.synchronize()                         # the iteration's only host wait: the instance count is back
         raw = rasterizer.forward_multi_finish(pend)
         imgs = raw["color"]

@@ -332,10 +332,12 @@ int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg,
 /*
  * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * Slots: 0 preprocess, 1 sort_depth, 2 scan_emit, 3 sort_tile, 4 tile_ranges, 5 render_fwd,
- *        6 render_bwd, 7 geom_bwd.  enable(1) resets the counters; query() synchronises the
- * recorded events and returns the accumulated milliseconds and the number of launches.
+ *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set
+ * (0 = off, 0xFF = all; every timed slot costs two event packets per launch group, so a benchmark times only
+ * the kernel it reports inside its timed region); query() synchronises the recorded events and returns the
+ * accumulated milliseconds and the number of launches.
  */
-void e3dgs_profile_enable(int on);
+void e3dgs_profile_enable(int slot_mask);
 int e3dgs_profile_query(int slot, double* total_ms, int* launches);
 const char* e3dgs_profile_slot_name(int slot);
 

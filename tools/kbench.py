@@ -33,7 +33,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-L.e3dgs_profile_enable(1)
+L.e3dgs_profile_enable(0xFF)
 for _ in range(a.iters):
     img = step()
 torch.cuda.synchronize()

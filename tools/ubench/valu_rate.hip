@@ -34,6 +34,23 @@ OPS(dpp_ror, x[i] = x[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float
 OPS(dpp_mov, x[i] = a + __int_as_float(__builtin_amdgcn_update_dpp(0, ix[i], 0xB1, 0xf, 0xf, false)); ix[i] += 1)
 OPS(sel3, x[i] = (ix[i] & 1) ? x[i] * a : b)
 
+// packed fp32: one v_pk_* instruction carries two independent fp32 operations per lane
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define PKOPS(NAME, BODY)                                                                     \
+    __global__ void k_##NAME(float* out, float a, float b, int n) {                            \
+        f2 x[CHAINS];                                                                        \
+        const f2 av = {a, a + 0.25f}, bv = {b, b - 0.125f};                                   \
+        for (int i = 0; i < CHAINS; ++i) { x[i].x = a + i + threadIdx.x; x[i].y = b + i - threadIdx.x; } \
+        for (int it = 0; it < n; ++it) {                                                     \
+            _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) { BODY; }                      \
+        }                                                                                     \
+        float s = 0; for (int i = 0; i < CHAINS; ++i) s += x[i].x + x[i].y;                   \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                        \
+    }
+PKOPS(pk_fma, x[i] = __builtin_elementwise_fma(x[i], av, bv))
+PKOPS(pk_mul, x[i] = x[i] * av)
+PKOPS(pk_add, x[i] = x[i] + av)
+
 template <typename K>
 void run(const char* name, K kern, int ops_per_body) {
     float* out; hipMalloc(&out, 256 * 2048 * 4);
@@ -57,5 +74,6 @@ int main() {
     run("rndne+add", k_rndne, 2); run("cvt,cvt,add", k_cvt, 3); run("rcp+add", k_rcp, 2); run("exp2+mul", k_exp2, 2);
     run("dpp+add", k_dpp, 1); run("dpp_ror+add", k_dpp_ror, 1); run("swz+add", k_swz, 1); run("bperm+add", k_bperm, 1);
     run("dppmov,add,iadd", k_dpp_mov, 3); run("and,mul,sel", k_sel3, 3);
+    run("pk_fma", k_pk_fma, 1); run("pk_mul", k_pk_mul, 1); run("pk_add", k_pk_add, 1);
     return 0;
 }
