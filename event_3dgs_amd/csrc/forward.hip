@@ -82,8 +82,9 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod,
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------ preprocess
-// One thread per Gaussian, looping over the views of the call: the mean, Sigma3, the opacity activation and
-// (through L1) the SH coefficients are fetched once for all views.  Splat q = i * n + v.
+// One thread per splat q = i * n + v (Gaussian i, view v).  The n threads of one Gaussian sit in adjacent lanes
+// and read the same parameter addresses, so HBM sees the parameters once per call while the grid is n times
+// larger than a per-Gaussian loop (which was latency-bound at 3 waves/SIMD) and every store is contiguous.
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
@@ -92,10 +93,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord,
     uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     // housekeeping that would otherwise be two memset commands (each costs a barrier packet on the queue)
-    for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
-    if (i == 0) *offsets0 = 0u;
+    for (int t = tid; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
+    if (tid == 0) *offsets0 = 0u;
+    const int nv = vs.n;
+    const int i = nv == 1 ? tid : tid / nv;
     if (i >= P) return;
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     float S[6];
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
     // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
     const float pmin = -(logf(255.0f * o_) + 1e-3f);
-#pragma unroll 1
-    for (int v = 0; v < vs.n; ++v) {
+    {
+        const int v = tid - i * nv;
         const ViewParams& vp = vs.v[v];
-        const size_t q = (size_t)i * vs.n + v;
+        const size_t q = (size_t)tid;
         const float* V = vp.view;
         const float* Pm = vp.proj;
         int radius_out = 0;
@@ -594,7 +597,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     if (P <= 0) HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
     *count_host = 0;
     if (P > 0) {
-        const unsigned pb = (unsigned)((P + 255) / 256);
+        const unsigned pb = (unsigned)((Q + 255) / 256);
         {
         ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
