@@ -304,20 +304,22 @@ __device__ __forceinline__ void build_cov3(const float sact[3], float scale_modi
     S[5] = FMA(L[2][0], L[2][0], FMA(L[2][1], L[2][1], L[2][2] * L[2][2]));
 }
 
-// Per-splat sums of the per-instance gradient records.  Slots are Gaussian-major in index order, so the 256
-// splats of a workgroup own ONE contiguous slot range: it is streamed through LDS with fully coalesced 16-byte
-// loads (256 records per chunk) and every thread adds the records of its own run from LDS, in slot order
-// (fixed order -> deterministic).  Output: 3 float4 per splat, (mx my A B | C o c0 c1 | c2 - - -).
+// Per-splat sums of the per-instance gradient records.  A splat's records sit contiguously at its emission
+// positions, so the 256 depth-consecutive splats of a workgroup own ONE contiguous slot range: it is streamed
+// through LDS with fully coalesced 16-byte loads (256 records per chunk) and every thread adds the records of
+// its own run from LDS, in slot order (fixed order -> deterministic).  Output: 3 float4 per splat at its INDEX
+// q, (mx my A B | C o c0 c1 | c2 - - -), which the per-Gaussian kernels then read coalesced.
 constexpr int RR_CHUNK = 256;
-__global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint2* __restrict__ run,
+__global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint32_t* __restrict__ order,
+                                                         const uint2* __restrict__ run_sorted,
                                                          const float* __restrict__ part, float4* __restrict__ gsum) {
     __shared__ float4 sbuf[3 * RR_CHUNK];
     __shared__ uint32_t sRange[2];
-    const uint32_t t = threadIdx.x, q0 = blockIdx.x * 256u, q = q0 + t;
-    const uint32_t qlast = (Q < q0 + 256u ? Q : q0 + 256u) - 1u;
-    const uint2 rn = q < Q ? run[q] : make_uint2(0u, 0u);
+    const uint32_t t = threadIdx.x, j0 = blockIdx.x * 256u, j = j0 + t;
+    const uint32_t jlast = (Q < j0 + 256u ? Q : j0 + 256u) - 1u;
+    const uint2 rn = j < Q ? run_sorted[j] : make_uint2(0u, 0u);
     if (t == 0) sRange[0] = rn.x;
-    if (q == qlast) sRange[1] = rn.x + rn.y;
+    if (j == jlast) sRange[1] = rn.x + rn.y;
     __syncthreads();
     const uint32_t S0 = sRange[0], S1 = sRange[1];
     float4 a0 = make_float4(0, 0, 0, 0), a1 = make_float4(0, 0, 0, 0);
@@ -339,8 +341,9 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint2
         }
         __syncthreads();
     }
-    if (q < Q) {
-        gsum[3 * (size_t)q] = a0; gsum[3 * (size_t)q + 1] = a1; gsum[3 * (size_t)q + 2] = make_float4(a2, 0.0f, 0.0f, 0.0f);
+    if (j < Q) {              // zeros for splats whose every tile was culled (their radius can still be > 0)
+        const size_t q = order[j];
+        gsum[3 * q] = a0; gsum[3 * q + 1] = a1; gsum[3 * q + 2] = make_float4(a2, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -754,7 +757,8 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     // per-splat sums live behind the instance records in the caller's scratch: grad_acc is (num_rendered + Q, 12)
     float4* gsum = reinterpret_cast<float4*>(grad_acc + E3_ACC_STRIDE * (size_t)num_rendered);
     if (num_rendered > 0)
-        run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.run, grad_acc, gsum);
+        run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
+                                                                                   grad_acc, gsum);
     if (nv == 1 && (flags & E3_FLAG_ACCUMULATE))
         geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,

@@ -150,11 +150,9 @@ struct GeomState {
                        //   [0] (x, y, conic.x, conic.y)  [1] (conic.z, opacity, r, g)  [2] (b, pmin, -, -)
                        //   pmin: alpha >= 1/255 needs power >= pmin = -(ln(255 o) + margin)
     uint32_t* clamped; // SH clamp bitmask (bit ch)
-    uint2* run;        // (first slot, kept instance count) of each Gaussian: where backward finds its
-                       // per-instance gradient records.  Slots number the instances Gaussian-major in INDEX
-                       // order (exclusive scan of `cnt`), so neighbouring Gaussians own neighbouring records
-    uint32_t* cnt;     // kept instances per Gaussian (binning count pass)
-    uint32_t* slot;    // exclusive scan of cnt
+    uint2* run;        // (first slot, kept instance count) of the splat at each DEPTH-SORTED position (ids in
+                       // ord0): a splat's instances are emitted contiguously, slot = emission position, so the
+                       // gradient records of the splats of a workgroup (in depth order) form one contiguous range
     uint2* rect;       // packed tile rectangle: .x = xmin | ymin<<16, .y = xmax | ymax<<16
     uint32_t* key0;    // depth keys (ping)
     uint32_t* key1;    // (pong)
@@ -175,8 +173,6 @@ struct GeomState {
         g.rec = carve<float4>(p, 3 * n);
         g.clamped = carve<uint32_t>(p, n);
         g.run = carve<uint2>(p, n);
-        g.cnt = carve<uint32_t>(p, n);
-        g.slot = carve<uint32_t>(p, n);
         g.rect = carve<uint2>(p, n);
         g.key0 = carve<uint32_t>(p, n);
         g.key1 = carve<uint32_t>(p, n);
@@ -197,7 +193,7 @@ struct BinningState {
     uint32_t* vals_alt;
     uint32_t* keys;       // tile ids
     uint32_t* keys_alt;
-    uint32_t* emit_gid;   // Gaussian id of each slot (see GeomState::run)                      [read by fwd + bwd]
+    uint32_t* emit_gid;   // splat id of each slot (= emission position)                       [read by fwd + bwd]
     uint32_t* scratch;
     static size_t required(size_t I) {
         char* p = nullptr;

@@ -245,12 +245,10 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
                                                               const uint32_t* __restrict__ wave_offsets,
                                                               uint32_t* __restrict__ wave_counts,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                              uint32_t* __restrict__ emit_gid, uint2* __restrict__ run,
-                                                              uint32_t* __restrict__ cnt_out,
-                                                              const uint32_t* __restrict__ slot_start) {
+                                                              uint32_t* __restrict__ emit_gid,
+                                                              uint2* __restrict__ run_sorted) {
     __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
-    __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per Gaussian of the wave
-    __shared__ uint32_t sSlot[BIN_WAVES][WAVE]; // first slot of each Gaussian of the wave (EMIT only)
+    __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per splat of the wave (EMIT only)
     __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
     __shared__ uint32_t sIncl[BIN_WAVES][WAVE];
     __shared__ uint32_t sId[BIN_WAVES][WAVE];
@@ -291,8 +289,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
         sD[wave][lane] = n ? make_float4(-a.w / b.x, -a.w / a.z, 1.0f / fw, __uint_as_float(tbase))
                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    sCnt[wave][lane] = 0;
-    if (EMIT) sSlot[wave][lane] = (s < P) ? slot_start[g] : 0u;
+    if (EMIT) sCnt[wave][lane] = 0;
     wave_sync();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t count = 0;
@@ -317,27 +314,30 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
         const int tx = (int)((xy0 & 0xFFFFu) + (k - row * w)), ty = (int)((xy0 >> 16) + row);
         const bool keep = active && (!cull || tile_touched(A4.x, A4.y, A4.z, A4.w, B4.x, B4.y, D4.x, D4.y, tx, ty));
         const uint64_t mask = __ballot(keep);
-        if (keep) {
-            // ordinal of this instance among its Gaussian's kept ones (any order will do: it only names a slot)
-            const uint32_t k_in = atomicAdd(&sCnt[wave][j], 1u);
-            if (EMIT) {
-                // emission position = depth order (what the stable tile sort preserves); the payload is the
-                // instance's SLOT, Gaussian-major in index order, where backward parks its gradient record
-                const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
-                const uint32_t slot = sSlot[wave][j] + k_in;
-                keys[pos] = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
-                vals[pos] = slot;
-                emit_gid[slot] = sId[wave][j];
-            }
+        if (EMIT && keep) {
+            // emission position = depth order (what the stable tile sort preserves).  It is also the instance's
+            // SLOT: where backward parks its gradient record; the kept instances of one splat are contiguous
+            const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
+            keys[pos] = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+            vals[pos] = pos;
+            emit_gid[pos] = sId[wave][j];
+            atomicAdd(&sCnt[wave][j], 1u);
         }
         count += (uint32_t)__popcll(mask);
     }
-    wave_sync();
     if (!EMIT) {
         if (lane == 0) wave_counts[gw] = count;
-        if (s < P) cnt_out[g] = sCnt[wave][lane];
-    } else if (s < P) {
-        run[g] = make_uint2(sSlot[wave][lane], sCnt[wave][lane]);
+    } else {
+        // run of each splat, stored at its DEPTH-SORTED position: (first slot, kept instances)
+        wave_sync();
+        const uint32_t c = sCnt[wave][lane];
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (s < P) run_sorted[s] = make_uint2(out_base + inc - c, c);
     }
 }
 
@@ -620,12 +620,9 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nv, ntiles, order, geom.rect, geom.rec,
                                                                      vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
-                                                                     nullptr, nullptr, nullptr, nullptr, geom.cnt,
-                                                                     nullptr);
+                                                                     nullptr, nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
-        // slots: exclusive scan of the per-splat kept counts in INDEX order
-        launch_exclusive_scan_u32(geom.cnt, geom.slot, Q, geom.scratch, false, s);
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back
@@ -661,8 +658,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nviews, tiles_per_view, geom.ord0,
                                                                     geom.rect, geom.rec, gx, g_tile_cull, geom.offsets,
-                                                                    nullptr, k0, v0, bin.emit_gid, geom.run, nullptr,
-                                                                    geom.slot);
+                                                                    nullptr, k0, v0, bin.emit_gid, geom.run);
         }
         KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
