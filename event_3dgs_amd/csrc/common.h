@@ -306,8 +306,10 @@ void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint
                                hipStream_t s);
 // Stable LSD radix sort of (key,val) u32 pairs on bits [0,nbits).  Result is returned in
 // (*keys_out,*vals_out) which are one of the two provided buffer pairs.
+// identity_payload: v0 is NOT read; the payload of element i is i (saves writing and reading the index array).
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
-                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
+                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
+                             bool identity_payload = false);
 static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---------------------------------------------------------------- optional event profiler (capi.hip)

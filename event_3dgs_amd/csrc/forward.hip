@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewSet vs, int flags,
     int* __restrict__ radii,
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
-    uint2* __restrict__ rect, uint32_t* __restrict__ key, uint32_t* __restrict__ ord,
+    uint2* __restrict__ rect, uint32_t* __restrict__ key,
     uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     // housekeeping that would otherwise be two memset commands (each costs a barrier packet on the queue)
@@ -187,8 +187,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
         radii[(size_t)v * P + i] = radius_out;
         rect[q] = rect_out;
-        key[q] = key_out;
-        ord[q] = (uint32_t)q;
+        key[q] = key_out;          // the depth sort's payload is q itself (identity_payload): no id array written
     }
 }
 
@@ -316,10 +315,10 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
         const uint64_t mask = __ballot(keep);
         if (EMIT && keep) {
             // emission position = depth order (what the stable tile sort preserves).  It is also the instance's
-            // SLOT: where backward parks its gradient record; the kept instances of one splat are contiguous
+            // SLOT: where backward parks its gradient record; the kept instances of one splat are contiguous.
+            // The sort payload is this position itself, so no payload array is written (identity_payload)
             const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
             keys[pos] = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
-            vals[pos] = pos;
             emit_gid[pos] = sId[wave][j];
             atomicAdd(&sCnt[wave][j], 1u);
         }
@@ -602,7 +601,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         ProfScope ps(PS_PREPROCESS, s);
         preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
                                                          vs, flags, radii, geom.rec, geom.clamped,
-                                                         geom.rect, geom.key0, geom.ord0, img.ranges, ntiles * nv,
+                                                         geom.rect, geom.key0, img.ranges, ntiles * nv,
                                                          geom.offsets);
         }
         KERNEL_OK("preprocess_kernel");
@@ -610,7 +609,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         {
         ProfScope ps(PS_SORT_DEPTH, s);
         launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, 32, geom.scratch, &keys_sorted,
-                                &order, s);
+                                &order, s, true);
         }
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
@@ -664,7 +663,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         uint32_t *ks, *vs;
         {
         ProfScope ps(PS_SORT_TILE, s);
-        launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s);
+        launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s, true);
         }
         KERNEL_OK("radix sort (tile)");
         if (vs != bin.perm) return e3_fail(hipErrorUnknown, "internal: sorted list not in perm");

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         size_t idx = wbase + (size_t)r * WAVE + lane;
         bool ok = idx < n;
         key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = ok ? vals_in[idx] : 0u;
+        val[r] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;   // no payload array: the payload is the index
     }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
         size_t idx = wbase + (size_t)r * WAVE + lane;
         bool ok = idx < n;
         key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = ok ? vals_in[idx] : 0u;
+        val[r] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
     }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -378,7 +378,8 @@ static size_t onesweep_max_blocks() {
 }
 
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
-                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s) {
+                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
+                             bool identity_payload) {
     uint32_t *ki = k0, *ko = k1, *vi = v0, *vo = v1;
     const int passes = radix_passes(nbits);
     // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
@@ -393,7 +394,8 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
         (void)hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), s);
         radix_global_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, passes, ghist);
         for (int p = 0; p < passes; ++p) {
-            radix_onesweep_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, vi, ko, vo, n, 8 * p, ghist + 256 * p,
+            radix_onesweep_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, (identity_payload && p == 0) ? nullptr : vi,
+                                                                         ko, vo, n, 8 * p, ghist + 256 * p,
                                                                          desc + (size_t)p * nb * 256, tickets + p);
             uint32_t* t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
@@ -406,7 +408,8 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
         for (int shift = 0; shift < nbits; shift += 8) {
             radix_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, shift, hist, nb);
             launch_exclusive_scan_u32(hist, hist, hn, scan_scratch, false, s);
-            radix_scatter_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, vi, ko, vo, n, shift, hist, nb);
+            radix_scatter_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(
+                ki, (identity_payload && shift == 0) ? nullptr : vi, ko, vo, n, shift, hist, nb);
             uint32_t* t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
         }
