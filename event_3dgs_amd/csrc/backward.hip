@@ -122,7 +122,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 const float dy = a.y - pfy[k];
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
-                const bool live = (contributor <= last[k]) && !(power > 0.0f) && (power >= c.y);
+                const bool live = (contributor <= last[k]) && (power >= c.y);   // power > 0 is rejected by `valid`
                 if (__builtin_amdgcn_ballot_w64(live) != 0) {
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 const float dy = a.y - pfy[k];
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
-                const bool live = (T[k] > 0.0f) && !(power > 0.0f) && (power >= c.y);
+                const bool live = (T[k] > 0.0f) && (power >= c.y);     // power > 0 (degenerate conic) is rejected by `valid`
                 if (__builtin_amdgcn_ballot_w64(live) != 0) {
                     ++live_strips;
                     ++live_strips;
