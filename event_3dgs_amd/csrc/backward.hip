@@ -122,8 +122,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 const float dy = a.y - pfy[k];
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
-                const bool live = (contributor <= last[k]) && (power >= c.y);   // power > 0 is rejected by `valid`
-                if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                // lane masks straight from the compares (SGPR pairs): 2 v_cmp + s_and + s_cbranch_scc;
+                // power > 0 is rejected by `valid`
+                const unsigned long long live_mask = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
+                                                     __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
+                if (live_mask != 0ull) {
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);

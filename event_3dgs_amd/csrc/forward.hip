@@ -478,8 +478,12 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 const float dy = a.y - pfy[k];
                 const float q = FMA(b.x * dy, dy, qx);
                 const float power = FMA(-0.5f, q, -(cydx * dy));
-                const bool live = (T[k] > 0.0f) && (power >= c.y);     // power > 0 (degenerate conic) is rejected by `valid`
-                if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                // wave-wide "any pixel of the strip live": compare intrinsics deliver the lane masks in SGPR pairs, so
+                // the test is 2 v_cmp + s_and + s_cbranch_scc (ballot(bool) costs two more VALU slots per strip);
+                // power > 0 (degenerate conic) is rejected by `valid` below
+                const unsigned long long live_mask = __builtin_amdgcn_fcmpf(T[k], 0.0f, 2 /* OGT */) &
+                                                     __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
+                if (live_mask != 0ull) {
                     ++live_strips;
                     ++live_strips;
                     const float G = exp_det_noclamp(power);
