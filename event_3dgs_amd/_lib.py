@@ -120,6 +120,7 @@ FLAG_ACCUMULATE = 2
 FLAG_SH_PLANAR = 4
 FLAG_BWD_ONLY_RENDER = 8
 FLAG_BWD_ONLY_GEOM = 16
+FLAG_COUNT_MAPPED = 64
 ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [

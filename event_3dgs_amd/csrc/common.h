@@ -25,6 +25,7 @@
 #define E3_FLAG_SH_PLANAR 4   // shs / dL_dsh are coefficient-major (M*3, P): lane-coalesced, no (P,M,3) stride
 #define E3_FLAG_BWD_ONLY_RENDER 8   // backward: run only the compositing backward (fills grad_acc)
 #define E3_FLAG_BWD_ONLY_GEOM 16    // backward: run only the per-Gaussian backward (consumes grad_acc)
+#define E3_FLAG_COUNT_MAPPED 64     // begin: num_rendered_host is pinned + device-mapped; the GPU stores the count there
 #define E3_MAX_VIEWS 4       // views per e3dgs_rasterize_backward_geom_multi call
 #define E3_ACC_STRIDE 12      // floats per (tile, Gaussian) instance in the backward gradient records
 

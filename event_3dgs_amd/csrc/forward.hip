@@ -553,6 +553,13 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
     present[i] = vz > E3_NEAR_CULL_Z ? 1 : 0;
 }
 
+// E3_FLAG_COUNT_MAPPED: the instance count is stored straight into host-visible (pinned, mapped) memory by the
+// GPU; the host polls that word instead of waiting for a copy command + stream synchronisation.
+__global__ void publish_count_kernel(const uint32_t* __restrict__ src, volatile int* __restrict__ dst_host) {
+    *dst_host = (int)*src;
+    __threadfence_system();
+}
+
 // ------------------------------------------------------------------------------------ host driver
 extern thread_local char g_err[512];
 extern int g_tile_cull;
@@ -598,7 +605,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     GeomState geom = GeomState::from(gp, Q);
     ImageState img = ImageState::from(ip, npix * nv, (size_t)ntiles * nv);
     if (P <= 0) HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
-    *count_host = 0;
+    if (!(flags & E3_FLAG_COUNT_MAPPED) || P <= 0) *count_host = 0;      // (mapped: the caller armed a sentinel)
     if (P > 0) {
         const unsigned pb = (unsigned)((Q + 255) / 256);
         {
@@ -629,7 +636,10 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back
-        HIP_OK(hipMemcpyAsync(count_host, geom.offsets + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (flags & E3_FLAG_COUNT_MAPPED)
+            publish_count_kernel<<<dim3(1), dim3(1), 0, s>>>(geom.offsets + nwaves, count_host);
+        else
+            HIP_OK(hipMemcpyAsync(count_host, geom.offsets + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     return 0;
 }

@@ -343,6 +343,8 @@ def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list
     if count_host is None:
         count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
     arrays, keep = _view_arrays(settings_list)
+    if flags & _lib.FLAG_COUNT_MAPPED:
+        count_host[0] = -1                      # sentinel: the GPU overwrites it with the count (wait_count polls)
     if pool is not None:
         radii = pool.typed("radii", (n, P), torch.int32)
     else:
@@ -358,6 +360,29 @@ def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list
                           radii=radii, geom=geom.tensor, image=img.tensor,
                           inputs=(means3D_c, sh_c, None, scales_c, rots_c, None), opacities=opac_c, bg=bg, keep=keep,
                           count_host=count_host, device=dev, pool=pool)
+
+
+def wait_count(pending, timeout_s=10.0):
+    """Wait until the instance count of a forward_multi_begin(..., flags | FLAG_COUNT_MAPPED) call has arrived in its
+    pinned host word: the GPU stores it there directly and this polls it (a stream synchronisation costs a copy
+    command plus the runtime's wake-up latency, during which the GPU has nothing queued)."""
+    import ctypes as C
+    import time
+    if not (pending.flags & _lib.FLAG_COUNT_MAPPED):
+        torch.cuda.current_stream(pending.device).synchronize()
+        return
+    word = C.c_int.from_address(pending.count_host.data_ptr())
+    spins = 0
+    while word.value == -1:
+        spins += 1
+        if spins & 0xFFFF == 0:
+            t0 = getattr(pending, "_t0", None)
+            if t0 is None:
+                pending._t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > timeout_s:
+                torch.cuda.current_stream(pending.device).synchronize()      # surfaces a device error, if any
+                if word.value == -1:
+                    raise RuntimeError("instance count never arrived")
 
 
 def forward_multi_finish(pending):
@@ -377,14 +402,14 @@ def forward_multi_finish(pending):
                                                     int(bool(p.rs.debug)), _lib.current_stream())
     _lib.check(rc, "e3dgs_rasterize_forward_multi_finish")
     return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, settings_list=p.settings_list,
-                flags=p.flags, inputs=p.inputs, opacities=p.opacities, bg=p.bg, keep=p.keep, geom=p.geom,
-                binning=binning.tensor, image=p.image, pool=p.pool)
+                flags=p.flags & ~_lib.FLAG_COUNT_MAPPED, inputs=p.inputs, opacities=p.opacities, bg=p.bg, keep=p.keep,
+                geom=p.geom, binning=binning.tensor, image=p.image, pool=p.pool)
 
 
 def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flags=0, pool=None):
     """begin + synchronise + finish."""
     pend = forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags, pool=pool)
-    torch.cuda.current_stream(means3D.device).synchronize()
+    wait_count(pend)
     return forward_multi_finish(pend)
 
 

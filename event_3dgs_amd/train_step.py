@@ -207,9 +207,9 @@ class EventTrainer:
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
         # ---- the three renders (train.py:144,159,161)
         pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
-                                              settings, flags=self.FWD_FLAGS, count_host=self._counts,
-                                              pool=self._pool)
-        main.synchronize()                         # the iteration's only host wait: the instance count is back
+                                              settings, flags=self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED,
+                                              count_host=self._counts, pool=self._pool)
+        rasterizer.wait_count(pend)                # the iteration's only host wait: the instance count (polled)
         raw = rasterizer.forward_multi_finish(pend)
         imgs = raw["color"]
         if self._loss_bufs is None or self._loss_bufs[1].shape != imgs.shape:

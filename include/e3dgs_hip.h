@@ -54,6 +54,11 @@ const char* e3dgs_last_error(void);
                                     (P,M,3): neighbouring lanes read neighbouring addresses (used by the fused
                                     trainer, which owns its parameter layout) */
 
+#define E3DGS_FLAG_COUNT_MAPPED 64  /* forward_begin / forward_multi_begin: num_rendered_host points to PINNED host memory
+                                       that the device can address (hipHostMalloc; a torch pinned tensor).  The GPU
+                                       stores the count there itself (no copy command), so the caller may arm the
+                                       word with a sentinel (-1) and poll it instead of synchronising the stream;
+                                       with P == 0 the library writes 0 at once. */
 #define E3DGS_FLAG_BWD_ONLY_RENDER 8   /* backward: only the compositing backward (pixels -> grad_acc) */
 #define E3DGS_FLAG_BWD_ONLY_GEOM 16    /* backward: only the per-Gaussian backward (grad_acc -> parameter gradients).
                                           Together these let a caller overlap the compositing backward of several
