@@ -385,21 +385,33 @@ def wait_count(pending, timeout_s=10.0):
                     raise RuntimeError("instance count never arrived")
 
 
-def forward_multi_finish(pending):
-    """Second half; the caller has synchronised the stream since forward_multi_begin().  Returns a dict like
-    forward_raw's with color (n,3,H,W) and radii (n,P)."""
+def prepare_multi_finish(pending):
+    """Everything forward_multi_finish needs except the instance count: called BEFORE waiting for the count so that
+    the host has as little as possible to do between the count's arrival and the next kernel launch (the GPU is
+    idle in that window)."""
     L = _lib.lib()
     p = pending
-    I = int(p.count_host[0])
     if p.pool is not None:
         out_color = p.pool.typed("out_color", (p.n, 3, p.H, p.W))
     else:
         out_color = torch.empty(p.n, 3, p.H, p.W, dtype=torch.float32, device=p.device)
     binning = _Scratch(p.device, p.pool, "binning")
+    fixed_a = (binning.cb, None, p.n, p.P, p.W, p.H, _lib.ptr(p.bg), _lib.ptr(p.geom), _lib.ptr(p.image))
+    fixed_b = (_lib.ptr(out_color), int(bool(p.rs.debug)), _lib.current_stream())
+    fn = L.e3dgs_rasterize_forward_multi_finish
+    p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b))
+    return p.prepared
+
+
+def forward_multi_finish(pending):
+    """Second half; the caller has synchronised the stream since forward_multi_begin().  Returns a dict like
+    forward_raw's with color (n,3,H,W) and radii (n,P)."""
+    L = _lib.lib()
+    p = pending
+    out_color, binning, call = p.prepared if getattr(p, "prepared", None) else prepare_multi_finish(p)
+    I = int(p.count_host[0])
     with torch.cuda.device(p.device):
-        rc = L.e3dgs_rasterize_forward_multi_finish(binning.cb, None, p.n, p.P, p.W, p.H, _lib.ptr(p.bg),
-                                                    _lib.ptr(p.geom), _lib.ptr(p.image), I, _lib.ptr(out_color),
-                                                    int(bool(p.rs.debug)), _lib.current_stream())
+        rc = call(I)
     _lib.check(rc, "e3dgs_rasterize_forward_multi_finish")
     return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, settings_list=p.settings_list,
                 flags=p.flags & ~_lib.FLAG_COUNT_MAPPED, inputs=p.inputs, opacities=p.opacities, bg=p.bg, keep=p.keep,
@@ -409,6 +421,7 @@ def forward_multi_finish(pending):
 def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flags=0, pool=None):
     """begin + synchronise + finish."""
     pend = forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list, flags, pool=pool)
+    prepare_multi_finish(pend)
     wait_count(pend)
     return forward_multi_finish(pend)
 

@@ -209,6 +209,7 @@ class EventTrainer:
         pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
                                               settings, flags=self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED,
                                               count_host=self._counts, pool=self._pool)
+        rasterizer.prepare_multi_finish(pend)      # (host work done while the GPU still computes the count)
         rasterizer.wait_count(pend)                # the iteration's only host wait: the instance count (polled)
         raw = rasterizer.forward_multi_finish(pend)
         imgs = raw["color"]
