@@ -13,8 +13,7 @@
 constexpr int BWD_WAVES = 4;
 
 extern unsigned long long* g_trace;
-__global__ void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ work,
-                                  uint32_t* __restrict__ order);
+void launch_tile_order(int ntiles, const uint2* ranges, const uint32_t* work, uint32_t* order, hipStream_t s);
 __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
@@ -748,7 +747,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     ImageState img = ImageState::from(ip, (size_t)W * H * nv, ntiles);
     if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
-        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, img.work, img.order_bwd);
+        launch_tile_order(ntiles, img.ranges, img.work, img.order_bwd, s);
         render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
             g_trace, ntiles, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
             background, img.final_T, img.n_contrib, bin.perm, dL_dpix, grad_acc);

@@ -403,6 +403,68 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
     }
 }
 
+// Same, for up to 32 K tiles (3 x 1080p = 24 480): every thread keeps its (up to) 32 keys in registers, so global
+// memory is read once instead of three times and the three phases only touch LDS (30 -> ~10 us; this kernel sits
+// alone on the GPU twice per iteration).
+constexpr int ORDER_ITEMS = 32;
+__global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ work,
+                                                              uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t smax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t key[ORDER_ITEMS];
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < ORDER_ITEMS; ++i) {
+        const int t = tid + i * 1024;
+        uint32_t k = 0;
+        if (t < ntiles) {
+            if (work) k = work[t];
+            else { const uint2 r = ranges[t]; k = r.y - r.x; }
+        }
+        key[i] = k;
+        m = max(m, k);
+    }
+    m = wave_max_u32(m);
+    if (lane == 0) wsum[wave] = m;
+    hist[tid] = 0;
+    __syncthreads();
+    if (tid == 0) { uint32_t x = 0; for (int w = 0; w < 16; ++w) x = max(x, wsum[w]); smax = x; }
+    __syncthreads();
+    const uint32_t width = smax / 1024u + 1u;
+#pragma unroll
+    for (int i = 0; i < ORDER_ITEMS; ++i)
+        if (tid + i * 1024 < ntiles) atomicAdd(&hist[1023u - min(1023u, key[i] / width)], 1u);
+    __syncthreads();
+    uint32_t v = hist[tid], inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    hist[tid] = woff + inc - v;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ORDER_ITEMS; ++i) {
+        const int t = tid + i * 1024;
+        if (t < ntiles) {
+            uint32_t pos = atomicAdd(&hist[1023u - min(1023u, key[i] / width)], 1u);
+            order[pos] = (uint32_t)t;
+        }
+    }
+}
+
+void launch_tile_order(int ntiles, const uint2* ranges, const uint32_t* work, uint32_t* order, hipStream_t s) {
+    if (ntiles <= ORDER_ITEMS * 1024)
+        tile_order_reg_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
+    else
+        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
+}
+
 unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
 
 __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
@@ -689,7 +751,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     }
     {
     ProfScope ps(PS_RANGES, s);
-    tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, img.ranges, nullptr, img.order);
+    launch_tile_order(ntiles, img.ranges, nullptr, img.order, s);
     }
     KERNEL_OK("tile_order_kernel");
     ProfScope ps_render(PS_RENDER_FWD, s);
