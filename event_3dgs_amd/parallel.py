@@ -14,9 +14,46 @@ def allreduce_mean_(flat_grad, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return flat_grad
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
-    flat_grad.div_(world)
+    op, divide = _mean_op(group)
+    dist.all_reduce(flat_grad, op=op, group=group)
+    if divide:
+        flat_grad.div_(world)
     return flat_grad
+
+
+def _mean_op(group):
+    """NCCL/RCCL averages inside the collective (ncclAvg); gloo has no AVG, so the caller divides."""
+    try:
+        backend = dist.get_backend(group)
+    except Exception:
+        backend = "gloo"
+    return (dist.ReduceOp.AVG, False) if backend == "nccl" else (dist.ReduceOp.SUM, True)
+
+
+class PendingMean:
+    """Handle of allreduce_mean_async_: wait() makes the CURRENT stream wait for the collective (the host does not
+    block with RCCL) and finishes the mean where the backend cannot average."""
+
+    def __init__(self, tensor, work, divide_by):
+        self.tensor, self.work, self.divide_by = tensor, work, divide_by
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            if self.divide_by:
+                self.tensor.div_(self.divide_by)
+        return self.tensor
+
+
+def allreduce_mean_async_(chunk, group=None):
+    """Starts the in-place mean over ranks of one contiguous chunk of the gradient buffer and returns at once.
+    Issuing the chunks of the buffer back to back and waiting for chunk k only before the optimizer step of chunk k
+    overlaps the optimizer (HBM-bound) with the remaining collectives (xGMI-bound)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return PendingMean(chunk, None, 0)
+    op, divide = _mean_op(group)
+    work = dist.all_reduce(chunk, op=op, group=group, async_op=True)
+    return PendingMean(chunk, work, dist.get_world_size(group) if divide else 0)
 
 
 def rank_camera_indices(rank, world, n_cameras, iteration, seed=0, exclude=(5, 25, 45, 65, 85)):

@@ -198,9 +198,22 @@ class EventTrainer:
         the loss kernel ([0] = loss).  The three renders are ONE multi-view pass of the rasteriser (every kernel
         of the pipeline runs once over the three cameras), forward and backward; one host wait per iteration
         (the instance count)."""
+        scalars = self.compute_gradients(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur)
+        self.apply_update(sync_grads)
+        return scalars
+
+    def apply_update(self, sync_grads=True):
+        """Gradient averaging over the ranks (if any) + Adam (train.py:330-332) for the iteration whose gradients
+        compute_gradients() left in the flat buffer."""
         self.iteration += 1
         it = self.iteration
-        main = torch.cuda.current_stream(self.device)
+        if self.world > 1 and sync_grads:
+            self._allreduce_and_adam(it)                           # 59 floats/Gaussian + c, pipelined with Adam
+        else:
+            self._adam(it)
+
+    def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):
+        """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer."""
         if self._counts is None:
             self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
         v = self.views
@@ -227,12 +240,54 @@ class EventTrainer:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out)
         self.c_grad.copy_(scalars[1:2])
-        if self.world > 1 and sync_grads:
-            parallel.allreduce_mean_(self.flat_grad, self.pg)      # ONE collective: 59 floats/Gaussian + c
-        self._adam(it)
         self.last_radii = raw["radii"][0]
         self.last_scalars = scalars
         return scalars
+
+    # ---- multi-GPU: the gradient buffer is averaged in 6 contiguous chunks (xyz | 4 quarters of the features |
+    # opacity+scaling+rotation+c); the chunks' collectives are issued back to back and the Adam launches of chunk k
+    # wait only for chunk k, so the HBM-bound optimizer hides under the xGMI-bound collectives that follow it
+    FEATURE_CHUNKS = 4
+
+    def _comm_chunks(self):
+        N = self.N
+        f_off, f_n = self.seg["features"]
+        q = (f_n // self.FEATURE_CHUNKS + 255) // 256 * 256
+        chunks = [("xyz", self.seg["xyz"][0], self.seg["xyz"][1])]
+        o = 0
+        while o < f_n:
+            chunks.append(("features", f_off + o, min(q, f_n - o)))
+            o += q
+        t_off = self.seg["opacity"][0]
+        chunks.append(("tail", t_off, self.flat.numel() - t_off))
+        return chunks
+
+    def _allreduce_and_adam(self, it):
+        chunks = self._comm_chunks()
+        pend = [parallel.allreduce_mean_async_(self.flat_grad[off:off + n], self.pg) for _, off, n in chunks]
+        f_off, _ = self.seg["features"]
+        for (kind, off, n), p in zip(chunks, pend):
+            p.wait()
+            if kind == "xyz":
+                self._adam_range(off, n, self.xyz_lr(it), it)
+            elif kind == "features":
+                # f_dc rows (the first 3N elements of the segment) use feature_lr, everything after feature_lr / 20
+                dc_left = max(0, f_off + 3 * self.N - off)
+                if dc_left > 0:
+                    self._adam_range(off, n, self.lrs["features"], it, lr_b=self.lrs["features_rest"], period=n,
+                                     split=min(dc_left, n))
+                else:
+                    self._adam_range(off, n, self.lrs["features_rest"], it)
+            else:
+                for name in ("opacity", "scaling", "rotation"):
+                    so, sn = self.seg[name]
+                    self._adam_range(so, sn, self.lrs[name], it)
+                so, sn = self.seg["c"]
+                self._adam_range(so, sn, self.c_lr, it, eps=1e-8)
+
+    def _adam_range(self, off, n, lr, it, eps=1e-15, **kw):
+        sl = slice(off, off + n)
+        losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, eps=eps, **kw)
 
     def _adam(self, it):
         for name, _ in SEGMENTS + (("c", 1),):

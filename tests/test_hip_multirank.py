@@ -1,0 +1,79 @@
+"""GPU: the multi-rank training step (view-parallel DP) end to end.  The box has one GPU, so the two
+ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); the code path is the one
+`bench.py --gpus N` runs -- chunked asynchronous mean of the flat gradient buffer pipelined with the per-chunk
+Adam launches -- and must equal the single-process emulation (mean of the two ranks' gradients, plain Adam)
+bit for bit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N, W, H, STEPS = 6000, 208, 144, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _inputs(rank):
+    from event_3dgs_amd import synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params = synth.make_scene(N, "trained", seed=0, device=DEV)
+    cams = [orbit_camera(3 * rank, 16, W, H, device=DEV, daz=d) for d in (0.0, 0.004, 0.012)]
+    bg = torch.zeros(3, device=DEV)
+    gp = dict(params)
+    gp["xyz"] = params["xyz"] + 0.01 * torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gt = EventTrainer(gp, DEV)
+    gts = [(torch.round(gt.render_raw(c, bg)["color"].clamp(0, 1) * 255.0) / 255.0).contiguous() for c in cams]
+    return params, cams, gts, bg
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams, gts, bg = _inputs(rank)
+    tr = EventTrainer(params, DEV)
+    assert tr.world == 2
+    for _ in range(STEPS):
+        tr.step(*cams, *gts, bg)
+    torch.cuda.synchronize()
+    torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu()}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_emulation(tmp_path):
+    out = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k                    # replicas stay identical
+    # single process: both ranks' gradients, their mean, plain (unchunked) Adam
+    from event_3dgs_amd.train_step import EventTrainer
+    assert not dist.is_initialized()
+    pa, ca, ga, bg = _inputs(0)
+    pb, cb, gb, _ = _inputs(1)
+    ta, tb = EventTrainer(pa, DEV), EventTrainer(pb, DEV)
+    for _ in range(STEPS):
+        ta.compute_gradients(*ca, *ga, bg)
+        tb.compute_gradients(*cb, *gb, bg)
+        mean = (ta.flat_grad + tb.flat_grad).div_(2)           # what gloo's SUM followed by div_(world) computes
+        ta.flat_grad.copy_(mean); tb.flat_grad.copy_(mean)
+        ta.apply_update(); tb.apply_update()
+    torch.cuda.synchronize()
+    assert torch.equal(ta.flat.cpu(), r0["flat"])
+    assert torch.equal(ta.exp_avg.cpu(), r0["m"])
+    assert torch.equal(ta.exp_avg_sq.cpu(), r0["v"])
+    # and the update really used both ranks' views
+    solo = EventTrainer(pa, DEV)
+    for _ in range(STEPS):
+        solo.step(*ca, *ga, bg)
+    assert not torch.equal(solo.flat.cpu(), r0["flat"])

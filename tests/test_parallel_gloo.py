@@ -39,7 +39,14 @@ def _worker(rank, world, port, out):
     torch.set_num_threads(2)
     act, _ = scene(300, 64, 48, seed=4)
     flat = _view_grad(act, rank, 64, 48)          # every rank: its own view of the replicated model
+    # the trainer's pipelined form: contiguous chunks, all collectives issued first, waited for one by one
+    chunked = flat.clone()
+    cuts = [0, 7, 100, 1000, chunked.numel()]
+    pend = [parallel.allreduce_mean_async_(chunked[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for p in pend:
+        p.wait()
     parallel.allreduce_mean_(flat)
+    assert torch.equal(chunked, flat)
     idx = [parallel.rank_camera_indices(r, world, 100, iteration=7) for r in range(world)]
     if rank == 0:
         torch.save({"flat": flat, "idx": idx}, out)
@@ -66,3 +73,25 @@ def test_allreduce_is_identity_without_process_group():
     from event_3dgs_amd import parallel
     t = torch.arange(5.0)
     assert torch.equal(parallel.allreduce_mean_(t.clone()), t)
+
+
+def test_comm_chunks_tile_the_flat_buffer():
+    """EventTrainer._comm_chunks: the six collectives cover every element of the flat gradient buffer once, in order,
+    and the f_dc / f_rest learning-rate boundary falls inside the first feature chunk."""
+    import types
+    from event_3dgs_amd.train_step import EventTrainer, SEGMENTS
+    for N in (1, 255, 1000, 1_000_000):
+        seg, off = {}, 0
+        for name, per in SEGMENTS:
+            seg[name] = (off, N * per); off += N * per
+        seg["c"] = (off, 1)
+        fake = types.SimpleNamespace(N=N, seg=seg, flat=torch.empty(0).new_empty(off + 1), FEATURE_CHUNKS=4)
+        chunks = EventTrainer._comm_chunks(fake)
+        pos = 0
+        for kind, o, n in chunks:
+            assert o == pos and n > 0
+            pos += n
+        assert pos == off + 1
+        feats = [c for c in chunks if c[0] == "features"]
+        assert feats[0][1] == seg["features"][0] and sum(c[2] for c in feats) == 48 * N
+        assert feats[0][2] >= min(3 * N, 48 * N)          # all f_dc rows sit in the first feature chunk
