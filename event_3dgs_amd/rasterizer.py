@@ -339,7 +339,7 @@ def forward_multi_begin(means3D, sh, opacities, scales, rotations, settings_list
     means3D_c, sh_c, opac_c = _prep(means3D, "means3D"), _prep(sh, "shs"), _prep(opacities, "opacities")
     scales_c, rots_c = _prep(scales, "scales"), _prep(rotations, "rotations")
     bg = _prep(rs.bg, "bg")
-    M = sh_c.shape[0] // 3 if (flags & _lib.FLAG_SH_PLANAR) else sh_c.shape[1]
+    M = sh.shape[0] // 3 if (flags & _lib.FLAG_SH_PLANAR) else sh.shape[1]       # (sh_c is None when P == 0)
     if count_host is None:
         count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
     arrays, keep = _view_arrays(settings_list)

@@ -337,3 +337,38 @@ def test_multi_view_argument_checks():
     with pytest.raises(Exception, match="nviews"):
         rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], five,
                                  flags=tr.FWD_FLAGS)
+
+
+def test_multi_view_edge_cases_empty_and_all_culled():
+    """P == 0 and "every Gaussian behind the cameras" through the multi-view pass (polled count included):
+    background images, zero instance count, zero gradients."""
+    from event_3dgs_amd import _lib, rasterizer
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    W, H = 70, 50
+    bg = torch.tensor([0.3, 0.6, 0.9], device=DEV)
+    cams = [orbit_camera(k, 16, W, H, device=DEV) for k in range(3)]
+    # ---- all culled: move the scene far behind every camera
+    params, _ = _scene(N=300)
+    tr = EventTrainer(params, DEV)
+    v = tr.views
+    v["xyz"].add_(1000.0)
+    settings = [tr._settings(c, bg) for c in cams]
+    for flags in (tr.FWD_FLAGS, tr.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED):
+        raw = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
+                                       flags=flags)
+        assert raw["num_rendered"] == 0 and int(raw["radii"].abs().sum()) == 0
+        assert torch.equal(raw["color"], bg.view(1, 3, 1, 1).expand(3, 3, H, W))
+        out = dict(opacities=torch.full((tr.N, 1), float("nan"), device=DEV), means3D=torch.full((tr.N, 3), float("nan"), device=DEV),
+                   sh=torch.full((48, tr.N), float("nan"), device=DEV), scales=torch.full((tr.N, 3), float("nan"), device=DEV),
+                   rots=torch.full((tr.N, 4), float("nan"), device=DEV))
+        rasterizer.backward_multi(raw, torch.ones(3, 3, H, W, device=DEV), out)
+        torch.cuda.synchronize()
+        for n, t in out.items():
+            assert float(t.abs().max()) == 0.0, n
+    # ---- P == 0
+    e = lambda *s: torch.empty(*s, device=DEV)
+    raw = rasterizer.forward_multi(e(0, 3), e(48, 0), e(0, 1), e(0, 3), e(0, 4), settings,
+                                   flags=tr.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED)
+    assert raw["num_rendered"] == 0 and tuple(raw["radii"].shape) == (3, 0)
+    assert torch.equal(raw["color"], bg.view(1, 3, 1, 1).expand(3, 3, H, W))
