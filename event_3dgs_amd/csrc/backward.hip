@@ -108,9 +108,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
             const float4 c = sC[wave][j];
             const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
             const float dx = a.x - pfx;
-            const float cxdx = a.z * dx;
-            const float qx = cxdx * dx;
-            const float cydx = a.w * dx;
+            // power(dy) = -(A dx^2 + C dy^2)/2 - B dx dy as a quadratic in dy (Horner: 2 FMAs per strip instead of the
+            // forward's 4-op expression, whose rounding order only the bit-exact forward has to keep)
+            const float h0 = -0.5f * (a.z * dx) * dx;     // -A dx^2 / 2
+            const float h1 = -(a.w * dx);                 // -B dx
+            const float h2 = -0.5f * b.x;                 // -C / 2
             // per-lane partial sums over its (up to) 4 pixels; h = dL/dG * G
             //   Sx = sum h dx, Sy = sum h dy, Sxx = sum h dx^2, Sxy = sum h dx dy, Syy = sum h dy^2,
             //   So = sum G dL/dalpha, Sc* = sum alpha T dL/dC*
@@ -119,8 +121,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dy = a.y - pfy[k];
-                const float q = FMA(b.x * dy, dy, qx);
-                const float power = FMA(-0.5f, q, -(cydx * dy));
+                const float power = FMA(FMA(h2, dy, h1), dy, h0);
                 // lane masks straight from the compares (SGPR pairs): 2 v_cmp + s_and + s_cbranch_scc;
                 // power > 0 is rejected by `valid`
                 const unsigned long long live_mask = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
