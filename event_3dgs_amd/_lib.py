@@ -7,9 +7,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+NOTIFY_FN = C.CFUNCTYPE(None, C.c_void_p)
 _fp, _ip, _vp, _cp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
 
 _lib = None
@@ -62,6 +63,10 @@ def lib():
     L.e3dgs_rasterize_forward_multi_finish.restype = C.c_int
     L.e3dgs_rasterize_forward_multi_finish.argtypes = [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp,
                                                        C.c_int, _fp, C.c_int, _vp]
+    L.e3dgs_rasterize_forward_multi_finish_colour.restype = C.c_int
+    L.e3dgs_rasterize_forward_multi_finish_colour.argtypes = (
+        [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp, C.c_int, _fp, C.c_int]
+        + [C.c_int, C.c_int, _fp, _fp, _pp, C.c_int, NOTIFY_FN, _vp, _vp])
     L.e3dgs_rasterize_backward_multi.restype = C.c_int
     L.e3dgs_rasterize_backward_multi.argtypes = (
         [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
@@ -121,12 +126,13 @@ FLAG_SH_PLANAR = 4
 FLAG_BWD_ONLY_RENDER = 8
 FLAG_BWD_ONLY_GEOM = 16
 FLAG_COUNT_MAPPED = 64
+FLAG_DEFER_COLOR = 128
 ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
     "e3dgs_rasterize_backward", "e3dgs_rasterize_forward_multi", "e3dgs_rasterize_forward_multi_begin",
-    "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_backward_multi",
+    "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

@@ -57,7 +57,7 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 3; }
+int e3dgs_abi_version(void) { return 4; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -259,6 +259,31 @@ int e3dgs_rasterize_forward_multi_finish(e3dgs_alloc_fn binning_alloc, void* bin
         return e3_fail(hipErrorInvalidValue, "bad arguments");
     return e3_forward_finish_impl(binning_alloc, binning_user, nviews, P, width, height, background, geom_buffer,
                                   image_buffer, num_rendered, out_color, debug, (hipStream_t)stream);
+}
+
+int e3dgs_rasterize_forward_multi_finish_colour(e3dgs_alloc_fn binning_alloc, void* binning_user, int nviews, int P,
+                                                int width, int height, const float* background, char* geom_buffer,
+                                                char* image_buffer, int num_rendered, float* out_color, int debug,
+                                                int D, int M, const float* means3D, const float* shs,
+                                                const float* const* cam_pos, int flags,
+                                                e3dgs_notify_fn before_colour, void* notify_user, void* stream) {
+    g_err[0] = 0;
+    if (nviews < 1 || nviews > E3_MAX_VIEWS || P < 0 || num_rendered < 0 || !geom_buffer || !image_buffer)
+        return e3_fail(hipErrorInvalidValue, "bad arguments");
+    if (P > 0 && (!means3D || !shs || !cam_pos)) return e3_fail(hipErrorInvalidValue, "means3D, shs and cam_pos are required");
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
+    DeferredColour dc;
+    dc.views.n = nviews;
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        const int u = v < nviews ? v : 0;
+        if (P > 0 && !cam_pos[u]) return e3_fail(hipErrorInvalidValue, "null per-view pointer");
+        dc.views.view[v] = nullptr; dc.views.proj[v] = nullptr; dc.views.campos[v] = P > 0 ? cam_pos[u] : nullptr;
+        dc.views.tanfovx[v] = 1.0f; dc.views.tanfovy[v] = 1.0f;        // colour only needs the camera position
+    }
+    dc.D = D; dc.M = M; dc.flags = flags; dc.means3D = means3D; dc.shs = shs;
+    dc.before = before_colour; dc.user = notify_user;
+    return e3_forward_finish_impl(binning_alloc, binning_user, nviews, P, width, height, background, geom_buffer,
+                                  image_buffer, num_rendered, out_color, debug, (hipStream_t)stream, &dc);
 }
 
 int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,

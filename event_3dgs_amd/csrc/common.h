@@ -26,6 +26,7 @@
 #define E3_FLAG_BWD_ONLY_RENDER 8   // backward: run only the compositing backward (fills grad_acc)
 #define E3_FLAG_BWD_ONLY_GEOM 16    // backward: run only the per-Gaussian backward (consumes grad_acc)
 #define E3_FLAG_COUNT_MAPPED 64     // begin: num_rendered_host is pinned + device-mapped; the GPU stores the count there
+#define E3_FLAG_DEFER_COLOR 128     // multi begin: no SH evaluation in preprocess; finish runs colour_kernel
 #define E3_MAX_VIEWS 4       // views per e3dgs_rasterize_backward_geom_multi call
 #define E3_ACC_STRIDE 12      // floats per (tile, Gaussian) instance in the backward gradient records
 
@@ -291,9 +292,17 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                           const float* shs, const float* colors, const float* opac, const float* scales,
                           float scale_modifier, const float* rots, const float* cov_pre, int* radii, int debug,
                           int flags, int* count_host, hipStream_t s);
+struct DeferredColour {          // inputs of colour_kernel (E3_FLAG_DEFER_COLOR), handed to `finish`
+    ViewBatch views;
+    int D, M, flags;
+    const float* means3D;
+    const float* shs;
+    void (*before)(void*);      // optional: called on the host right before colour_kernel is enqueued
+    void* user;
+};
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s);
+                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc = nullptr);
 int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_rendered, const float* background, int W,
                      int H, const float* means3D, const float* shs, const float* colors, const float* opacities,
                      const float* scales, float scale_modifier, const float* rots, const float* cov_pre,

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 if ((xmax - xmin) * (ymax - ymin) != 0) {
                     float rgb[3];
                     uint32_t cl = 0;
-                    if (shs) {
+                    if (shs && (flags & E3_FLAG_DEFER_COLOR)) {
+                        rgb[0] = rgb[1] = rgb[2] = 0.0f;          // colour_kernel fills colour + clamp mask later
+                    } else if (shs) {
                         const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
                         sh_to_rgb(D, planar ? shs + i : shs + (size_t)i * M * 3, planar ? (size_t)P : (size_t)1, mx, my,
                                   mz, vp.campos, rgb, cl);
@@ -189,6 +191,33 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         rect[q] = rect_out;
         key[q] = key_out;          // the depth sort's payload is q itself (identity_payload): no id array written
     }
+}
+
+// E3_FLAG_DEFER_COLOR: SH -> RGB of the visible splats as a kernel of its own, launched right before compositing.
+// The SH coefficients are 81 % of the parameter bytes; everything in front of the compositing kernel (projection,
+// both sorts, binning) does not need them, so a trainer can still be averaging / updating them (previous iteration's
+// all-reduce + Adam on another stream) while the next iteration builds its lists.  Same sh_to_rgb() as the
+// preprocess kernel: bit-identical colours.
+__global__ __launch_bounds__(256) void colour_kernel(int P, int nv, int D, int M, const float* __restrict__ means,
+                                                     const float* __restrict__ shs, ViewSet vs, int flags,
+                                                     const uint2* __restrict__ rect, float4* __restrict__ rec,
+                                                     uint32_t* __restrict__ clamped) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = nv == 1 ? q : q / nv;
+    if (i >= P) return;
+    const uint2 r = rect[q];
+    if (((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16)) == 0u) return;      // culled splat
+    const int v = q - i * nv;
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
+    float rgb[3];
+    uint32_t cl = 0;
+    sh_to_rgb(D, planar ? shs + i : shs + (size_t)i * M * 3, planar ? (size_t)P : (size_t)1, mx, my, mz, vs.v[v].campos,
+              rgb, cl);
+    float* rp = reinterpret_cast<float*>(rec + 3 * (size_t)q);
+    *reinterpret_cast<float2*>(rp + 6) = make_float2(rgb[0], rgb[1]);       // rec[1].zw
+    rp[8] = rgb[2];                                                         // rec[2].x
+    clamped[q] = cl;
 }
 
 __device__ __forceinline__ uint32_t rect_area(uint2 r) {
@@ -708,7 +737,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
 
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s) {
+                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc) {
     const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
     const int tiles_per_view = gx * gy;
     const int ntiles = tiles_per_view * nviews;
@@ -754,6 +783,17 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     launch_tile_order(ntiles, img.ranges, nullptr, img.order, s);
     }
     KERNEL_OK("tile_order_kernel");
+    if (dc && P > 0) {
+        // deferred SH -> RGB (E3_FLAG_DEFER_COLOR).  `before` lets the caller make this stream wait for whatever
+        // still owns the SH coefficients (e.g. the previous iteration's optimizer step on another stream).
+        if (dc->before) dc->before(dc->user);
+        ProfScope ps(PS_PREPROCESS, s);
+        const ViewSet vs = make_view_set(dc->views, W, H, 1.0f);
+        colour_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>(P, nviews, dc->D, dc->M, dc->means3D, dc->shs,
+                                                                             vs, dc->flags, geom.rect, geom.rec,
+                                                                             geom.clamped);
+        KERNEL_OK("colour_kernel");
+    }
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
         g_trace, ntiles, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,

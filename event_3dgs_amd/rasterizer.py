@@ -397,9 +397,24 @@ def prepare_multi_finish(pending):
         out_color = torch.empty(p.n, 3, p.H, p.W, dtype=torch.float32, device=p.device)
     binning = _Scratch(p.device, p.pool, "binning")
     fixed_a = (binning.cb, None, p.n, p.P, p.W, p.H, _lib.ptr(p.bg), _lib.ptr(p.geom), _lib.ptr(p.image))
-    fixed_b = (_lib.ptr(out_color), int(bool(p.rs.debug)), _lib.current_stream())
-    fn = L.e3dgs_rasterize_forward_multi_finish
-    p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b))
+    fixed_b = (_lib.ptr(out_color), int(bool(p.rs.debug)))
+    stream = _lib.current_stream()
+    if p.flags & _lib.FLAG_DEFER_COLOR:
+        # SH -> RGB right before compositing; `before_colour` (a Python callable set on the pending object) runs on
+        # the host just before that kernel is enqueued, e.g. to make the stream wait for the SH coefficients' owner
+        import ctypes as C
+        means3D_c, sh_c = p.inputs[0], p.inputs[1]
+        campos = (C.c_void_p * p.n)(*[t.data_ptr() for t in p.keep[2]])
+        hook = getattr(p, "before_colour", None)
+        notify = _lib.NOTIFY_FN((lambda _u: hook()) if hook else (lambda _u: None))
+        p._colour_keep = (campos, notify)
+        fn = L.e3dgs_rasterize_forward_multi_finish_colour
+        tail = (int(p.rs.sh_degree), p.M, _lib.ptr(means3D_c), _lib.ptr(sh_c), campos,
+                p.flags & _lib.FLAG_SH_PLANAR, notify, None, stream)
+        p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b, *tail))
+    else:
+        fn = L.e3dgs_rasterize_forward_multi_finish
+        p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b, stream))
     return p.prepared
 
 
@@ -414,7 +429,8 @@ def forward_multi_finish(pending):
         rc = call(I)
     _lib.check(rc, "e3dgs_rasterize_forward_multi_finish")
     return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, settings_list=p.settings_list,
-                flags=p.flags & ~_lib.FLAG_COUNT_MAPPED, inputs=p.inputs, opacities=p.opacities, bg=p.bg, keep=p.keep,
+                flags=p.flags & ~(_lib.FLAG_COUNT_MAPPED | _lib.FLAG_DEFER_COLOR), inputs=p.inputs,
+                opacities=p.opacities, bg=p.bg, keep=p.keep,
                 geom=p.geom, binning=binning.tensor, image=p.image, pool=p.pool)
 
 

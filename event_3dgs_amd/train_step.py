@@ -14,6 +14,7 @@ MI355X-first differences from the reference loop (results equal within fp32 tole
     torch.cat per render, gaussian_model.py:105-108) and keep their separate learning rates.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -56,12 +57,13 @@ class EventTrainer:
 
     def features_reference_layout(self):
         """(N,16,3) view-copy of the SH coefficients in the reference's layout (gaussian_model.py:105-108)."""
+        self.sync_features()
         return self.views["features"].t().reshape(self.N, 16, 3).contiguous()
 
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
-                 track_densification_stats=False):
+                 track_densification_stats=False, overlap_features=None):
         self.device = torch.device(device)
         self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
@@ -73,6 +75,21 @@ class EventTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.track_stats = track_densification_stats
+        # The SH coefficients are 48 of the 59 floats per Gaussian, and nothing in front of the compositing kernel reads
+        # them (E3DGS_FLAG_DEFER_COLOR).  With overlap_features their gradient averaging + Adam run on a second stream
+        # and the NEXT iteration's projection / sorts / binning proceed meanwhile; the main stream waits for them right
+        # before its colour kernel.  Results are identical to the serial order.  Default: on when there are several
+        # ranks (it hides up to ~0.75 ms of the xGMI-bound collective per iteration); off on one GPU, where the
+        # HBM-bound Adam and the next preprocess only compete for bandwidth and the separate colour kernel costs
+        # 60 us (measured 299 vs 302 iters/s).  E3DGS_OVERLAP=0/1 overrides.
+        if overlap_features is None:
+            overlap_features = self.world > 1
+        env = os.environ.get("E3DGS_OVERLAP")
+        if env is not None:
+            overlap_features = env != "0"
+        self.overlap_features = bool(overlap_features)
+        self._side = None
+        self._feat_event = None
         zeros = lambda t: torch.zeros_like(t)
         groups = {"xyz": params["xyz"], "f_dc": params["features_dc"], "f_rest": params["features_rest"],
                   "opacity": params["opacity"], "scaling": params["scaling"], "rotation": params["rotation"]}
@@ -127,6 +144,7 @@ class EventTrainer:
 
     def export_groups(self):
         """Reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]  (scene/gaussian_model.py:154-163 groups)."""
+        self.sync_features()
         N = self.N
         out = {}
         for idx, buf in enumerate((self.flat, self.exp_avg, self.exp_avg_sq)):
@@ -189,6 +207,7 @@ class EventTrainer:
 
     def render_raw(self, cam, bg):
         """Forward only, fused activations.  Returns the forward_raw dict (image in ["color"])."""
+        self.sync_features()
         v = self.views
         return rasterizer.forward_raw(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None,
                                       self._settings(cam, bg), flags=self.FWD_FLAGS)
@@ -207,10 +226,47 @@ class EventTrainer:
         compute_gradients() left in the flat buffer."""
         self.iteration += 1
         it = self.iteration
-        if self.world > 1 and sync_grads:
+        dist_on = self.world > 1 and sync_grads
+        if self.overlap_features:
+            self._update_overlapped(it, dist_on)
+        elif dist_on:
             self._allreduce_and_adam(it)                           # 59 floats/Gaussian + c, pipelined with Adam
         else:
             self._adam(it)
+
+    def sync_features(self):
+        """Make the current stream wait for the SH-coefficient update still running on the side stream (call before
+        anything other than step() touches the parameters: rendering, export, densification ...)."""
+        if self._feat_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._feat_event)
+            self._feat_event = None
+
+    def _update_overlapped(self, it, dist_on):
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        side = self._side
+        chunks = self._comm_chunks()
+        small = [c for c in chunks if c[0] != "features"]
+        feats = [c for c in chunks if c[0] == "features"]
+        grads_ready = main.record_event()
+        mean = (lambda c: parallel.allreduce_mean_async_(self.flat_grad[c[1]:c[1] + c[2]], self.pg)) if dist_on else \
+               (lambda c: None)
+        # every rank issues its collectives in the same order: small groups (main stream) first, then the features
+        pend_small = [(c, mean(c)) for c in small]
+        with torch.cuda.stream(side):
+            side.wait_event(grads_ready)
+            pend_feat = [(c, mean(c)) for c in feats]
+        for c, p in pend_small:
+            if p is not None:
+                p.wait()
+            self._adam_chunk(c, it)
+        with torch.cuda.stream(side):
+            for c, p in pend_feat:
+                if p is not None:
+                    p.wait()
+                self._adam_chunk(c, it)
+            self._feat_event = side.record_event()
 
     def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):
         """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer."""
@@ -219,9 +275,12 @@ class EventTrainer:
         v = self.views
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
         # ---- the three renders (train.py:144,159,161)
+        flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
+        if self.overlap_features:
+            flags |= _lib.FLAG_DEFER_COLOR         # projection / sorts / binning do not read the SH coefficients ...
         pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
-                                              settings, flags=self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED,
-                                              count_host=self._counts, pool=self._pool)
+                                              settings, flags=flags, count_host=self._counts, pool=self._pool)
+        pend.before_colour = self.sync_features    # ... whose update (side stream) must be done before the colour kernel
         rasterizer.prepare_multi_finish(pend)      # (host work done while the GPU still computes the count)
         rasterizer.wait_count(pend)                # the iteration's only host wait: the instance count (polled)
         raw = rasterizer.forward_multi_finish(pend)
@@ -265,25 +324,29 @@ class EventTrainer:
     def _allreduce_and_adam(self, it):
         chunks = self._comm_chunks()
         pend = [parallel.allreduce_mean_async_(self.flat_grad[off:off + n], self.pg) for _, off, n in chunks]
-        f_off, _ = self.seg["features"]
-        for (kind, off, n), p in zip(chunks, pend):
+        for c, p in zip(chunks, pend):
             p.wait()
-            if kind == "xyz":
-                self._adam_range(off, n, self.xyz_lr(it), it)
-            elif kind == "features":
-                # f_dc rows (the first 3N elements of the segment) use feature_lr, everything after feature_lr / 20
-                dc_left = max(0, f_off + 3 * self.N - off)
-                if dc_left > 0:
-                    self._adam_range(off, n, self.lrs["features"], it, lr_b=self.lrs["features_rest"], period=n,
-                                     split=min(dc_left, n))
-                else:
-                    self._adam_range(off, n, self.lrs["features_rest"], it)
+            self._adam_chunk(c, it)
+
+    def _adam_chunk(self, chunk, it):
+        kind, off, n = chunk
+        f_off, _ = self.seg["features"]
+        if kind == "xyz":
+            self._adam_range(off, n, self.xyz_lr(it), it)
+        elif kind == "features":
+            # f_dc rows (the first 3N elements of the segment) use feature_lr, everything after feature_lr / 20
+            dc_left = max(0, f_off + 3 * self.N - off)
+            if dc_left > 0:
+                self._adam_range(off, n, self.lrs["features"], it, lr_b=self.lrs["features_rest"], period=n,
+                                 split=min(dc_left, n))
             else:
-                for name in ("opacity", "scaling", "rotation"):
-                    so, sn = self.seg[name]
-                    self._adam_range(so, sn, self.lrs[name], it)
-                so, sn = self.seg["c"]
-                self._adam_range(so, sn, self.c_lr, it, eps=1e-8)
+                self._adam_range(off, n, self.lrs["features_rest"], it)
+        else:
+            for name in ("opacity", "scaling", "rotation"):
+                so, sn = self.seg[name]
+                self._adam_range(so, sn, self.lrs[name], it)
+            so, sn = self.seg["c"]
+            self._adam_range(so, sn, self.c_lr, it, eps=1e-8)
 
     def _adam_range(self, off, n, lr, it, eps=1e-15, **kw):
         sl = slice(off, off + n)
@@ -310,6 +373,7 @@ class EventTrainer:
     def step_autograd(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):
         """Same iteration through torch autograd: torch activations (gaussian_model.py:95-118), the drop-in
         rasteriser operator with in-kernel SH, the autograd event loss.  Gradients land in flat_grad."""
+        self.sync_features()
         self.iteration += 1
         it = self.iteration
         self.flat_grad.zero_()

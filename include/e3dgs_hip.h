@@ -34,6 +34,8 @@ extern "C" {
 
 /* Returns a device pointer to at least `bytes` bytes (256-B aligned), owned by the caller. */
 typedef char* (*e3dgs_alloc_fn)(void* user, size_t bytes);
+/* Plain host-side notification (see e3dgs_rasterize_forward_multi_finish_colour). */
+typedef void (*e3dgs_notify_fn)(void* user);
 
 /* ABI version; bumped on any signature change. */
 int e3dgs_abi_version(void);
@@ -59,6 +61,12 @@ const char* e3dgs_last_error(void);
                                        stores the count there itself (no copy command), so the caller may arm the
                                        word with a sentinel (-1) and poll it instead of synchronising the stream;
                                        with P == 0 the library writes 0 at once. */
+#define E3DGS_FLAG_DEFER_COLOR 128  /* forward_multi_begin: do not evaluate the SH colours in the preprocess kernel.  The
+                                       call MUST then be completed with e3dgs_rasterize_forward_multi_finish_colour,
+                                       which evaluates them (same arithmetic, bit-identical) right before compositing.
+                                       Nothing in front of the compositing kernel reads `shs`, so a trainer may still
+                                       be reducing / updating the SH coefficients of the previous iteration on
+                                       another stream while this iteration projects, sorts and bins. */
 #define E3DGS_FLAG_BWD_ONLY_RENDER 8   /* backward: only the compositing backward (pixels -> grad_acc) */
 #define E3DGS_FLAG_BWD_ONLY_GEOM 16    /* backward: only the per-Gaussian backward (grad_acc -> parameter gradients).
                                           Together these let a caller overlap the compositing backward of several
@@ -223,6 +231,18 @@ int e3dgs_rasterize_forward_multi_finish(
     int nviews, int P, int width, int height, const float* background,
     char* geom_buffer, char* image_buffer, int num_rendered,
     float* out_color, int debug, void* stream);
+
+/* finish() for a begin() issued with E3DGS_FLAG_DEFER_COLOR.  flags: E3DGS_FLAG_SH_PLANAR as given to begin().
+ * before_colour (optional) is called on the host immediately before the colour kernel is enqueued: make `stream`
+ * wait there for whatever still writes `shs`. */
+int e3dgs_rasterize_forward_multi_finish_colour(
+    e3dgs_alloc_fn binning_alloc, void* binning_user,
+    int nviews, int P, int width, int height, const float* background,
+    char* geom_buffer, char* image_buffer, int num_rendered,
+    float* out_color, int debug,
+    int D, int M, const float* means3D, const float* shs, const float* const* cam_pos, int flags,
+    e3dgs_notify_fn before_colour, void* notify_user,
+    void* stream);
 
 int e3dgs_rasterize_backward_multi(
     int nviews, int P, int D, int M, int num_rendered,

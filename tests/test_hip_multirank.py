@@ -34,14 +34,14 @@ def _inputs(rank):
     return params, cams, gts, bg
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from event_3dgs_amd.train_step import EventTrainer
     params, cams, gts, bg = _inputs(rank)
-    tr = EventTrainer(params, DEV)
-    assert tr.world == 2
+    tr = EventTrainer(params, DEV, overlap_features=overlap)
+    assert tr.world == 2 and tr.overlap_features == overlap
     for _ in range(STEPS):
         tr.step(*cams, *gts, bg)
     torch.cuda.synchronize()
@@ -50,9 +50,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_single_process_emulation(tmp_path):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_equal_single_process_emulation(tmp_path, overlap):
+    """overlap=True: the SH-coefficient collectives + Adam run on a side stream under the next iteration's
+    projection / sorts / binning (deferred colour kernel); overlap=False: everything in order on one stream."""
     out = str(tmp_path / "rank")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k                    # replicas stay identical
@@ -61,7 +64,7 @@ def test_two_ranks_equal_single_process_emulation(tmp_path):
     assert not dist.is_initialized()
     pa, ca, ga, bg = _inputs(0)
     pb, cb, gb, _ = _inputs(1)
-    ta, tb = EventTrainer(pa, DEV), EventTrainer(pb, DEV)
+    ta, tb = EventTrainer(pa, DEV, overlap_features=False), EventTrainer(pb, DEV, overlap_features=False)
     for _ in range(STEPS):
         ta.compute_gradients(*ca, *ga, bg)
         tb.compute_gradients(*cb, *gb, bg)

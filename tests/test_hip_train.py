@@ -262,8 +262,9 @@ def test_fit_loop_with_densification_and_eval(tmp_path):
     assert torch.equal(a, b)                                   # the PLY holds the exact pre-activation state
 
 
+@pytest.mark.parametrize("defer_colour", [False, True])
 @pytest.mark.parametrize("nviews", [1, 2, 3, 4])
-def test_multi_view_pass_equals_single_view_calls(nviews):
+def test_multi_view_pass_equals_single_view_calls(nviews, defer_colour):
     """e3dgs_rasterize_forward_multi / _backward_multi against nviews separate single-view calls: images and
     radii bit-identical; gradients == the sum of the per-view gradients (what autograd's accumulation of the
     per-render backward calls produces at train.py:211).  Gradient buffers start as NaN to prove every element
@@ -297,8 +298,9 @@ def test_multi_view_pass_equals_single_view_calls(nviews):
             m2d_ref = single["means2D"]
     # ---- one multi-view pass
     def multi():
+        # defer_colour: SH -> RGB in its own kernel right before compositing (E3DGS_FLAG_DEFER_COLOR): same bits
         raw = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
-                                       flags=tr.FWD_FLAGS)
+                                       flags=tr.FWD_FLAGS | (_lib.FLAG_DEFER_COLOR if defer_colour else 0))
         out = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
         out["means2D"] = torch.full((tr.N, 3), float("nan"), device=DEV)
         rasterizer.backward_multi(raw, dpix, out)
