@@ -188,10 +188,9 @@ struct GeomState {
     }
 };
 
-// binning state: everything sized by the instance count I.  point_list is first (backward reads it).
+// binning state: everything sized by the instance count I.
 struct BinningState {
     uint32_t* perm;       // sorted instance list (tile-major, depth order) as SLOT indices     [read by fwd + bwd]
-    uint32_t* point_list; // unused scratch (kept so that offsets stay stable)
     uint32_t* vals_alt;
     uint32_t* keys;       // tile ids
     uint32_t* keys_alt;
@@ -206,7 +205,6 @@ struct BinningState {
         BinningState b;
         size_t n = I ? I : 1;
         b.perm = carve<uint32_t>(p, n);
-        b.point_list = carve<uint32_t>(p, 1);
         b.vals_alt = carve<uint32_t>(p, n);
         b.keys = carve<uint32_t>(p, n);
         b.keys_alt = carve<uint32_t>(p, n);
@@ -217,7 +215,7 @@ struct BinningState {
 };
 
 struct ImageState {
-    uint2* ranges;       // per tile [start, end) into point_list
+    uint2* ranges;       // per tile [start, end) into BinningState::perm
     float* final_T;      // per pixel
     uint32_t* n_contrib; // per pixel
     uint32_t* order;     // tiles by descending list length (launch order of the forward compositing kernel)

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
                                                               const float4* __restrict__ rec, int gx, int cull,
                                                               const uint32_t* __restrict__ wave_offsets,
                                                               uint32_t* __restrict__ wave_counts,
-                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                              uint32_t* __restrict__ keys,
                                                               uint32_t* __restrict__ emit_gid,
                                                               uint2* __restrict__ run_sorted) {
     __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
@@ -721,7 +721,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nv, ntiles, order, geom.rect, geom.rec,
                                                                      vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
-                                                                     nullptr, nullptr, nullptr, nullptr);
+                                                                     nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
         }
@@ -762,7 +762,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nviews, tiles_per_view, geom.ord0,
                                                                     geom.rect, geom.rec, gx, g_tile_cull, geom.offsets,
-                                                                    nullptr, k0, v0, bin.emit_gid, geom.run);
+                                                                    nullptr, k0, bin.emit_gid, geom.run);
         }
         KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
