@@ -160,6 +160,7 @@ int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_al
     g_err[0] = 0;
     int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
     if (rc) return rc;
+    flags &= ~(E3_FLAG_DEFER_COLOR | E3_FLAG_COUNT_MAPPED);     // only meaningful for the split multi-view calls
     return forward_sync(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user,
                         one_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy), P, D, M, background, width,
                         height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
@@ -176,6 +177,7 @@ int e3dgs_rasterize_forward_begin(e3dgs_alloc_fn geom_alloc, void* geom_user, e3
     g_err[0] = 0;
     int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
     if (rc) return rc;
+    flags &= ~E3_FLAG_DEFER_COLOR;                             // the single-view finish has no colour stage
     return e3_forward_begin_impl(geom_alloc, geom_user, image_alloc, image_user,
                                  one_view(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy), P, D, M, width, height,
                                  means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
@@ -227,6 +229,7 @@ int e3dgs_rasterize_forward_multi(e3dgs_alloc_fn geom_alloc, void* geom_user, e3
     ViewBatch vb;
     rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
     if (rc) return rc;
+    flags &= ~(E3_FLAG_DEFER_COLOR | E3_FLAG_COUNT_MAPPED);
     return forward_sync(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, vb, P, D, M,
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                         rotations, cov3D_precomp, out_color, radii, debug, flags, num_rendered_host, stream);
