@@ -43,6 +43,21 @@ class DensifyStats:
         self.xyz_gradient_accum = self.xyz_gradient_accum + visf * torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True)
         self.denom = self.denom + visf
 
+    def sync(self, group=None):
+        """Multi-rank training: every rank accumulated the statistics of ITS camera triplets; before a
+        densification step they are combined -- sum of the gradient-norm accumulators and view counts, max of the
+        screen radii -- so that all ranks take the identical clone / split / prune decisions.  (Every densification
+        step resets the statistics, so combining the accumulators equals combining the per-iteration deltas.)"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        both = torch.cat((self.xyz_gradient_accum, self.denom), dim=1).contiguous()
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        self.xyz_gradient_accum, self.denom = both[:, :1].contiguous(), both[:, 1:].contiguous()
+        r = self.max_radii2D.contiguous()
+        dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+        self.max_radii2D = r
+
     def _zero(self, n, device):
         self.xyz_gradient_accum = torch.zeros(n, 1, device=device)
         self.denom = torch.zeros(n, 1, device=device)

@@ -6,7 +6,9 @@ from random import randint
 
 import torch
 
-from . import densify
+import torch.distributed as dist
+
+from . import densify, parallel
 from .train_step import EventTrainer
 
 HELD_OUT = (5, 25, 45, 65, 85)       # evaluation views, train.py:129-131 / eval.py:118
@@ -24,16 +26,27 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
                     blurry_cameras=None, densify_until_iter=15000, densify_from_iter=500, densification_interval=100,
                     opacity_reset_interval=10000, densify_grad_threshold=0.0002, percent_dense=0.01, white_background=False,
                     sh_ramp_interval=1000, max_sh_degree=3, start_sh_degree=0, rng=randint, on_iteration=None,
-                    **trainer_kw):
+                    seed=0, **trainer_kw):
     """Returns the trained EventTrainer.  opacity_reset_interval defaults to the event-mode value the reference
-    forces at train.py:119.  `params` = pre-activation dict (synth.make_scene / scene_io.create_from_pcd)."""
+    forces at train.py:119.  `params` = pre-activation dict (synth.make_scene / scene_io.create_from_pcd).
+
+    With an initialised process group (one process per GPU) every rank draws its own camera triplet
+    (parallel.rank_camera_indices), gradients are averaged inside EventTrainer.step, and before each densification
+    step the statistics are combined over the ranks and the split sampler is seeded identically, so the replicas
+    stay bit-identical through clone / split / prune."""
     tr = EventTrainer(params, device, spatial_lr_scale=cameras_extent, active_sh_degree=start_sh_degree,
                       track_densification_stats=True, **trainer_kw)
     stats = densify.DensifyStats(tr.N, device)
+    world = dist.get_world_size(tr.pg) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(tr.pg) if world > 1 else 0
     for iteration in range(1, iterations + 1):
         if iteration % sh_ramp_interval == 0 and tr.active_sh_degree < max_sh_degree:      # train.py:99-100
             tr.active_sh_degree += 1
-        index = sample_index(len(train_cameras), True, rng)
+        if world > 1:
+            index = parallel.rank_camera_indices(rank, world, len(train_cameras), iteration, seed, HELD_OUT)
+            index = min(index, len(train_cameras) - 4)                                      # index + 1 must exist
+        else:
+            index = sample_index(len(train_cameras), True, rng)
         cam, now, nxt = train_cameras[index], event_cameras[index], event_cameras[index + 1]
         blur = blurry_cameras[index].original_image if blurry_cameras else None             # train.py:197-203
         scalars = tr.step(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image, bg, gt_blur=blur)
@@ -43,6 +56,9 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
         if upd:                                                                             # train.py:317-327
             stats.update(tr.viewspace_grad, tr.last_radii)
             if dens:
+                if world > 1:
+                    stats.sync(tr.pg)
+                    torch.manual_seed(seed * 1000003 + iteration)       # identical torch.normal draws in the split
                 tr.densify_and_prune(stats, densify_grad_threshold, 0.005, cameras_extent, size_thr, percent_dense)
             if reset:
                 tr.reset_opacity()

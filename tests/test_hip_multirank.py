@@ -80,3 +80,47 @@ def test_two_ranks_equal_single_process_emulation(tmp_path, overlap):
     for _ in range(STEPS):
         solo.step(*ca, *ga, bg)
     assert not torch.equal(solo.flat.cpu(), r0["flat"])
+
+
+def _fit_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from event_3dgs_amd import fit, synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    Wf, Hf, K = 112, 80, 32
+    bg = torch.zeros(3, device=DEV)
+    gt_params = synth.make_scene(2500, "trained", seed=9, device=DEV)
+    gt_tr = EventTrainer(gt_params, DEV, overlap_features=False)
+    q8 = lambda t: (torch.round(t.clamp(0, 1) * 255) / 255).contiguous()
+    train, events = [], []
+    for k in range(K):
+        for lst, daz in ((train, 0.0), (events, 0.003)):
+            c = orbit_camera(k, K, Wf, Hf, device=DEV, daz=daz)
+            c.original_image = q8(gt_tr.render_raw(c, bg)["color"])
+            lst.append(c)
+    params = synth.make_scene(1200, "trained", seed=3, device=DEV)
+    sizes = []
+    tr = fit.fit_event_scene(params, train, events, bg, DEV, iterations=14, cameras_extent=4.4, densify_from_iter=3,
+                             densification_interval=5, densify_grad_threshold=1e-9, start_sh_degree=3, seed=5,
+                             on_iteration=lambda it, t, s: sizes.append(t.N))
+    torch.cuda.synchronize()
+    g = tr.export_groups()
+    torch.save({"sizes": sizes, "xyz": g["xyz"][0].cpu(), "f_rest": g["f_rest"][0].cpu(), "m": g["scaling"][1].cpu()},
+               f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_with_densification_keeps_replicas_identical(tmp_path):
+    """The event training loop on two ranks: per-rank camera draws, averaged gradients, densification statistics
+    combined over the ranks (sum / max) and an identically seeded split sampler -- after two densification steps the
+    replicas hold the same number of Gaussians and bit-identical parameters and optimizer state."""
+    out = str(tmp_path / "fit")
+    mp.spawn(_fit_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["sizes"] == r1["sizes"]
+    assert r0["sizes"][0] == 1200 and r0["sizes"][-1] != 1200          # densification really changed the model
+    for k in ("xyz", "f_rest", "m"):
+        assert torch.equal(r0[k], r1[k]), k
