@@ -34,11 +34,20 @@ for f in ("fetch", "write"):
     for k, v in agg.items():
         out.setdefault(k, {})[f"{f.upper()}_SIZE_KB_avg"] = sum(v) / len(v)
         out[k][f"{f}_launches"] = len(v)
+# gfx950 corrections, calibrated with tools/ubench/pmc_calib.hip on this stack (known byte counts):
+#   FETCH_SIZE reports HALF of the fetched bytes for coalesced 16-B/lane streams (1 GiB read -> 524 299 KB) AND for
+#   the scattered 48-B record gathers of the compositing kernels (8 Mi records: 654 057 KB = 8 Mi x 1.25 lines x 128 B / 2:
+#   it counts 128-B line requests at 64 B) -> x2;  WRITE_SIZE is exact for streams (1 GiB -> 1 048 576 KB) and counts
+#   32-B sectors for scattered 48-B stores (8 Mi records: 554 049 KB) -> x1.
+FETCH_CORRECTION, WRITE_CORRECTION = 2.0, 1.0
 for k, v in out.items():
-    v["hbm_bytes_per_launch"] = int((v.get("FETCH_SIZE_KB_avg", 0) + v.get("WRITE_SIZE_KB_avg", 0)) * 1024)
-    v["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, KB units, 3-view launches of the timed steps only, "
-                 "kernel dispatches serialised by the profiler; FETCH_SIZE is known to under-count wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md); "
-                 "uncorrected here because these kernels gather 16-B records")
+    v["hbm_bytes_per_launch"] = int((FETCH_CORRECTION * v.get("FETCH_SIZE_KB_avg", 0) +
+                                     WRITE_CORRECTION * v.get("WRITE_SIZE_KB_avg", 0)) * 1024)
+    v["fetch_correction"], v["write_correction"] = FETCH_CORRECTION, WRITE_CORRECTION
+    v["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, KB units, 3-view launches of the timed steps "
+                 "only, kernel dispatches serialised by the profiler; hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE "
+                 "(gfx950 correction of MI355X_MICROARCH.md, re-calibrated for 48-B record gathers/scatters with "
+                 "tools/ubench/pmc_calib.hip: fetches are 128-B lines counted at 64 B)")
 json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1)
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(open(f"{dst}/kernel_stats_top.txt").read())
