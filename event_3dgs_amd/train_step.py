@@ -285,11 +285,12 @@ class EventTrainer:
         rasterizer.wait_count(pend)                # the iteration's only host wait: the instance count (polled)
         raw = rasterizer.forward_multi_finish(pend)
         imgs = raw["color"]
-        if self._loss_bufs is None or self._loss_bufs[1].shape != imgs.shape:
-            self._loss_bufs = (torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(imgs),
+        key = ("event",) + tuple(imgs.shape)
+        if self._loss_bufs is None or self._loss_bufs[0] != key:
+            self._loss_bufs = (key, torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(imgs),
                                torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(imgs.shape[3], imgs.shape[2]),
                                            dtype=torch.uint8, device=self.device))
-        sc, dpix, scratch = self._loss_bufs
+        _, sc, dpix, scratch = self._loss_bufs
         scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[1], imgs[2], self.c, gt_int, gt_now, gt_next, gt_blur,
                                                  out=(sc, dpix[0], dpix[1], dpix[2], scratch))     # train.py:165-203
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
@@ -368,6 +369,90 @@ class EventTrainer:
                 lr, kw = self.lrs[name], {}
             losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, eps=eps,
                               **kw)
+
+    # ------------------------------------------------------------------ the other two training modes of train.py
+    def step_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2, sync_grads=True):
+        """One iteration of the reference's `--gray` (train.py:213-223) or RGB (train.py:292-296) mode on the fused
+        path: ONE render, loss = (1 - lambda) L1 + lambda (1 - SSIM) (gray: both terms on rgb_to_grayscale), backward,
+        Adam.  No autograd graph; the SSIM kernel returns its own gradient.  Returns the loss as a device scalar."""
+        if mode not in ("gray", "rgb"):
+            raise ValueError("mode must be 'gray' or 'rgb'")
+        loss = self.compute_gradients_image(cam, gt_image, bg, mode, lambda_dssim)
+        self.apply_update(sync_grads)
+        return loss
+
+    def compute_gradients_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):
+        if self._counts is None:
+            self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
+        v = self.views
+        flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
+        if self.overlap_features:
+            flags |= _lib.FLAG_DEFER_COLOR
+        pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                              [self._settings(cam, bg)], flags=flags, count_host=self._counts,
+                                              pool=self._pool)
+        pend.before_colour = self.sync_features
+        rasterizer.prepare_multi_finish(pend)
+        rasterizer.wait_count(pend)
+        raw = rasterizer.forward_multi_finish(pend)
+        img = raw["color"][0]
+        gt = gt_image if gt_image.dtype == torch.float32 else gt_image.float()
+        gt = gt.contiguous()
+        gray = mode == "gray"
+        L = _lib.lib()
+        C, H, W = img.shape
+        key = ("img", C, H, W)
+        if self._loss_bufs is None or self._loss_bufs[0] != key:
+            self._loss_bufs = (key, torch.empty(1, dtype=torch.float32, device=self.device), torch.empty(1, C, H, W, device=self.device),
+                               torch.empty(L.e3dgs_ssim_scratch_bytes(C, H, W), dtype=torch.uint8, device=self.device))
+        _, ssim_val, dpix, scratch = self._loss_bufs
+        d = dpix[0]
+        with torch.cuda.device(self.device):
+            rc = L.e3dgs_ssim(C, H, W, int(gray), _lib.ptr(img), _lib.ptr(gt), _lib.ptr(ssim_val), _lib.ptr(d),
+                              _lib.ptr(scratch), _lib.current_stream())
+        _lib.check(rc, "e3dgs_ssim")
+        # d holds dSSIM/dimage; loss = (1 - lambda) L1 + lambda (1 - SSIM)
+        if gray:                                   # utils/loss_utils.py:18-23,40-48: L1 on 0.299 R + 0.587 G + 0.114 B
+            w = img.new_tensor([0.299, 0.587, 0.114]).view(3, 1, 1)
+            diff = ((img - gt) * w).sum(0, keepdim=True)
+            l1 = diff.abs().mean()
+            d.mul_(-lambda_dssim).add_(torch.sign(diff) * w, alpha=(1.0 - lambda_dssim) / (H * W))
+        else:                                      # utils/loss_utils.py:270-271
+            diff = img - gt
+            l1 = diff.abs().mean()
+            d.mul_(-lambda_dssim).add_(torch.sign(diff), alpha=(1.0 - lambda_dssim) / diff.numel())
+        loss = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim_val[0])
+        g = self.grads
+        out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
+        if self.track_stats:
+            out["means2D"] = self.viewspace_grad
+        rasterizer.backward_multi(raw, dpix, out)
+        self.c_grad.zero_()                        # the contrast threshold only exists in the event loss
+        self.last_radii = raw["radii"][0]
+        self.last_scalars = loss
+        return loss
+
+    def step_image_autograd(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):
+        """The same iteration through torch autograd (torch activations, drop-in operator, autograd losses): the
+        equivalence check of step_image."""
+        self.sync_features()
+        self.iteration += 1
+        it = self.iteration
+        self.flat_grad.zero_()
+        leaves = {k: v.detach().requires_grad_(True) for k, v in self.views.items()}
+        feats_ref = leaves["features"].t().reshape(self.N, 16, 3)
+        scales, rots = torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"])
+        opac = torch.sigmoid(leaves["opacity"])
+        m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
+        img, radii = rasterize_gaussians(leaves["xyz"], m2, feats_ref, None, opac, scales, rots, None,
+                                         self._settings(cam, bg))
+        fn = losses.gray_iteration_loss if mode == "gray" else losses.rgb_iteration_loss
+        loss = fn(img, gt_image, lambda_dssim)
+        loss.backward()
+        for k, v in leaves.items():
+            self.grads[k].copy_(v.grad)
+        self._adam(it)
+        return loss.detach()
 
     # ------------------------------------------------------------------ reference-style path (autograd)
     def step_autograd(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):

@@ -374,3 +374,28 @@ def test_multi_view_edge_cases_empty_and_all_culled():
                                    flags=tr.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED)
     assert raw["num_rendered"] == 0 and tuple(raw["radii"].shape) == (3, 0)
     assert torch.equal(raw["color"], bg.view(1, 3, 1, 1).expand(3, 3, H, W))
+
+
+@pytest.mark.parametrize("mode", ["gray", "rgb"])
+def test_fused_image_step_equals_autograd_step(mode):
+    """The `--gray` (train.py:213-223) and RGB (train.py:292-296) iterations on the fused path -- one render, L1 + SSIM
+    with the SSIM kernel's own gradient, no autograd graph -- against the same iteration through torch autograd."""
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene()
+    bg = torch.zeros(3, device=DEV)
+    gt = _gts(params, cams, bg)[0]
+    a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
+    la = a.step_image(cams[0], gt, bg, mode=mode)
+    lb = b.step_image_autograd(cams[0], gt, bg, mode=mode)
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    for name in ("xyz", "features", "opacity", "scaling", "rotation"):
+        ga, gb = a.grads[name].cpu().numpy(), b.grads[name].cpu().numpy()
+        assert np.abs(gb).max() > 0
+        assert rel_l2(ga, gb) <= 1e-3, (name, rel_l2(ga, gb))
+    assert rel_l2(a.exp_avg.cpu().numpy(), b.exp_avg.cpu().numpy()) <= 1e-3
+    # a few steps train: the loss goes down
+    first = float(la)
+    for _ in range(15):
+        last = float(a.step_image(cams[0], gt, bg, mode=mode))
+    assert last < first
