@@ -24,16 +24,23 @@ def sample_index(n_cameras, event=True, rng=randint):
 
 def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations, cameras_extent=1.0,
                     blurry_cameras=None, densify_until_iter=15000, densify_from_iter=500, densification_interval=100,
-                    opacity_reset_interval=10000, densify_grad_threshold=0.0002, percent_dense=0.01, white_background=False,
+                    opacity_reset_interval=None, densify_grad_threshold=0.0002, percent_dense=0.01, white_background=False,
                     sh_ramp_interval=1000, max_sh_degree=3, start_sh_degree=0, rng=randint, on_iteration=None,
-                    seed=0, **trainer_kw):
-    """Returns the trained EventTrainer.  opacity_reset_interval defaults to the event-mode value the reference
-    forces at train.py:119.  `params` = pre-activation dict (synth.make_scene / scene_io.create_from_pcd).
+                    seed=0, mode="event", lambda_dssim=0.2, **trainer_kw):
+    """Returns the trained EventTrainer.  opacity_reset_interval defaults to the value the reference uses for the
+    mode (10000 forced in event mode at train.py:119, otherwise the 3000 of arguments/__init__.py).  `params` = pre-activation dict (synth.make_scene / scene_io.create_from_pcd).
 
     With an initialised process group (one process per GPU) every rank draws its own camera triplet
     (parallel.rank_camera_indices), gradients are averaged inside EventTrainer.step, and before each densification
     step the statistics are combined over the ranks and the split sampler is seeded identically, so the replicas
-    stay bit-identical through clone / split / prune."""
+    stay bit-identical through clone / split / prune.
+
+    mode: "event" (train.py:149-212, the north-star path), "gray" (train.py:213-223) or "rgb" (train.py:292-296);
+    the last two render one camera per iteration and need no event cameras (event_cameras may be None)."""
+    if mode not in ("event", "gray", "rgb"):
+        raise ValueError("mode must be 'event', 'gray' or 'rgb'")
+    if opacity_reset_interval is None:              # train.py:119 forces 10000 in event mode; arguments/__init__.py: 3000
+        opacity_reset_interval = 10000 if mode == "event" else 3000
     tr = EventTrainer(params, device, spatial_lr_scale=cameras_extent, active_sh_degree=start_sh_degree,
                       track_densification_stats=True, **trainer_kw)
     stats = densify.DensifyStats(tr.N, device)
@@ -46,10 +53,15 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
             index = parallel.rank_camera_indices(rank, world, len(train_cameras), iteration, seed, HELD_OUT)
             index = min(index, len(train_cameras) - 4)                                      # index + 1 must exist
         else:
-            index = sample_index(len(train_cameras), True, rng)
-        cam, now, nxt = train_cameras[index], event_cameras[index], event_cameras[index + 1]
-        blur = blurry_cameras[index].original_image if blurry_cameras else None             # train.py:197-203
-        scalars = tr.step(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image, bg, gt_blur=blur)
+            index = sample_index(len(train_cameras), mode == "event", rng)
+        cam = train_cameras[index]
+        if mode == "event":
+            now, nxt = event_cameras[index], event_cameras[index + 1]
+            blur = blurry_cameras[index].original_image if blurry_cameras else None         # train.py:197-203
+            scalars = tr.step(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image, bg,
+                              gt_blur=blur)
+        else:
+            scalars = tr.step_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim)
         upd, dens, size_thr, reset = densify.densification_schedule(
             iteration, densify_until_iter, densify_from_iter, densification_interval, opacity_reset_interval,
             white_background)

@@ -399,3 +399,27 @@ def test_fused_image_step_equals_autograd_step(mode):
     for _ in range(15):
         last = float(a.step_image(cams[0], gt, bg, mode=mode))
     assert last < first
+
+
+@pytest.mark.parametrize("mode", ["gray", "rgb"])
+def test_fit_loop_image_modes(mode):
+    """fit_event_scene in the reference's `--gray` / RGB modes: one render per iteration, densification schedule."""
+    import random
+    from event_3dgs_amd import fit, synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    W, H, K = 96, 64, 24
+    bg = torch.zeros(3, device=DEV)
+    gt_tr = EventTrainer(synth.make_scene(2000, "trained", seed=9, device=DEV), DEV)
+    train = []
+    for k in range(K):
+        c = orbit_camera(k, K, W, H, device=DEV)
+        c.original_image = gt_tr.render_raw(c, bg)["color"].clamp(0, 1).contiguous()
+        train.append(c)
+    losses_seen, sizes = [], []
+    tr = fit.fit_event_scene(synth.make_scene(1500, "trained", seed=4, device=DEV), train, None, bg, DEV, iterations=40,
+                             cameras_extent=4.4, densify_from_iter=10, densification_interval=15, start_sh_degree=3,
+                             densify_grad_threshold=1e-9, rng=random.Random(1).randint, mode=mode,
+                             on_iteration=lambda it, t, s: (losses_seen.append(float(s)), sizes.append(t.N)))
+    assert sizes[-1] != 1500 and np.isfinite(losses_seen).all()
+    assert np.mean(losses_seen[-8:]) < 1.25 * np.mean(losses_seen[:8])     # random views + densification: no blow-up
