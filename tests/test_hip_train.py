@@ -423,3 +423,44 @@ def test_fit_loop_image_modes(mode):
                              on_iteration=lambda it, t, s: (losses_seen.append(float(s)), sizes.append(t.N)))
     assert sizes[-1] != 1500 and np.isfinite(losses_seen).all()
     assert np.mean(losses_seen[-8:]) < 1.25 * np.mean(losses_seen[:8])     # random views + densification: no blow-up
+
+
+def test_multi_view_many_tiles_and_huge_splats():
+    """Paths the benchmark configuration does not reach: more than 32 K tiles in one call (fallback LPT ordering kernel,
+    16-bit tile keys) and splats that cover hundreds of tiles (long candidate walks in the binning kernels, tile lists
+    far beyond one 64-entry round).  The multi-view pass must still equal the single-view calls bit for bit."""
+    from event_3dgs_amd import rasterizer
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, _ = _scene(N=1500)
+    params = dict(params)
+    params["scaling"] = params["scaling"] + math.log(6.0)            # 6x larger splats
+    W, H, nviews = 2048, 1152, 4                                      # 128 x 72 x 4 = 36 864 tiles
+    cams = [orbit_camera(k, 8, W, H, device=DEV, daz=0.02 * k) for k in range(nviews)]
+    bg = torch.tensor([0.1, 0.0, 0.2], device=DEV)
+    tr = EventTrainer(params, DEV)
+    v = tr.views
+    raw = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                   [tr._settings(c, bg) for c in cams], flags=tr.FWD_FLAGS)
+    assert raw["num_rendered"] > 300 * tr.N                           # hundreds of tiles per splat
+    total = 0
+    for k, cam in enumerate(cams):
+        one = tr.render_raw(cam, bg)
+        total += one["num_rendered"]
+        assert torch.equal(raw["color"][k], one["color"]), k
+        assert torch.equal(raw["radii"][k], one["radii"]), k
+    assert raw["num_rendered"] == total
+    names = dict(means3D=v["xyz"], sh=v["features"], opacities=v["opacity"], scales=v["scaling"], rots=v["rotation"])
+    dpix = torch.randn(nviews, 3, H, W, generator=torch.Generator().manual_seed(2)).to(DEV)
+    out = {n: torch.full_like(t, float("nan")) for n, t in names.items()}
+    rasterizer.backward_multi(raw, dpix, out)
+    ref = {n: torch.zeros_like(t) for n, t in names.items()}
+    for k, cam in enumerate(cams):
+        single = {n: torch.empty_like(t) for n, t in names.items()}
+        rasterizer.backward_raw(tr.render_raw(cam, bg), dpix[k], single, flags=tr.FWD_FLAGS)
+        for n in names:
+            ref[n] += single[n]
+    torch.cuda.synchronize()
+    for n in names:
+        assert torch.isfinite(out[n]).all(), n
+        assert rel_l2(out[n].cpu(), ref[n].cpu()) < 5e-6, n
