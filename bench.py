@@ -196,6 +196,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows)
 
+    # gradient exchange per iteration and rank: mean of the non-SH groups (+ of the SH gradient unless it is rebuilt
+    # from the all-gathered per-view colour gradients, EventTrainer.factorize_sh)
+    if world == 1:
+        grad_ar_bytes = grad_ag_bytes = 0
+    elif trainer.factorize_sh:
+        grad_ar_bytes, grad_ag_bytes = 4 * (11 * N + 1), 4 * (27 * N + 9)
+    else:
+        grad_ar_bytes, grad_ag_bytes = 4 * (FLOATS_PER_GAUSSIAN * N + 1), 0
     if rank == 0:
         iters_per_s = args.steps * world / dt
         out = {
@@ -205,7 +213,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "gaussians": N, "width": W, "height": H, "visible": vis,
                        "tile_instances": I1, "tile_instances_3views": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
-                       "parallelism": f"view-dp{world}", "grad_allreduce_bytes": 4 * FLOATS_PER_GAUSSIAN * N if world > 1 else 0,
+                       "parallelism": f"view-dp{world}", "grad_allreduce_bytes": grad_ar_bytes,
+                       "sh_colour_allgather_bytes_per_rank": grad_ag_bytes,
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
     MultiViews mv, int flags, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-    float* __restrict__ dL_drot) {
+    float* __restrict__ dL_drot, float* __restrict__ gcol /* (n, P, 3) or null: per-view clamp-masked dL/dcolour */) {
     // per-view (unit direction, 1/len, masked colour gradient) of this thread's Gaussian.  The view loop of the
     // geometry part is NOT unrolled (one copy of a ~90-register body); its per-view results go through this
     // LDS slice so that the SH part can hold them in statically indexed registers.
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     const bool preact = (flags & E3_FLAG_PREACT) != 0;
     const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
     const float* sh = pl ? shs + i : shs + (size_t)i * M * 3;
-    float* dsh = pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
-    const size_t st = pl ? (size_t)P : (size_t)1;
+    float* dsh = !dL_dsh ? nullptr : (pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3);    // null: SH gradient rebuilt from
+    const size_t st = pl ? (size_t)P : (size_t)1;                                        // gcol (sh_grad_views_kernel)
     uint32_t vis = 0;
     const int nv = mv.vs.n;
 #pragma unroll
@@ -618,7 +618,12 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
         if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
         dL_dopacity[i] = 0.0f;
         dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
-        for (int k = 0; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+        if (dsh) for (int k = 0; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+        if (gcol)
+            for (int v = 0; v < nv; ++v) {
+                float* gp = gcol + ((size_t)v * P + i) * 3;
+                gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+            }
         dL_dscale[3 * (size_t)i] = 0.0f; dL_dscale[3 * (size_t)i + 1] = 0.0f; dL_dscale[3 * (size_t)i + 2] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = 0.0f;
@@ -656,6 +661,10 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
         }
         sV[0][v][tid] = o_dx; sV[1][v][tid] = o_dy; sV[2][v][tid] = o_dz; sV[3][v][tid] = o_il;
         sV[4][v][tid] = o_g0; sV[5][v][tid] = o_g1; sV[6][v][tid] = o_g2;
+        if (gcol) {
+            float* gp = gcol + ((size_t)v * P + i) * 3;
+            gp[0] = o_g0; gp[1] = o_g1; gp[2] = o_g2;
+        }
     }
     if (dL_dmean2D) {   // densification statistics use render #1 only (train.py:145)
         dL_dmean2D[3 * (size_t)i] = m2x; dL_dmean2D[3 * (size_t)i + 1] = m2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
@@ -698,10 +707,10 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
                     ddx[v] = FMA(Yx, sgn, ddx[v]); ddy[v] = FMA(Yy, sgn, ddy[v]); ddz[v] = FMA(Yz, sgn, ddz[v]);
                 }
             }
-            dsh[(size_t)(3 * k) * st] = o0; dsh[(size_t)(3 * k + 1) * st] = o1; dsh[(size_t)(3 * k + 2) * st] = o2;
+            if (dsh) { dsh[(size_t)(3 * k) * st] = o0; dsh[(size_t)(3 * k + 1) * st] = o1; dsh[(size_t)(3 * k + 2) * st] = o2; }
         }
     }
-    for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+    if (dsh) for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
 #pragma unroll
     for (int v = 0; v < E3_MAX_VIEWS; ++v) {
         if (v < nv) {
@@ -713,6 +722,68 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
         }
     }
     dL_dmean3D[3 * (size_t)i] = gmean[0]; dL_dmean3D[3 * (size_t)i + 1] = gmean[1]; dL_dmean3D[3 * (size_t)i + 2] = gmean[2];
+}
+
+// ---- SH gradient from per-view colour gradients -------------------------------------------------------------
+// dL/dsh[k][ch] = sum over views of Y_k(dir_view) * dL/dcolour_view[ch]: a rank-<=3 structure per view.  Under view-
+// parallel data parallelism the ranks therefore do not have to average the 48 SH-gradient floats per Gaussian
+// (81 % of the gradient bytes): they exchange the 3 clamp-masked colour-gradient floats per (Gaussian, view) plus
+// the camera centres -- 9 instead of 48 floats per Gaussian and rank for an event iteration -- and every rank
+// rebuilds the averaged SH gradient itself.  `packed` holds one block per rank:
+// [views_per_rank x P x 3 colour gradients | views_per_rank x 3 camera centres], `rank_stride` floats apart.
+__global__ __launch_bounds__(256) void sh_grad_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
+                                                            const float* __restrict__ means,
+                                                            const float* __restrict__ packed, size_t rank_stride,
+                                                            float scale, float* __restrict__ dL_dsh, int planar) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float acc[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    const int nk = (D + 1) * (D + 1);
+#pragma unroll 1
+    for (int r = 0; r < nranks; ++r) {
+        const float* blk = packed + (size_t)r * rank_stride;
+        const float* cams = blk + (size_t)views_per_rank * P * 3;
+#pragma unroll 1
+        for (int v = 0; v < views_per_rank; ++v) {
+            const float* gp = blk + ((size_t)v * P + i) * 3;
+            const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;          // culled / clamped in this view
+            const float ox = mx - cams[3 * v], oy = my - cams[3 * v + 1], oz = mz - cams[3 * v + 2];
+            const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+            const float x = ox / len, y = oy / len, z = oz / len;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < nk) {
+                    float Y, Yx, Yy, Yz;
+                    sh_basis(k, x, y, z, Y, Yx, Yy, Yz);
+                    acc[k][0] = FMA(Y, g0, acc[k][0]); acc[k][1] = FMA(Y, g1, acc[k][1]); acc[k][2] = FMA(Y, g2, acc[k][2]);
+                }
+            }
+        }
+    }
+    float* dsh = planar ? dL_dsh + i : dL_dsh + (size_t)i * M * 3;
+    const size_t st = planar ? (size_t)P : (size_t)1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < nk) {
+            dsh[(size_t)(3 * k) * st] = acc[k][0] * scale; dsh[(size_t)(3 * k + 1) * st] = acc[k][1] * scale;
+            dsh[(size_t)(3 * k + 2) * st] = acc[k][2] * scale;
+        }
+    }
+    for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+}
+
+int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
+                          size_t rank_stride, float scale, float* dL_dsh, int flags, hipStream_t s) {
+    if (P <= 0) return 0;
+    sh_grad_views_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
+                                                                     rank_stride, scale, dL_dsh,
+                                                                     (flags & E3_FLAG_SH_PLANAR) != 0);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 // ------------------------------------------------------------------------------------ host driver
@@ -733,7 +804,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                      const int* radii, const char* geom_buffer, const char* binning_buffer,
                      const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                     float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s) {
+                     float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s, float* dL_dcolour_views) {
     (void)colors;
     if (P <= 0) return 0;
     const ViewSet vs = make_view_set(views, W, H, scale_modifier);
@@ -778,7 +849,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.gsum = gsum;
         geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
-            dL_dscale, dL_drot);
+            dL_dscale, dL_drot, dL_dcolour_views);
     }
     }
     KERNEL_OK("geom_bwd_kernel");

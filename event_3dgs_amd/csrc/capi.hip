@@ -57,7 +57,7 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 4; }
+int e3dgs_abi_version(void) { return 5; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -297,8 +297,8 @@ int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rend
                                    const float* tan_fovy, const int* radii, const char* geom_buffer,
                                    const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
                                    float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
-                                   float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, int flags,
-                                   void* stream) {
+                                   float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug,
+                                   int flags, void* stream) {
     g_err[0] = 0;
     ViewBatch vb;
     int rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
@@ -306,13 +306,31 @@ int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rend
     if (P > 0 && (!shs || !scales || !rotations)) return e3_fail(hipErrorInvalidValue, "shs + scales + rotations are required");
     if (D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
     // nviews == 1 runs the general single-view kernel, so pass 2 to apply the multi-view argument rules always
+    // dL_dsh may be NULL when the caller takes the per-view colour gradients instead (e3dgs_sh_grad_from_colour)
+    float dummy_sh = 0.0f;
     rc = check_backward_args(2, P, shs, nullptr, opacities, nullptr, grad_acc, dL_dopacity, nullptr, dL_dmean3D,
-                             nullptr, dL_dsh, dL_dscale, dL_drot, flags);
+                             nullptr, (dL_dsh || !dL_dcolour_views) ? dL_dsh : &dummy_sh, dL_dscale, dL_drot, flags);
     if (rc) return rc;
+    if (dL_dcolour_views && nviews < 2)
+        return e3_fail(hipErrorInvalidValue, "dL_dcolour_views needs the multi-view per-Gaussian kernel (nviews >= 2)");
     return e3_backward_impl(vb, P, D, M, num_rendered, background, width, height, means3D, shs, nullptr, opacities,
                             scales, scale_modifier, rotations, nullptr, radii, geom_buffer, binning_buffer, image_buffer,
                             dL_dpix, grad_acc, dL_dmean2D, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_dsh, dL_dscale,
-                            dL_drot, debug, flags, (hipStream_t)stream);
+                            dL_drot, debug, flags, (hipStream_t)stream, dL_dcolour_views);
+}
+
+int e3dgs_sh_grad_from_colour(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
+                              const float* packed, size_t rank_stride, float scale, float* dL_dsh, int flags,
+                              void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || nranks < 1 || views_per_rank < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1))
+        return e3_fail(hipErrorInvalidValue, "bad sizes");
+    if (P > 0 && (!means3D || !packed || !dL_dsh)) return e3_fail(hipErrorInvalidValue, "null pointer");
+    if (rank_stride < (size_t)views_per_rank * ((size_t)P * 3 + 3))
+        return e3_fail(hipErrorInvalidValue, "rank_stride smaller than one rank block");
+    int rc = e3_sh_grad_views_impl(P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, dL_dsh, flags,
+                                   (hipStream_t)stream);
+    return rc ? e3_fail((hipError_t)rc, "sh_grad_views_kernel") : 0;
 }
 
 size_t e3dgs_state_offset_emit_gid(int num_rendered) {

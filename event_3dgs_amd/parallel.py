@@ -56,6 +56,28 @@ def allreduce_mean_async_(chunk, group=None):
     return PendingMean(chunk, work, dist.get_world_size(group) if divide else 0)
 
 
+class PendingGather:
+    def __init__(self, out, work):
+        self.out, self.work = out, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        return self.out
+
+
+def allgather_async_(out, local, group=None):
+    """Starts the all-gather of one contiguous `local` block per rank into the rows of `out` (world, numel)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        out[0].copy_(local)
+        return PendingGather(out, None)
+    try:
+        work = dist.all_gather_into_tensor(out.view(-1), local, group=group, async_op=True)
+    except (RuntimeError, NotImplementedError):           # backends without the flat form (older gloo)
+        work = dist.all_gather(list(out.unbind(0)), local, group=group, async_op=True)
+    return PendingGather(out, work)
+
+
 def rank_camera_indices(rank, world, n_cameras, iteration, seed=0, exclude=(5, 25, 45, 65, 85)):
     """Deterministic per-rank camera draw mirroring train.py:116-131: index in [2, n-4], the held-out
     evaluation views shifted down by one.  Every rank can recompute every other rank's draw."""

@@ -445,7 +445,8 @@ def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flag
 def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
     """e3dgs_rasterize_backward_multi for a forward_multi result.  grad_out_color is (n,3,H,W); `out` maps
     means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are fully overwritten
-    with the gradient summed over the views."""
+    with the gradient summed over the views.  Optional `colour_views` (n,P,3): the per-view clamp-masked colour
+    gradients (then `sh` may be omitted; see sh_grad_from_colour)."""
     L = _lib.lib()
     rs = raw["settings"]
     sl = raw["settings_list"]
@@ -478,8 +479,24 @@ def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
             *arrays, _lib.ptr(raw["radii"]), _lib.ptr(raw["geom"]), _lib.ptr(raw["binning"]), _lib.ptr(raw["image"]),
             _lib.ptr(g), _lib.ptr(grad_acc), _lib.ptr(out.get("means2D")), _lib.ptr(out.get("opacities")),
             _lib.ptr(out.get("means3D")), _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")),
-            _lib.ptr(out.get("rots")), int(bool(rs.debug)), int(flags), _lib.current_stream())
+            _lib.ptr(out.get("rots")), _lib.ptr(out.get("colour_views")), int(bool(rs.debug)), int(flags),
+            _lib.current_stream())
     _lib.check(rc, "e3dgs_rasterize_backward_multi")
+
+
+def sh_grad_from_colour(means3D, packed, nranks, views_per_rank, sh_degree, M, dL_dsh, scale, planar=True):
+    """e3dgs_sh_grad_from_colour: the mean SH gradient over all ranks' views, rebuilt from the all-gathered per-view
+    colour gradients.  `packed` is (nranks, views_per_rank*P*3 + views_per_rank*3) float32: per rank the
+    `colour_views` output of backward_multi followed by its camera centres."""
+    L = _lib.lib()
+    P = means3D.shape[0]
+    if packed.dim() != 2 or packed.shape[0] != nranks or not packed.is_contiguous():
+        raise ValueError("packed must be a contiguous (nranks, block) tensor")
+    with torch.cuda.device(means3D.device):
+        rc = L.e3dgs_sh_grad_from_colour(P, nranks, views_per_rank, int(sh_degree), int(M), _lib.ptr(means3D),
+                                         _lib.ptr(packed), packed.shape[1], float(scale), _lib.ptr(dL_dsh),
+                                         _lib.FLAG_SH_PLANAR if planar else 0, _lib.current_stream())
+    _lib.check(rc, "e3dgs_sh_grad_from_colour")
 
 
 class GaussianRasterizer(nn.Module):

@@ -88,6 +88,15 @@ class EventTrainer:
         if env is not None:
             overlap_features = env != "0"
         self.overlap_features = bool(overlap_features)
+        # Several ranks: the SH gradient (48 of the 59 floats per Gaussian) is not averaged as such.  It is
+        # sum_views Y_k(dir) * dL/dcolour, so the ranks all-gather the 3 colour-gradient floats per (Gaussian, view) and
+        # their camera centres (9 instead of 48 floats per Gaussian and rank) and each rebuilds the mean SH gradient
+        # (e3dgs_sh_grad_from_colour).  E3DGS_FACTORIZE_SH=0 falls back to averaging the SH gradient itself.
+        self.factorize_sh = self.world > 1 and os.environ.get("E3DGS_FACTORIZE_SH", "1") != "0"
+        self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
+        self._gathered = None
+        self._packed_views = 0         # views whose colour gradients the last backward left in _packed (0: none)
+        self._xyz_prev = None          # the means the gradients were computed with (Adam moves them meanwhile)
         self._side = None
         self._feat_event = None
         zeros = lambda t: torch.zeros_like(t)
@@ -227,7 +236,7 @@ class EventTrainer:
         self.iteration += 1
         it = self.iteration
         dist_on = self.world > 1 and sync_grads
-        if self.overlap_features:
+        if self.overlap_features or self.factorize_sh:
             self._update_overlapped(it, dist_on)
         elif dist_on:
             self._allreduce_and_adam(it)                           # 59 floats/Gaussian + c, pipelined with Adam
@@ -242,31 +251,58 @@ class EventTrainer:
             self._feat_event = None
 
     def _update_overlapped(self, it, dist_on):
+        """xyz / opacity / scaling / rotation / c: mean over the ranks + Adam on the main stream.  SH coefficients:
+        exchange (factorised: all-gather of the per-view colour gradients + local rebuild; otherwise chunked mean of
+        the SH gradient) + Adam, on the side stream when overlap_features is set, else on the main stream."""
         main = torch.cuda.current_stream(self.device)
-        if self._side is None:
+        if self.overlap_features and self._side is None:
             self._side = torch.cuda.Stream(self.device)
-        side = self._side
+        side = self._side if self.overlap_features else main
         chunks = self._comm_chunks()
         small = [c for c in chunks if c[0] != "features"]
         feats = [c for c in chunks if c[0] == "features"]
-        grads_ready = main.record_event()
+        fact = self.factorize_sh and self._packed_views > 0
+        if fact:
+            # the rebuild needs the means the gradients were computed with; Adam (main stream) is about to move them
+            if self._xyz_prev is None or self._xyz_prev.shape != self.views["xyz"].shape:
+                self._xyz_prev = torch.empty_like(self.views["xyz"])
+            self._xyz_prev.copy_(self.views["xyz"])
+        grads_ready = main.record_event() if self.overlap_features else None
         mean = (lambda c: parallel.allreduce_mean_async_(self.flat_grad[c[1]:c[1] + c[2]], self.pg)) if dist_on else \
                (lambda c: None)
-        # every rank issues its collectives in the same order: small groups (main stream) first, then the features
+        # every rank issues its collectives in the same order: small groups first, then the SH exchange
         pend_small = [(c, mean(c)) for c in small]
         with torch.cuda.stream(side):
-            side.wait_event(grads_ready)
-            pend_feat = [(c, mean(c)) for c in feats]
+            if grads_ready is not None:
+                side.wait_event(grads_ready)
+            if fact:
+                gather = parallel.allgather_async_(self._gathered, self._packed, self.pg) if dist_on else None
+                pend_feat = None
+            else:
+                pend_feat = [(c, mean(c)) for c in feats]
         for c, p in pend_small:
             if p is not None:
                 p.wait()
             self._adam_chunk(c, it)
         with torch.cuda.stream(side):
-            for c, p in pend_feat:
-                if p is not None:
-                    p.wait()
-                self._adam_chunk(c, it)
-            self._feat_event = side.record_event()
+            if fact:
+                if gather is not None:
+                    packed, nranks = gather.wait(), self.world
+                else:                                   # local step: this rank's views only
+                    packed, nranks = self._packed.view(1, -1), 1
+                rasterizer.sh_grad_from_colour(self._xyz_prev, packed, nranks, self._packed_views,
+                                               self.active_sh_degree, 16, self.grads["features"], 1.0 / nranks,
+                                               planar=True)
+                self._packed_views = 0
+                for c in feats:
+                    self._adam_chunk(c, it)
+            else:
+                for c, p in pend_feat:
+                    if p is not None:
+                        p.wait()
+                    self._adam_chunk(c, it)
+            if self.overlap_features:
+                self._feat_event = side.record_event()
 
     def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):
         """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer."""
@@ -296,6 +332,18 @@ class EventTrainer:
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
+        if self.factorize_sh:
+            # the kernel hands out the per-view colour gradients instead of the SH gradient (rebuilt after the exchange)
+            nv, P = 3, self.N
+            if self._packed is None or self._packed.numel() != nv * P * 3 + nv * 3:
+                self._packed = torch.empty(nv * P * 3 + nv * 3, dtype=torch.float32, device=self.device)
+                self._gathered = torch.empty(self.world, self._packed.numel(), dtype=torch.float32, device=self.device)
+            self._packed_views = nv
+            out["sh"] = None
+            out["colour_views"] = self._packed[:nv * P * 3].view(nv, P, 3)
+            tail = self._packed[nv * P * 3:].view(nv, 3)
+            for k, st in enumerate(settings):
+                tail[k].copy_(st.campos)
         if self.track_stats:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out)
@@ -426,6 +474,7 @@ class EventTrainer:
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.track_stats:
             out["means2D"] = self.viewspace_grad
+        self._packed_views = 0                     # single render: the SH gradient itself is exchanged
         rasterizer.backward_multi(raw, dpix, out)
         self.c_grad.zero_()                        # the contrast threshold only exists in the event loss
         self.last_radii = raw["radii"][0]

@@ -256,8 +256,28 @@ int e3dgs_rasterize_backward_multi(
     const float* dL_dpix,             /* (nviews,3,H,W) */
     float* grad_acc,                  /* (num_rendered + nviews*P,12) scratch (uninitialised is fine) */
     float* dL_dmean2D,                /* (P,3) or NULL: view 0 */
-    float* dL_dopacity, float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    float* dL_dopacity, float* dL_dmean3D,
+    float* dL_dsh,                    /* may be NULL if dL_dcolour_views is given */
+    float* dL_dscale, float* dL_drot,
+    float* dL_dcolour_views,          /* (nviews,P,3) or NULL: per-view dL/dcolour with the SH clamp mask applied
+                                         (zero where the view does not see the Gaussian); needs nviews >= 2 */
     int debug, int flags, void* stream);
+
+/*
+ * SH gradient from per-view colour gradients:  dL/dsh[k][ch] = scale * sum over all views of
+ * Y_k(direction from the view's camera centre to the Gaussian) * dL/dcolour_view[ch].
+ * New capability for view-parallel data parallelism (north_star: train.py's loop sharded by camera with an
+ * all-reduce of the Gaussian gradients): the SH coefficients are 48 of the 59 gradient floats per Gaussian, but
+ * their gradient is determined by 3 floats per (Gaussian, view).  Instead of all-reducing 48 floats per Gaussian the
+ * ranks all-gather their (views_per_rank x P x 3) colour gradients + camera centres and each rank rebuilds the mean
+ * SH gradient here (scale = 1 / nranks): 9 instead of 48 floats per Gaussian and rank for an event iteration.
+ * `packed`: nranks blocks, `rank_stride` floats apart, each [views_per_rank*P*3 colour gradients as written by
+ * e3dgs_rasterize_backward_multi(dL_dcolour_views) | views_per_rank*3 camera centres].  dL_dsh (P,M,3) or, with
+ * E3DGS_FLAG_SH_PLANAR, (M*3,P); written in full (zeros above degree D).
+ */
+int e3dgs_sh_grad_from_colour(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
+                              const float* packed, size_t rank_stride, float scale, float* dL_dsh, int flags,
+                              void* stream);
 
 /*
  * Exact tile culling (default ON; environment E3DGS_TILE_CULL=0 turns it off at load time).

@@ -464,3 +464,54 @@ def test_multi_view_many_tiles_and_huge_splats():
     for n in names:
         assert torch.isfinite(out[n]).all(), n
         assert rel_l2(out[n].cpu(), ref[n].cpu()) < 5e-6, n
+
+
+def test_sh_gradient_rebuilt_from_colour_views():
+    """e3dgs_sh_grad_from_colour: the SH gradient rebuilt from the per-view clamp-masked colour gradients that
+    backward_multi hands out equals the SH gradient backward_multi computes itself -- for one "rank" exactly the same
+    sum, for two rank blocks (views split 2 + 2, scale 1/2) the mean of the two halves."""
+    from event_3dgs_amd import rasterizer
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, _ = _scene(N=3000)
+    W, H, nviews = 150, 110, 4
+    cams = [orbit_camera(k, 16, W, H, device=DEV, daz=0.01 * k) for k in range(nviews)]
+    bg = torch.zeros(3, device=DEV)
+    tr = EventTrainer(params, DEV, active_sh_degree=3)
+    v = tr.views
+    P = tr.N
+    dpix = torch.randn(nviews, 3, H, W, generator=torch.Generator().manual_seed(8)).to(DEV)
+    names = dict(means3D=v["xyz"], sh=v["features"], opacities=v["opacity"], scales=v["scaling"], rots=v["rotation"])
+
+    def run(cam_list, dp):
+        raw = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                       [tr._settings(c, bg) for c in cam_list], flags=tr.FWD_FLAGS)
+        out = {n: torch.empty_like(t) for n, t in names.items()}
+        out["colour_views"] = torch.full((len(cam_list), P, 3), float("nan"), device=DEV)
+        rasterizer.backward_multi(raw, dp, out)
+        return out
+    full = run(cams, dpix)
+    assert torch.isfinite(full["colour_views"]).all()
+    centres = torch.stack([c.camera_center.contiguous() for c in cams])
+    # ---- one block with all four views, scale 1
+    packed = torch.cat((full["colour_views"].reshape(-1), centres.reshape(-1))).view(1, -1).contiguous()
+    got = torch.full_like(v["features"], float("nan"))
+    rasterizer.sh_grad_from_colour(v["xyz"], packed, 1, nviews, 3, 16, got, 1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got.cpu(), full["sh"].cpu()) < 2e-6
+    # ---- two blocks of two views, scale 1/2 == mean of the two halves' SH gradients
+    a, b = run(cams[:2], dpix[:2].contiguous()), run(cams[2:], dpix[2:].contiguous())
+    blocks = torch.stack([torch.cat((o["colour_views"].reshape(-1), centres[i:i + 2].reshape(-1)))
+                          for o, i in ((a, 0), (b, 2))]).contiguous()
+    rasterizer.sh_grad_from_colour(v["xyz"], blocks, 2, 2, 3, 16, got, 0.5)
+    torch.cuda.synchronize()
+    assert rel_l2(got.cpu(), (0.5 * (a["sh"] + b["sh"])).cpu()) < 2e-6
+    # dL_dsh may be omitted when the colour views are taken
+    raw = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                   [tr._settings(c, bg) for c in cams], flags=tr.FWD_FLAGS)
+    out = {n: torch.empty_like(t) for n, t in names.items() if n != "sh"}
+    out["colour_views"] = torch.empty(nviews, P, 3, device=DEV)
+    rasterizer.backward_multi(raw, dpix, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out["colour_views"], full["colour_views"]) and torch.equal(out["means3D"], full["means3D"])
