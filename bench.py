@@ -201,7 +201,7 @@ def main():
     if world == 1:
         grad_ar_bytes = grad_ag_bytes = 0
     elif trainer.factorize_sh:
-        grad_ar_bytes, grad_ag_bytes = 4 * (11 * N + 1), 4 * (27 * N + 9)
+        grad_ar_bytes, grad_ag_bytes = 4 * (11 * N + 1), 4 * (9 * N + 9)      # 3 views x 3 colour channels (+ 3 centres)
     else:
         grad_ar_bytes, grad_ag_bytes = 4 * (FLOATS_PER_GAUSSIAN * N + 1), 0
     if rank == 0:
