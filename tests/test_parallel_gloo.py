@@ -47,6 +47,10 @@ def _worker(rank, world, port, out):
         p.wait()
     parallel.allreduce_mean_(flat)
     assert torch.equal(chunked, flat)
+    # the all-gather used for the per-view colour gradients: row r of `out` = rank r's block
+    local = torch.full((5,), float(rank + 1))
+    gathered = parallel.allgather_async_(torch.zeros(world, 5), local).wait()
+    assert torch.equal(gathered, torch.tensor([[1.0] * 5, [2.0] * 5]))
     idx = [parallel.rank_camera_indices(r, world, 100, iteration=7) for r in range(world)]
     if rank == 0:
         torch.save({"flat": flat, "idx": idx}, out)
