@@ -215,6 +215,7 @@ def main():
                        "tile_instances": I1, "tile_instances_3views": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
                        "parallelism": f"view-dp{world}", "grad_allreduce_bytes": grad_ar_bytes,
                        "sh_colour_allgather_bytes_per_rank": grad_ag_bytes,
+                       "sh_exchange_on_side_stream": bool(trainer.overlap_features),
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
