@@ -98,6 +98,37 @@ class _Scratch:
         return self.tensor.data_ptr()
 
 
+def _mark_visible(pos, view, proj):
+    """uint8 (P,) on the device: 1 where view-space z > 0.2 (e3dgs_mark_visible); inputs already contiguous fp32."""
+    P = pos.shape[0]
+    present = torch.zeros(P, dtype=torch.uint8, device=pos.device)
+    if P:
+        with torch.cuda.device(pos.device):
+            rc = _lib.lib().e3dgs_mark_visible(P, _lib.ptr(pos), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(present),
+                                               _lib.current_stream())
+        _lib.check(rc, "e3dgs_mark_visible")
+    return present
+
+
+def _cpu_snapshot(args):
+    """Host copies of an argument tuple (tensors cloned to the CPU, everything else kept)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _debug_guard(enabled, args, path, what, fn):
+    """debug=True contract of the operator ([UPSTREAM] _RasterizeGaussians, SURVEY 8b "Errors"): keep host copies of
+    the arguments, and if the call raises, write them to `path` with torch.save before re-raising."""
+    if not enabled:
+        return fn()
+    snapshot = _cpu_snapshot(args)
+    try:
+        return fn()
+    except Exception:
+        torch.save(snapshot, path)
+        print("\nAn error occured in %s. Please forward %s for debugging." % (what, path))
+        raise
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -134,6 +165,12 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
             raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales_c is None or rots_c is None) == (cov_c is None)):
             raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    if rs.prefiltered and P:
+        # The caller promises that every Gaussian passes the near-plane test; upstream's kernel traps the device on a
+        # violation ([UPSTREAM] in_frustum).  Here the same test (e3dgs_mark_visible) runs first
+        # and a violation is a Python exception instead of a lost context.
+        if not bool(_mark_visible(means3D_c, view, proj).all()):
+            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
     out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     radii = torch.empty(P, dtype=torch.int32, device=dev)
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
@@ -238,7 +275,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
-        raw = forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+        rs = raster_settings
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        raw = _debug_guard(rs.debug, args, "snapshot_fw.dump", "forward", lambda: forward_raw(
+            means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings))
         ctx.raster_settings = raster_settings
         ctx.num_rendered = raw["num_rendered"]
         ctx.consts = raw["consts"]
@@ -261,7 +303,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         raw = dict(num_rendered=ctx.num_rendered, M=M, settings=rs, flags=0,
                    inputs=(means3D, sh, colors, scales, rots, cov), opacities=None, consts=ctx.consts, radii=radii,
                    geom=geomB, binning=binB, image=imgB)
-        backward_raw(raw, grad_out_color, out)
+        args = (ctx.consts[0], means3D, radii, colors, scales, rots, rs.scale_modifier, cov, ctx.consts[1], ctx.consts[2],
+                rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, ctx.consts[3], geomB, ctx.num_rendered, binB,
+                imgB, rs.debug)
+        _debug_guard(rs.debug, args, "snapshot_bw.dump", "backward", lambda: backward_raw(raw, grad_out_color, out))
         return (out["means3D"], out["means2D"], out["sh"], out["colors"], out["opacities"], out["scales"], out["rots"],
                 out["cov3D"], None)
 
@@ -508,13 +553,9 @@ class GaussianRasterizer(nn.Module):
         with torch.no_grad():
             rs = self.raster_settings
             pos = _prep(positions, "positions")
-            P = 0 if pos is None else pos.shape[0]
-            present = torch.zeros(P, dtype=torch.uint8, device=positions.device)
-            if P:
-                rc = _lib.lib().e3dgs_mark_visible(P, _lib.ptr(pos), _lib.ptr(_prep(rs.viewmatrix, "viewmatrix")),
-                                                   _lib.ptr(_prep(rs.projmatrix, "projmatrix")), _lib.ptr(present),
-                                                   _lib.current_stream())
-                _lib.check(rc, "e3dgs_mark_visible")
+            if pos is None or pos.shape[0] == 0:
+                return torch.zeros(0, dtype=torch.bool, device=positions.device)
+            present = _mark_visible(pos, _prep(rs.viewmatrix, "viewmatrix"), _prep(rs.projmatrix, "projmatrix"))
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,

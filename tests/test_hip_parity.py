@@ -200,6 +200,46 @@ def test_mark_visible_matches_near_plane_test():
     assert (vis != ref).sum() <= 1 and 0 < vis.sum() < 500
 
 
+def test_prefiltered_and_debug_contracts(tmp_path, monkeypatch):
+    """SURVEY 8b "Errors": prefiltered=True with a near-culled Gaussian is an error (upstream traps the device; here a
+    Python exception); debug=True writes snapshot_fw.dump / snapshot_bw.dump with host copies of the arguments when
+    the call raises, and is otherwise invisible in the results."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    monkeypatch.chdir(tmp_path)
+    act, cam = scene(300, 64, 48, seed=9)
+    to = lambda k: act[k].to(dev)
+    call = lambda rs, m: GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros(300, 3, device=dev), opacities=to("opacities"),
+                                                colors_precomp=to("colors"), scales=to("scales"), rotations=to("rotations"))
+    plain = call(_settings(cam, (0, 0, 0), dev), to("means3D"))
+    # all in front of the camera: prefiltered + debug change nothing
+    rs_pf = _settings(cam, (0, 0, 0), dev, debug=True)._replace(prefiltered=True)
+    img, radii = call(rs_pf, to("means3D"))
+    assert torch.equal(img, plain[0]) and torch.equal(radii, plain[1])
+    assert not (tmp_path / "snapshot_fw.dump").exists()
+    # one Gaussian behind the camera: error, and the debug snapshot holds the offending inputs
+    bad = to("means3D").clone()
+    bad[7] = (cam.camera_center * 2.0).to(dev)
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        call(rs_pf, bad)
+    snap = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert torch.equal(snap[1], bad.cpu()) and snap[17] is True
+    # without prefiltered the same input renders (the Gaussian is culled silently)
+    img, radii = call(_settings(cam, (0, 0, 0), dev), bad)
+    assert int(radii[7]) == 0
+    # backward failure under debug -> snapshot_bw.dump
+    m = to("means3D").requires_grad_(True)
+    img, _ = call(_settings(cam, (0, 0, 0), dev, debug=True), m)
+    from event_3dgs_amd import rasterizer
+    def boom(*a, **k):
+        raise RuntimeError("injected")
+    monkeypatch.setattr(rasterizer, "backward_raw", boom)
+    with pytest.raises(RuntimeError, match="injected"):
+        img.sum().backward()
+    snap = torch.load(tmp_path / "snapshot_bw.dump", weights_only=False)
+    assert torch.equal(snap[1], m.detach().cpu()) and snap[12].shape == (3, 48, 64)
+
+
 def test_backward_is_deterministic():
     """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
     act, cam = scene(3000, 192, 128, seed=13)
