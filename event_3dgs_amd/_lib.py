@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 NOTIFY_FN = C.CFUNCTYPE(None, C.c_void_p)
@@ -76,6 +76,9 @@ def lib():
     L.e3dgs_set_tile_cull.restype = None
     L.e3dgs_set_tile_cull.argtypes = [C.c_int]
     L.e3dgs_get_tile_cull.restype = C.c_int
+    L.e3dgs_set_small_scene_paths.restype = None
+    L.e3dgs_set_small_scene_paths.argtypes = [C.c_int]
+    L.e3dgs_get_small_scene_paths.restype = C.c_int
     L.e3dgs_state_offset_emit_gid.restype = C.c_size_t
     L.e3dgs_state_offset_emit_gid.argtypes = [C.c_int]
     L.e3dgs_state_offsets.restype = None
@@ -136,6 +139,6 @@ EXPORTED_SYMBOLS = [
     "e3dgs_rasterize_backward", "e3dgs_rasterize_forward_multi", "e3dgs_rasterize_forward_multi_begin",
     "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi",
     "e3dgs_sh_grad_from_colour",
-    "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
+    "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

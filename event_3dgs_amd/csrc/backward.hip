@@ -352,6 +352,37 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
     }
 }
 
+// Few splats with long runs (point-cloud initialisation: thousands of Gaussians covering hundreds of tiles each): one
+// wave per splat.  Lane l adds records l, l + 64, ... of the run, then a fixed butterfly adds the lanes -- the
+// order depends only on the run length, so the result is as reproducible as the streaming kernel's.
+__global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const uint32_t* __restrict__ order,
+                                                              const uint2* __restrict__ run_sorted,
+                                                              const float* __restrict__ part,
+                                                              float4* __restrict__ gsum) {
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (j >= Q) return;
+    const uint2 rn = run_sorted[j];
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part) + 3 * (size_t)rn.x;
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t r = lane; r < rn.y; r += 64u) {
+        const float4 s0 = p4[3 * (size_t)r], s1 = p4[3 * (size_t)r + 1];
+        const float s2 = p4[3 * (size_t)r + 2].x;
+        a[0] += s0.x; a[1] += s0.y; a[2] += s0.z; a[3] += s0.w;
+        a[4] += s1.x; a[5] += s1.y; a[6] += s1.z; a[7] += s1.w; a[8] += s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] += __shfl_xor(a[k], o, 64);
+    }
+    if (lane == 0) {
+        const size_t q = order[j];
+        gsum[3 * q] = make_float4(a[0], a[1], a[2], a[3]);
+        gsum[3 * q + 1] = make_float4(a[4], a[5], a[6], a[7]);
+        gsum[3 * q + 2] = make_float4(a[8], 0.0f, 0.0f, 0.0f);
+    }
+}
+
 __device__ __forceinline__ void load_sums(const float4* __restrict__ gsum, size_t q, float g12[9]) {
     const float4 s0 = gsum[3 * q], s1 = gsum[3 * q + 1];
     const float s2 = gsum[3 * q + 2].x;
@@ -788,6 +819,7 @@ int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
 
 // ------------------------------------------------------------------------------------ host driver
 int e3_fail(hipError_t e, const char* what);
+extern int g_small_scene_paths;
 #define KERNEL_OK(name)                                       \
     do {                                                      \
         hipError_t _e = hipGetLastError();                    \
@@ -832,9 +864,17 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     ProfScope ps(PS_GEOM_BWD, s);
     // per-splat sums live behind the instance records in the caller's scratch: grad_acc is (num_rendered + Q, 12)
     float4* gsum = reinterpret_cast<float4*>(grad_acc + E3_ACC_STRIDE * (size_t)num_rendered);
-    if (num_rendered > 0)
+    if (num_rendered > 0 && Q <= E3_RUN_REDUCE_WAVE_MAX && g_small_scene_paths)
+        run_reduce_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
+                                                                                    grad_acc, gsum);
+    else if (num_rendered > 0)
         run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
                                                                                    grad_acc, gsum);
+    else        // no instance at all (a radius can still be > 0 when every tile of the splat was culled): zero sums
+    {
+        hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);
+        if (me != hipSuccess) return e3_fail(me, "hipMemsetAsync(gsum)");
+    }
     if (nv == 1 && (flags & E3_FLAG_ACCUMULATE))
         geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,

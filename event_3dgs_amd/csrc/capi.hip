@@ -14,6 +14,7 @@ int e3_fail(hipError_t e, const char* what) {
 
 // exact tile culling (forward.hip: tile_touched); E3DGS_TILE_CULL=0 in the environment disables it
 int g_tile_cull = [] { const char* e = getenv("E3DGS_TILE_CULL"); return (e && e[0] == '0') ? 0 : 1; }();
+int g_small_scene_paths = [] { const char* e = getenv("E3DGS_SMALL_SCENE_PATHS"); return (e && e[0] == '0') ? 0 : 1; }();
 
 // ---- event profiler
 bool g_prof_on = false;
@@ -57,7 +58,7 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 5; }
+int e3dgs_abi_version(void) { return 6; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -394,6 +395,8 @@ extern unsigned long long* g_trace;
 void e3dgs_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }   /* not in the public header */
 void e3dgs_set_tile_cull(int on) { g_tile_cull = on ? 1 : 0; }
 int e3dgs_get_tile_cull(void) { return g_tile_cull; }
+void e3dgs_set_small_scene_paths(int on) { g_small_scene_paths = on ? 1 : 0; }
+int e3dgs_get_small_scene_paths(void) { return g_small_scene_paths; }
 
 void e3dgs_profile_enable(int slot_mask) {
     g_prof_mask = (unsigned)slot_mask;

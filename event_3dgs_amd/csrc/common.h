@@ -146,6 +146,17 @@ static inline size_t sort_scratch_words(size_t n) {
 }
 
 // ---------------------------------------------------------------- scratch layouts
+// Splats per binning wave = 1 << shift: 64 when there are plenty of splats, fewer when the launch would otherwise
+// not fill the chip (bin_kernel).  Both halves of the forward derive the wave count from this.
+static inline int e3_bin_group_shift(size_t Q, int adaptive) {
+    int sh = 6;
+    if (!adaptive) return sh;
+    while (sh > 0 && ((Q + ((size_t)1 << sh) - 1) >> sh) < 8192) --sh;
+    return sh;
+}
+// run_reduce: below this many splats one WAVE sums a splat's records (lanes stride over the run) instead of one thread
+constexpr size_t E3_RUN_REDUCE_WAVE_MAX = 262144;
+
 // geometry state: everything sized by P.  The first three members are what backward reads.
 struct GeomState {
     float4* rec;       // 3 x float4 per Gaussian = one 48-B record the compositing kernels gather:
@@ -181,7 +192,7 @@ struct GeomState {
         g.ord0 = carve<uint32_t>(p, n);
         g.ord1 = carve<uint32_t>(p, n);
         g.tiles = carve<uint32_t>(p, n);
-        g.offsets = carve<uint32_t>(p, n);
+        g.offsets = carve<uint32_t>(p, n + 64);      // [0] = 0, then one entry per binning wave (<= n of them)
         g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_blocks(n) + 64);
         g.total = carve<uint32_t>(p, 64);
         return g;

@@ -264,9 +264,12 @@ __device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float 
 // (tile id, Gaussian id) compacted with a ballot prefix.  Emission order = depth order of the
 // Gaussians, row-major inside a rectangle -- exactly the order the reference's per-Gaussian loop
 // produces, so a stable sort on the tile id alone finishes the job.
+// With few splats (the first iterations after a point-cloud initialisation: thousands of Gaussians, each covering
+// hundreds of tiles) 64 splats per wave would leave most of the chip idle, so a wave then owns only 1 << gshift of
+// them (e3_bin_group_shift: at least 8192 waves whenever there are that many splats).
 constexpr int BIN_WAVES = 4;
 template <bool EMIT>
-__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews, int ntiles,
+__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift, int nviews, int ntiles,
                                                               const uint32_t* __restrict__ order,
                                                               const uint2* __restrict__ rect,
                                                               const float4* __restrict__ rec, int gx, int cull,
@@ -283,11 +286,12 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
     __shared__ float4 sD[BIN_WAVES][WAVE];       // -B/C, -B/A, 1/width, first tile id of the splat's view
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * BIN_WAVES + wave;
-    const int s = gw * WAVE + lane;
-    if (gw * WAVE >= P) return;
+    const int s = (gw << gshift) + lane;
+    if ((gw << gshift) >= P) return;
+    const bool mine = lane < (1 << gshift) && s < P;
     uint32_t n = 0, g = 0;
     float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
-    if (s < P) {
+    if (mine) {
         g = order[s];
         uint2 r = rect[g];
         uint32_t w = (r.y & 0xFFFFu) - (r.x & 0xFFFFu), h = (r.y >> 16) - (r.x >> 16);
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int nviews
             uint32_t t = __shfl_up(inc, o, 64);
             if (lane >= o) inc += t;
         }
-        if (s < P) run_sorted[s] = make_uint2(out_base + inc - c, c);
+        if (mine) run_sorted[s] = make_uint2(out_base + inc - c, c);
     }
 }
 
@@ -654,6 +658,7 @@ __global__ void publish_count_kernel(const uint32_t* __restrict__ src, volatile 
 // ------------------------------------------------------------------------------------ host driver
 extern thread_local char g_err[512];
 extern int g_tile_cull;
+extern int g_small_scene_paths;
 int e3_fail(hipError_t e, const char* what);
 #define HIP_OK(expr)                                          \
     do {                                                      \
@@ -715,11 +720,12 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         }
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
-        const unsigned nwaves = (unsigned)((Q + WAVE - 1) / WAVE);
+        const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
+        const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nv, ntiles, order, geom.rect, geom.rec,
+        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, geom.rect, geom.rec,
                                                                      vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
                                                                      nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
@@ -756,11 +762,12 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         // choose the emit target so that the final sorted values (slot indices) land in bin.perm
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.perm, *v1 = bin.vals_alt;
         if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
-        const unsigned nwaves = (unsigned)((Q + WAVE - 1) / WAVE);
+        const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
+        const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, nviews, tiles_per_view, geom.ord0,
+        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
                                                                     geom.rect, geom.rec, gx, g_tile_cull, geom.offsets,
                                                                     nullptr, k0, bin.emit_gid, geom.run);
         }

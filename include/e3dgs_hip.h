@@ -291,6 +291,18 @@ void e3dgs_set_tile_cull(int on);
 int e3dgs_get_tile_cull(void);
 
 /*
+ * Work decomposition for calls with few splats (a splat = one Gaussian under one view).  Right after a point-cloud
+ * initialisation (scene/gaussian_model.py:124-147: thousands of Gaussians whose scale is the distance to their
+ * neighbours) each splat covers hundreds of tiles; 64 splats per binning wave and one thread per splat in the
+ * gradient-record reduction would then leave most of the chip idle.  ON (default; environment E3DGS_SMALL_SCENE_PATHS=0
+ * turns it off): a binning wave owns fewer splats whenever that is needed for >= 8192 waves, and up to 262144 splats
+ * the records of a splat are summed by a whole wave.  Lists, images and radii do not depend on the switch; gradients
+ * agree to fp32 summation order.  OFF exists so that tests can run the large-scene kernels on small inputs.
+ */
+void e3dgs_set_small_scene_paths(int on);
+int e3dgs_get_small_scene_paths(void);
+
+/*
  * Byte offsets of the members of the three scratch buffers, for tests and tools that want to
  * inspect intermediate state (sorted lists, tile ranges, per-pixel n_contrib).
  *   out[0..4]  geom:    one 48-byte record per Gaussian (stride 12 floats): out[0] -> (x,y,conic.x,conic.y),

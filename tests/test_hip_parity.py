@@ -240,6 +240,42 @@ def test_prefiltered_and_debug_contracts(tmp_path, monkeypatch):
     assert torch.equal(snap[1], m.detach().cpu()) and snap[12].shape == (3, 48, 64)
 
 
+def test_small_scene_work_decomposition_is_invisible():
+    """e3dgs_set_small_scene_paths: fewer splats per binning wave and a wave per splat in the record reduction when
+    there are few splats.  OFF runs the large-scene kernels (64 splats per wave, streaming reduction) on the same small
+    input: identical image / radii / lists, gradients equal up to fp32 summation order -- and both within the oracle
+    tolerance (the default ON case is what every other test in this file exercises)."""
+    from event_3dgs_amd import _lib, rasterizer
+    from oracle import c_oracle
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    assert L.e3dgs_get_small_scene_paths() == 1
+    act, cam = scene(900, 176, 128, seed=21, scale_boost=4.0)       # big splats: long runs, hundreds of tiles each
+    bg = (0.2, 0.1, 0.0)
+
+    def lists():
+        raw = rasterizer.forward_raw(act["means3D"].to(dev), act["shs"].to(dev), None, act["opacities"].to(dev),
+                                     act["scales"].to(dev), act["rotations"].to(dev), None, _settings(cam, bg, dev))
+        st = rasterizer.state_views(raw, 900, 176, 128)
+        return raw["num_rendered"], st["point_list"].clone(), st["ranges"].clone()
+    on = _run_hip(act, cam, bg, True, False)
+    n_on, pl_on, rg_on = lists()
+    L.e3dgs_set_small_scene_paths(0)
+    try:
+        off = _run_hip(act, cam, bg, True, False)
+        n_off, pl_off, rg_off = lists()
+    finally:
+        L.e3dgs_set_small_scene_paths(1)
+    assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1])
+    assert n_on == n_off and torch.equal(pl_on, pl_off) and torch.equal(rg_on, rg_off)
+    f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, False))
+    gb = f.backward(on[3])
+    for k in on[2]:
+        assert rel_l2(on[2][k], off[2][k]) <= 2e-6, k
+        ref = gb[k].reshape(on[2][k].shape)
+        assert rel_l2(off[2][k], ref) <= GRAD_TOL and rel_l2(on[2][k], ref) <= GRAD_TOL, k
+
+
 def test_backward_is_deterministic():
     """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
     act, cam = scene(3000, 192, 128, seed=13)

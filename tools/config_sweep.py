@@ -1,0 +1,40 @@
+"""Step time and per-stage launch durations of the event iteration over the scene kinds / sizes of BASELINE.json
+(init-like = right after create_from_pcd: big isotropic splats; trained-like = the benchmark scene).
+Usage (GPU box, repo root):  python tools/config_sweep.py
+"""
+import os, sys, time, torch, numpy as np, ctypes as C
+sys.path.insert(0, os.getcwd())
+from event_3dgs_amd import synth, _lib
+from event_3dgs_amd.cameras import orbit_camera
+from event_3dgs_amd.train_step import EventTrainer
+from simple_knn._C import distCUDA2
+dev = torch.device("cuda", 0)
+L = _lib.lib()
+def stages(tr, cams, gts, bg, n=20):
+    L.e3dgs_profile_enable(0xFF)
+    for _ in range(n): tr.step(*cams, *gts, bg)
+    torch.cuda.synchronize()
+    out = {}
+    for slot in range(8):
+        ms, k = C.c_double(), C.c_int()
+        L.e3dgs_profile_query(slot, C.byref(ms), C.byref(k))
+        out[L.e3dgs_profile_slot_name(slot).decode()] = round(ms.value / n, 4)
+    L.e3dgs_profile_enable(0)
+    return out
+CONFIGS = ((2_500, 800, 800, "init"), (30_000, 800, 800, "init"), (200_000, 800, 800, "init"), (200_000, 800, 800, "trained"),
+           (1_000_000, 1920, 1080, "init"), (1_000_000, 1920, 1080, "trained"), (2_000_000, 1920, 1080, "trained"))
+for N, W, H, kind in CONFIGS:
+    params = synth.make_scene(N, kind, seed=0, device=dev, dist2_fn=distCUDA2)
+    cams = [orbit_camera(0, 64, W, H, device=dev, daz=d) for d in (0.0, 0.005, 0.015)]
+    bg = torch.zeros(3, device=dev)
+    tr = EventTrainer(params, dev)
+    gts = [(torch.round(tr.render_raw(c, bg)["color"].clamp(0, 1) * 255) / 255).contiguous() for c in cams]
+    for _ in range(3): tr.step(*cams, *gts, bg)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): tr.step(*cams, *gts, bg)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    raw = tr.render_raw(cams[0], bg)
+    print("%s N=%d %dx%d: step %.3f ms, instances/view %d" % (kind, N, W, H, (t1 - t0) * 50, raw["num_rendered"]))
+    print("  ", stages(tr, cams, gts, bg))
+    del tr, params, gts, raw
+    torch.cuda.empty_cache()
