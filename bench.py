@@ -19,6 +19,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of these boxes only supports dmabuf IPC: RCCL between processes needs this (kept if already set)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 CONFIGS = {
     # name: (N gaussians, W, H, deblur)
