@@ -117,24 +117,42 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
             //   Sx = sum h dx, Sy = sum h dy, Sxx = sum h dx^2, Sxy = sum h dx dy, Syy = sum h dy^2,
             //   So = sum G dL/dalpha, Sc* = sum alpha T dL/dC*
             float Sx = 0.0f, Sy = 0.0f, Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, So = 0.0f, Sc0 = 0.0f, Sc1 = 0.0f, Sc2 = 0.0f;
-            bool any = false;
+            unsigned long long any = 0ull;              // lanes that composited this entry at one of their pixels
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dy = a.y - pfy[k];
                 const float power = FMA(FMA(h2, dy, h1), dy, h0);
-                // lane masks straight from the compares (SGPR pairs): 2 v_cmp + s_and + s_cbranch_scc;
-                // power > 0 is rejected by `valid`
-                const unsigned long long live_mask = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
-                                                     __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
-                if (live_mask != 0ull) {
-                    // hardware exp2 (1 ulp) instead of the forward's bit-reproducible polynomial: backward is
-                    // tolerance-checked, and 2 issue slots replace 10 on the most executed path of the kernel
-                    const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-                    const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
-                    const bool valid = (contributor <= last[k]) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
-                    if (valid) {
-                        any = true;
-                        // backward is tolerance-checked (atomics reorder sums anyway): 1-ulp v_rcp_f32
+                // All decisions are lane masks in SGPR pairs (compare intrinsics) combined with scalar ops; the one
+                // divergent branch takes its mask through inverse_ballot (an s_and_saveexec, no VALU).
+                // c.y = pmin: below it alpha < 1/255 whatever the rounding (preprocess_kernel)
+                const unsigned long long live = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
+                                                __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
+                if (live != 0ull) {
+                    // The two skip decisions (alpha < 1/255, power > 0) are discontinuities, and the forward took them
+                    // with ITS arithmetic (its rounding order of `power`, the polynomial exp).  Away from the
+                    // thresholds the outcome cannot depend on that: power >= c.z = pmin + 4e-4 keeps, power <= -1e-5
+                    // is not positive.  Inside the bands the forward's own computation is redone, so that backward
+                    // differentiates exactly the set of (pixel, Gaussian) pairs the forward composited.
+                    // hardware exp2 (1 ulp) instead of the forward's bit-reproducible polynomial: the VALUES of
+                    // backward are tolerance-checked, and 2 issue slots replace 10 on the most executed path.
+                    // Issued before the mask algebra so that its latency overlaps the compares.
+                    float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                    asm volatile("" : "+v"(G));          // keep it here: the compiler would sink it into the branch
+                    const unsigned long long hi = __builtin_amdgcn_fcmpf(power, c.z, 3 /* OGE */);
+                    const unsigned long long nz = __builtin_amdgcn_fcmpf(power, -1e-5f, 2 /* OGT */);
+                    unsigned long long keep = live & hi & ~nz;
+                    const unsigned long long near = live & (~hi | nz);
+                    if (near != 0ull) {                  // rare (<1 % of the live strips)
+                        const float qf = FMA(b.x * dy, dy, (a.z * dx) * dx);
+                        const float pf = FMA(-0.5f, qf, -((a.w * dx) * dy));
+                        const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(pf));
+                        keep |= near & __builtin_amdgcn_fcmpf(pf, 0.0f, 13 /* ULE: !(pf > 0) */) &
+                                __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
+                    }
+                    any |= keep;
+                    if (__builtin_amdgcn_inverse_ballot_w64(keep)) {
+                        const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
+                        // 1-ulp v_rcp_f32
                         const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
                         T[k] = T[k] * inv_one_m;                        // transmittance in front of this entry
                         const float cd = FMA(b.z, dp0[k], FMA(b.w, dp1[k], c.x * dp2[k]));
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                     }
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(any) != 0) {
+            if (any != 0ull) {
                 touched |= 1ull << j;
                 float* r = &sRed[wave][0][0];
                 r[0 * 68 + lane] = Sx;  r[1 * 68 + lane] = Sy;  r[2 * 68 + lane] = Sxx;

@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
     const float o_ = (flags & E3_FLAG_PREACT) ? act_sigmoid(opac[i]) : opac[i];
     // strip-skip bound used by the compositing kernels: alpha >= 1/255 needs power >= pmin
-    // (the same fp32 `power` feeds both tests, so the margin only covers exp/log rounding)
-    const float pmin = -(logf(255.0f * o_) + 1e-3f);
+    // (in the forward the same fp32 `power` feeds both tests, so the margin only has to cover exp/log rounding, ~1e-6;
+    // backward evaluates `power` in another order, which moves it by ~1e-7 of its largest term: 2e-4 covers that too)
+    const float pmin = -(logf(255.0f * o_) + 2e-4f);
     {
         const int v = tid - i * nv;
         const ViewParams& vp = vs.v[v];
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     }
                     rec[3 * q] = make_float4(px, py, conx, cony);
                     rec[3 * q + 1] = make_float4(conz, o_, rgb[0], rgb[1]);
-                    rec[3 * q + 2] = make_float4(rgb[2], pmin, 0.0f, 0.0f);
+                    // .z: above pmin + 4e-4 alpha >= 1/255 holds whatever the rounding of power / exp (backward's band)
+                    rec[3 * q + 2] = make_float4(rgb[2], pmin, pmin + 4e-4f, 0.0f);
                     clamped[q] = cl;
                     radius_out = radius;
                     rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
@@ -579,8 +581,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 const unsigned long long live_mask = __builtin_amdgcn_fcmpf(T[k], 0.0f, 2 /* OGT */) &
                                                      __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
                 if (live_mask != 0ull) {
-                    ++live_strips;
-                    ++live_strips;
+                    live_strips += 2;                    // cost model of tile_work below: an evaluated strip ~ 2 entries
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     const bool valid = (T[k] > 0.0f) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
@@ -757,7 +758,8 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     if (!bp) return e3_fail(hipErrorOutOfMemory, "binning allocation callback returned NULL");
     BinningState bin = BinningState::from(bp, I);
     if (I > 0) {
-        const int tile_bits = ceil_log2((uint32_t)ntiles);
+        // at least one pass even for a single tile: the first pass is what materialises the identity payload
+        const int tile_bits = ntiles > 1 ? ceil_log2((uint32_t)ntiles) : 1;
         const int passes = radix_passes(tile_bits);
         // choose the emit target so that the final sorted values (slot indices) land in bin.perm
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.perm, *v1 = bin.vals_alt;

@@ -381,6 +381,7 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
                              uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
                              bool identity_payload) {
     uint32_t *ki = k0, *ko = k1, *vi = v0, *vo = v1;
+    if (identity_payload && nbits < 1) nbits = 1;        // the payload (0, 1, 2, ...) only exists after a pass
     const int passes = radix_passes(nbits);
     // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
     // for the multi-million instance sort the plain three-kernel pass is faster on this chip

@@ -1,0 +1,130 @@
+"""Randomised differential test: the HIP operator (through diff_gaussian_rasterization) against the C oracle on many
+random small configurations -- frame sizes that are not tile multiples, 1..4000 Gaussians, scale boosts from
+sub-pixel to screen-filling, opacities pushed to 0 / 1, SH degree 0..3 or precomputed colours, scale/rotation or
+precomputed covariance, scale_modifier, camera inside / outside the cloud, every background.
+
+Bars as in tests/test_hip_parity.py: radii and image bit-exact (the forward is designed to be), gradients <= 1e-3
+relative L2 (groups whose reference norm is ~0 are compared absolutely).
+Usage (GPU box, repo root):  python tools/fuzz_parity.py [cases] [first_seed]
+TEST INFRASTRUCTURE: imports oracle/ (allowed for tests and tools run as tests, never for the product).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import oracle_kwargs, rel_l2            # noqa: E402
+from event_3dgs_amd import synth                     # noqa: E402
+from event_3dgs_amd.cameras import orbit_camera      # noqa: E402
+from oracle import c_oracle, torch_oracle            # noqa: E402
+
+GRAD_TOL = 1e-3
+
+
+def make_case(seed):
+    r = np.random.default_rng(seed)
+    N = int(r.choice([1, 2, 7, 64, 300, 1000, 2500, 4000]))
+    W = int(r.integers(8, 200)); H = int(r.integers(8, 160))
+    kind_boost = float(np.exp(r.uniform(math.log(0.05), math.log(30.0))))
+    radius = float(r.choice([0.6, 1.5, 4.0, 9.0]))
+    act = synth.activate(synth.make_scene(N, "trained", seed=seed))
+    act["scales"] = act["scales"] * kind_boost
+    g = torch.Generator().manual_seed(seed + 100)
+    act["colors"] = torch.rand(N, 3, generator=g) * float(r.choice([1.0, 3.0])) - float(r.choice([0.0, 0.5]))
+    mode = r.integers(0, 4)
+    if mode == 1:
+        act["opacities"] = torch.full_like(act["opacities"], 1.0)
+    elif mode == 2:
+        act["opacities"] = act["opacities"] * 0.02            # most alphas under 1/255
+    elif mode == 3:
+        act["opacities"][::3] = 0.0
+    if r.random() < 0.3:
+        act["shs"] = act["shs"] * 4.0                          # colours clamp at 0 often
+    cam = orbit_camera(int(r.integers(0, 8)), 8, W, H, radius=radius)
+    return dict(act=act, cam=cam, N=N, W=W, H=H, use_sh=bool(r.random() < 0.6), use_cov=bool(r.random() < 0.3),
+                sh_degree=int(r.integers(0, 4)), scale_modifier=float(r.choice([1.0, 1.0, 0.5, 2.0])),
+                bg=tuple(float(x) for x in r.choice([0.0, 0.3, 1.0], size=3)), boost=kind_boost, radius=radius)
+
+
+def run_hip(c):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    act, cam = c["act"], c["cam"]
+    leaf = lambda t: t.detach().clone().to(dev).requires_grad_(True)
+    L = dict(means3D=leaf(act["means3D"]), opacities=leaf(act["opacities"]))
+    kw = {}
+    if c["use_sh"]:
+        L["shs"] = leaf(act["shs"]); kw["shs"] = L["shs"]
+    else:
+        L["colors"] = leaf(act["colors"]); kw["colors_precomp"] = L["colors"]
+    if c["use_cov"]:
+        L["cov3D"] = leaf(torch_oracle.build_cov3d(act["scales"], act["rotations"], c["scale_modifier"]))
+        kw["cov3D_precomp"] = L["cov3D"]
+    else:
+        L["scales"] = leaf(act["scales"]); L["rotations"] = leaf(act["rotations"])
+        kw["scales"] = L["scales"]; kw["rotations"] = L["rotations"]
+    means2D = torch.zeros(c["N"], 3, device=dev, requires_grad=True)
+    rs = GaussianRasterizationSettings(
+        cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+        torch.tensor(c["bg"], dtype=torch.float32, device=dev), c["scale_modifier"], cam.world_view_transform.to(dev),
+        cam.full_proj_transform.to(dev), c["sh_degree"], cam.camera_center.to(dev), False, False)
+    img, radii = GaussianRasterizer(rs)(means3D=L["means3D"], means2D=means2D, opacities=L["opacities"], **kw)
+    gw = torch.randn(3, c["H"], c["W"], generator=torch.Generator().manual_seed(c["N"] + c["W"]))
+    (img * gw.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    grads = {k: v.grad.cpu().numpy() for k, v in L.items() if v.grad is not None}
+    grads["means2D"] = means2D.grad.cpu().numpy()
+    return img.detach().cpu().numpy(), radii.cpu().numpy(), grads, gw.numpy()
+
+
+def check(seed):
+    c = make_case(seed)
+    img, radii, grads, gw = run_hip(c)
+    f = c_oracle.Forward(**oracle_kwargs(c["act"], c["cam"], c["bg"], c["use_sh"], c["use_cov"], c["sh_degree"],
+                                         c["scale_modifier"]))
+    problems = []
+    if not np.array_equal(radii, f.radii):
+        problems.append("radii differ at %d Gaussians" % int((radii != f.radii).sum()))
+    if not np.array_equal(img, f.out_color):
+        problems.append("image max abs diff %.3g" % float(np.abs(img - f.out_color).max()))
+    if not np.isfinite(img).all():
+        problems.append("non-finite image")
+    gb = f.backward(gw)
+    for k, g in grads.items():
+        ref = gb.get(k)
+        if ref is None:
+            continue
+        ref = ref.reshape(g.shape)
+        if not np.isfinite(g).all():
+            problems.append("non-finite grad " + k)
+            continue
+        scale = float(np.linalg.norm(ref))
+        err = rel_l2(g, ref) if scale > 1e-12 else float(np.abs(g).max())
+        if err > GRAD_TOL:
+            problems.append("grad %s err %.3g (|ref| %.3g)" % (k, err, scale))
+    desc = "seed %d: N=%d %dx%d boost %.2f r=%.1f sh=%s(%d) cov=%s mod=%.1f visible=%d I=%d" % (
+        seed, c["N"], c["W"], c["H"], c["boost"], c["radius"], c["use_sh"], c["sh_degree"], c["use_cov"],
+        c["scale_modifier"], int((f.radii > 0).sum()), f.num_rendered)
+    f.close()
+    return desc, problems
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    verbose = os.environ.get("FUZZ_VERBOSE") == "1"      # print the seed BEFORE running it (to locate a crash)
+    for seed in range(first, first + cases):
+        if verbose:
+            print("seed", seed, flush=True)
+        desc, problems = check(seed)
+        if problems:
+            bad += 1
+            print("FAIL", desc, "|", "; ".join(problems), flush=True)
+    print("fuzz_parity: %d cases, %d failing" % (cases, bad))
+    sys.exit(1 if bad else 0)
