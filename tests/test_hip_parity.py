@@ -289,6 +289,9 @@ def test_randomised_configurations_against_oracle(first):
     for seed in range(first, first + 16):
         desc, problems = fuzz_parity.check(seed)
         assert not problems, (desc, problems)
+    for seed in range(first, first + 8):        # several cameras in one pass, operator or trainer layout
+        desc, problems = fuzz_parity.check_multi(seed)
+        assert not problems, (desc, problems)
 
 
 @pytest.mark.parametrize("W,H", [(14, 14), (16, 16), (7, 30)])

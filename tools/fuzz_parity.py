@@ -6,6 +6,7 @@ precomputed covariance, scale_modifier, camera inside / outside the cloud, every
 Bars as in tests/test_hip_parity.py: radii and image bit-exact (the forward is designed to be), gradients <= 1e-3
 relative L2 (groups whose reference norm is ~0 are compared absolutely).
 Usage (GPU box, repo root):  python tools/fuzz_parity.py [cases] [first_seed]
+FUZZ_MODE=multi fuzzes the several-cameras-in-one-pass entry points (operator or trainer layout) instead.
 TEST INFRASTRUCTURE: imports oracle/ (allowed for tests and tools run as tests, never for the product).
 """
 import math
@@ -114,6 +115,101 @@ def check(seed):
     return desc, problems
 
 
+def check_multi(seed):
+    """Several cameras of the same Gaussians in one pass (e3dgs_rasterize_forward_multi / _backward_multi), in the
+    operator's layout or in the trainer's (pre-activation parameters, coefficient-major SH, deferred colour) against the
+    oracle run once per camera; gradients summed over the cameras and chain-ruled through the activations."""
+    from event_3dgs_amd import _lib, rasterizer
+    r = np.random.default_rng(10_000 + seed)
+    dev = torch.device("cuda:0")
+    N = int(r.choice([1, 5, 200, 1500, 4000]))
+    W = int(r.integers(8, 180)); H = int(r.integers(8, 140))
+    nviews = int(r.integers(1, 5))
+    boost = float(np.exp(r.uniform(math.log(0.1), math.log(20.0))))
+    radius = float(r.choice([0.8, 2.0, 4.0]))
+    trainer_layout = bool(r.random() < 0.6)
+    defer = trainer_layout and bool(r.random() < 0.5)
+    sh_degree = int(r.integers(0, 4))
+    params = synth.make_scene(N, "trained", seed=seed + 7)
+    params["scaling"] = params["scaling"] + math.log(boost)
+    if r.random() < 0.3:
+        params["opacity"] = params["opacity"] * 0.0 + float(r.choice([-8.0, 8.0]))
+    act = synth.activate(params)
+    cams = [orbit_camera(int(r.integers(0, 8)), 8, W, H, radius=radius, daz=0.03 * k) for k in range(nviews)]
+    bg = tuple(float(x) for x in r.choice([0.0, 0.4, 1.0], size=3))
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    settings = [GaussianRasterizationSettings(
+        H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), torch.tensor(bg, dtype=torch.float32, device=dev), 1.0,
+        c.world_view_transform.to(dev), c.full_proj_transform.to(dev), sh_degree, c.camera_center.to(dev), False, False)
+        for c in cams]
+    if trainer_layout:
+        flags = _lib.FLAG_PREACT | _lib.FLAG_SH_PLANAR | (_lib.FLAG_DEFER_COLOR if defer else 0)
+        sh_in = act["shs"].reshape(N, 48).t().contiguous().to(dev)
+        d = dict(means3D=params["xyz"].to(dev), opacities=params["opacity"].to(dev), scales=params["scaling"].to(dev),
+                 rotations=params["rotation"].to(dev))
+        sh_out = torch.empty(48, N, device=dev)
+    else:
+        flags = 0
+        sh_in = act["shs"].to(dev)
+        d = {k: act[k].to(dev) for k in ("means3D", "opacities", "scales", "rotations")}
+        sh_out = torch.empty(N, 16, 3, device=dev)
+    raw = rasterizer.forward_multi(d["means3D"], sh_in, d["opacities"], d["scales"], d["rotations"], settings, flags=flags)
+    gw = torch.randn(nviews, 3, H, W, generator=torch.Generator().manual_seed(seed))
+    out = dict(means2D=torch.empty(N, 3, device=dev), opacities=torch.empty(N, 1, device=dev),
+               means3D=torch.empty(N, 3, device=dev), sh=sh_out, scales=torch.empty(N, 3, device=dev),
+               rots=torch.empty(N, 4, device=dev))
+    rasterizer.backward_multi(raw, gw.to(dev), out)
+    torch.cuda.synchronize()
+    problems, ref, total = [], None, 0
+    for v, cam in enumerate(cams):
+        f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, False, sh_degree))
+        total += f.num_rendered
+        nr = int((raw["radii"][v].cpu().numpy() != f.radii).sum())
+        if nr > (max(1, N // 500) if trainer_layout else 0):          # ceil(3 sigma) can flip by one on a 1-ulp scale change
+            problems.append("view %d radii differ at %d" % (v, nr))
+        # the trainer layout evaluates exp / sigmoid / normalize in the kernel (1-ulp differences against the CPU's
+        # activations feeding the oracle): 1e-4 there, bit-exact in the operator's layout
+        # (a pixel whose alpha sits on the 1/255 threshold may flip with that ulp: a step of < 1/255, on a few pixels)
+        ad = np.abs(raw["color"][v].cpu().numpy() - f.out_color)
+        diff = float(ad.max())
+        flips = int((ad.max(axis=0) > 1e-4).sum())
+        if (diff > 0.0 and not trainer_layout) or (trainer_layout and (diff > 4e-3 or flips > 3)):
+            problems.append("view %d image max abs diff %.3g (%d pixels > 1e-4)" % (v, diff, flips))
+        gb = f.backward(gw[v].numpy())
+        if v == 0:
+            m2 = out["means2D"].cpu().numpy()
+            sc = float(np.linalg.norm(gb["means2D"]))
+            if (rel_l2(m2, gb["means2D"]) if sc > 1e-12 else float(np.abs(m2).max())) > GRAD_TOL:
+                problems.append("means2D (view 0)")
+        ref = {k: gb[k].astype(np.float64) + (ref[k] if ref else 0.0)
+               for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        f.close()
+    if raw["num_rendered"] > total:
+        problems.append("more instances than the reference binning")
+    if trainer_layout:      # chain rule through exp / normalize / sigmoid (scene/gaussian_model.py:95-118)
+        pre = {k: params[k].double().requires_grad_(True) for k in ("scaling", "rotation", "opacity")}
+        surrogate = (torch.exp(pre["scaling"]) * torch.tensor(ref["scales"])).sum() + \
+            (torch.nn.functional.normalize(pre["rotation"]) * torch.tensor(ref["rotations"])).sum() + \
+            (torch.sigmoid(pre["opacity"]) * torch.tensor(ref["opacities"]).reshape(N, 1)).sum()
+        surrogate.backward()
+        ref["scales"], ref["rotations"] = pre["scaling"].grad.numpy(), pre["rotation"].grad.numpy()
+        ref["opacities"] = pre["opacity"].grad.numpy()
+        ref["shs"] = ref["shs"].reshape(N, 48).T
+    for mine, theirs in dict(means3D="means3D", opacities="opacities", sh="shs", scales="scales", rots="rotations").items():
+        got = out[mine].cpu().numpy()
+        want = ref[theirs].reshape(got.shape)
+        if not np.isfinite(got).all():
+            problems.append("non-finite grad " + mine)
+            continue
+        sc = float(np.linalg.norm(want))
+        err = rel_l2(got, want) if sc > 1e-12 else float(np.abs(got).max())
+        if err > (2 * GRAD_TOL if trainer_layout else GRAD_TOL):     # a flipped threshold pixel also moves gradients
+            problems.append("grad %s err %.3g (|ref| %.3g)" % (mine, err, sc))
+    desc = "multi seed %d: N=%d %dx%d views=%d boost %.2f r=%.1f deg=%d trainer_layout=%s defer=%s I=%d" % (
+        seed, N, W, H, nviews, boost, radius, sh_degree, trainer_layout, defer, raw["num_rendered"])
+    return desc, problems
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -122,7 +218,7 @@ if __name__ == "__main__":
     for seed in range(first, first + cases):
         if verbose:
             print("seed", seed, flush=True)
-        desc, problems = check(seed)
+        desc, problems = (check_multi if os.environ.get("FUZZ_MODE") == "multi" else check)(seed)
         if problems:
             bad += 1
             print("FAIL", desc, "|", "; ".join(problems), flush=True)
