@@ -139,6 +139,19 @@ def test_dist_knn3_is_exact(P):
     assert np.allclose(got, ref, rtol=2e-5, atol=1e-12)
 
 
+def test_small_kernels_on_random_odd_shapes():
+    """tools/fuzz_aux.py: distCUDA2 (1..3000 points, duplicates, collinear, clusters), event loss (frames from 1x1,
+    zero targets, deblur term), SSIM value + gradient (frames smaller than the window), Adam -- against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_aux
+    for seed in range(12):
+        for fn in fuzz_aux.CHECKS:
+            desc, problems = fn(seed)
+            assert not problems, (desc, problems)
+
+
 def test_training_reduces_loss_and_tracks_reference_trainer():
     """A short run: the fused trainer and the autograd trainer stay together and the loss goes down."""
     from event_3dgs_amd.train_step import EventTrainer
