@@ -112,7 +112,30 @@ def main():
     def one_step():
         return trainer.step(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
 
-    for _ in range(args.warmup):
+    # Several ranks: the overlapped / factorised gradient exchange has only ever run over gloo (the development boxes
+    # have one GPU).  If its first step raises on this backend, every rank falls back to the plain schedule (one
+    # blocking mean of the gradient buffer per chunk, no side stream) instead of losing the run; the JSON says which.
+    dp_schedule = "single rank" if world == 1 else "side-stream SH exchange + factorised SH gradient"
+    warm = args.warmup
+    if world > 1:
+        err = None
+        try:
+            if os.environ.get("E3DGS_BENCH_FORCE_FALLBACK") == "1":          # test hook for the branch below
+                raise RuntimeError("forced by E3DGS_BENCH_FORCE_FALLBACK")
+            loss = one_step()
+            torch.cuda.synchronize()
+        except Exception as ex:           # noqa: BLE001 -- any failure of the first exchange
+            err = "%s: %s" % (type(ex).__name__, str(ex)[:200])
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag[0]):
+            os.environ["E3DGS_FACTORIZE_SH"] = "0"
+            os.environ["E3DGS_OVERLAP"] = "0"
+            trainer = EventTrainer(params, dev)
+            dp_schedule = "fallback (plain chunked all-reduce): " + (err or "another rank failed")
+        else:
+            warm = max(0, warm - 1)       # the probe step was the first warm-up step
+    for _ in range(warm):
         loss = one_step()
     torch.cuda.synchronize()
     if world > 1:
@@ -217,7 +240,7 @@ def main():
                        "tile_instances": I1, "tile_instances_3views": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
                        "parallelism": f"view-dp{world}", "grad_allreduce_bytes": grad_ar_bytes,
                        "sh_colour_allgather_bytes_per_rank": grad_ag_bytes,
-                       "sh_exchange_on_side_stream": bool(trainer.overlap_features),
+                       "sh_exchange_on_side_stream": bool(trainer.overlap_features), "dp_schedule": dp_schedule,
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
