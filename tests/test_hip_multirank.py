@@ -137,3 +137,49 @@ def test_two_rank_fit_with_densification_keeps_replicas_identical(tmp_path):
     assert r0["sizes"][0] == 1200 and r0["sizes"][-1] != 1200          # densification really changed the model
     for k in ("xyz", "f_rest", "m"):
         assert torch.equal(r0[k], r1[k]), k
+
+
+def _image_worker(rank, world, port, out, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams, gts, bg = _inputs(rank)
+    tr = EventTrainer(params, DEV)                       # defaults of a multi-rank run: overlap + factorised SH
+    assert tr.overlap_features and tr.factorize_sh
+    for _ in range(STEPS):
+        tr.step_image(cams[0], gts[0], bg, mode=mode)
+    tr.sync_features()
+    torch.cuda.synchronize()
+    torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu()}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["gray", "rgb"])
+def test_two_ranks_image_modes(tmp_path, mode):
+    """The one-render iterations (train.py:213-223, 292-296) under view-parallel DP: one camera per rank, the same
+    exchange as the event iteration with a single view in the colour-gradient all-gather.  Replicas stay bit-identical,
+    track the mean-of-gradients emulation, and differ from a single-rank run."""
+    out = str(tmp_path / "img")
+    mp.spawn(_image_worker, args=(2, _free_port(), out, mode), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in ("flat", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), k
+    from event_3dgs_amd.train_step import EventTrainer
+    pa, ca, ga, bg = _inputs(0)
+    pb, cb, gb, _ = _inputs(1)
+    ta, tb = EventTrainer(pa, DEV, overlap_features=False), EventTrainer(pb, DEV, overlap_features=False)
+    for _ in range(STEPS):
+        ta.compute_gradients_image(ca[0], ga[0], bg, mode=mode)
+        tb.compute_gradients_image(cb[0], gb[0], bg, mode=mode)
+        mean = (ta.flat_grad + tb.flat_grad).div_(2)
+        ta.flat_grad.copy_(mean); tb.flat_grad.copy_(mean)
+        ta.apply_update(); tb.apply_update()
+    torch.cuda.synchronize()
+    m_ref, m_got = ta.exp_avg.cpu(), r0["m"]
+    assert float((m_got - m_ref).norm() / m_ref.norm()) < 1e-4
+    solo = EventTrainer(pa, DEV)
+    for _ in range(STEPS):
+        solo.step_image(ca[0], ga[0], bg, mode=mode)
+    assert not torch.equal(solo.flat.cpu(), r0["flat"])
