@@ -22,7 +22,8 @@ def stages(tr, cams, gts, bg, n=20):
     L.e3dgs_profile_enable(0)
     return out
 CONFIGS = ((2_500, 800, 800, "init"), (30_000, 800, 800, "init"), (200_000, 800, 800, "init"), (200_000, 800, 800, "trained"),
-           (1_000_000, 1920, 1080, "init"), (1_000_000, 1920, 1080, "trained"), (2_000_000, 1920, 1080, "trained"))
+           (1_000_000, 1920, 1080, "init"), (1_000_000, 1920, 1080, "trained"), (2_000_000, 1920, 1080, "trained"),
+           (8_000_000, 1920, 1080, "trained"), (3_000_000, 3840, 2160, "trained"))
 for N, W, H, kind in CONFIGS:
     params = synth.make_scene(N, kind, seed=0, device=dev, dist2_fn=distCUDA2)
     cams = [orbit_camera(0, 64, W, H, device=dev, daz=d) for d in (0.0, 0.005, 0.015)]
