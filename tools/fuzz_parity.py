@@ -130,6 +130,7 @@ def check_multi(seed):
     trainer_layout = bool(r.random() < 0.6)
     defer = trainer_layout and bool(r.random() < 0.5)
     sh_degree = int(r.integers(0, 4))
+    modifier = float(r.choice([1.0, 1.0, 0.6, 1.7]))
     params = synth.make_scene(N, "trained", seed=seed + 7)
     params["scaling"] = params["scaling"] + math.log(boost)
     if r.random() < 0.3:
@@ -139,7 +140,7 @@ def check_multi(seed):
     bg = tuple(float(x) for x in r.choice([0.0, 0.4, 1.0], size=3))
     from diff_gaussian_rasterization import GaussianRasterizationSettings
     settings = [GaussianRasterizationSettings(
-        H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), torch.tensor(bg, dtype=torch.float32, device=dev), 1.0,
+        H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), torch.tensor(bg, dtype=torch.float32, device=dev), modifier,
         c.world_view_transform.to(dev), c.full_proj_transform.to(dev), sh_degree, c.camera_center.to(dev), False, False)
         for c in cams]
     if trainer_layout:
@@ -162,7 +163,7 @@ def check_multi(seed):
     torch.cuda.synchronize()
     problems, ref, total = [], None, 0
     for v, cam in enumerate(cams):
-        f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, False, sh_degree))
+        f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, False, sh_degree, modifier))
         total += f.num_rendered
         nr = int((raw["radii"][v].cpu().numpy() != f.radii).sum())
         if nr > (max(1, N // 500) if trainer_layout else 0):          # ceil(3 sigma) can flip by one on a 1-ulp scale change
@@ -205,8 +206,8 @@ def check_multi(seed):
         err = rel_l2(got, want) if sc > 1e-12 else float(np.abs(got).max())
         if err > (2 * GRAD_TOL if trainer_layout else GRAD_TOL):     # a flipped threshold pixel also moves gradients
             problems.append("grad %s err %.3g (|ref| %.3g)" % (mine, err, sc))
-    desc = "multi seed %d: N=%d %dx%d views=%d boost %.2f r=%.1f deg=%d trainer_layout=%s defer=%s I=%d" % (
-        seed, N, W, H, nviews, boost, radius, sh_degree, trainer_layout, defer, raw["num_rendered"])
+    desc = "multi seed %d: N=%d %dx%d views=%d boost %.2f r=%.1f deg=%d trainer_layout=%s defer=%s mod=%.1f I=%d" % (
+        seed, N, W, H, nviews, boost, radius, sh_degree, trainer_layout, defer, modifier, raw["num_rendered"])
     return desc, problems
 
 
