@@ -121,7 +121,12 @@ def ptr(t):
 
 
 def current_stream():
+    """Raw handle of torch's current HIP stream on the current device.  The private raw getter costs ~0.3 us against
+    ~8 us for torch.cuda.current_stream() (a Stream object per call) -- ten calls per training step."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return raw(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
