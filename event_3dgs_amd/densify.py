@@ -81,10 +81,11 @@ def _append(groups, stats, new):
 
 
 def _prune(groups, stats, mask):
-    """prune_points / _prune_optimizer (:273-305)."""
-    keep = ~mask
+    """prune_points / _prune_optimizer (:273-305).  The reference indexes 21 tensors with the boolean mask (a
+    nonzero + host sync each); here the row list is built once and gathered."""
+    keep = torch.nonzero(~mask).squeeze(1)
     for name in GROUPS:
-        groups[name] = [t[keep] for t in groups[name]]
+        groups[name] = [t.index_select(0, keep) for t in groups[name]]
     stats._mask(keep)
 
 
@@ -95,32 +96,39 @@ def densify_and_prune(groups, stats, max_grad, min_opacity, extent, max_screen_s
     scaling = lambda: torch.exp(groups["scaling"][0])
     # ---- clone
     sel = (torch.norm(grads, dim=-1) >= max_grad) & (scaling().max(dim=1).values <= percent_dense * extent)
-    _append(groups, stats, {k: groups[k][0][sel] for k in GROUPS})
+    rows = torch.nonzero(sel).squeeze(1)
+    _append(groups, stats, {k: groups[k][0].index_select(0, rows) for k in GROUPS})
     # ---- split
     n_init = groups["xyz"][0].shape[0]
     padded = torch.zeros(n_init, device=grads.device)
     padded[:grads.shape[0]] = grads.squeeze()
     sel = (padded >= max_grad) & (scaling().max(dim=1).values > percent_dense * extent)
-    stds = scaling()[sel].repeat(N, 1)
+    rows = torch.nonzero(sel).squeeze(1)
+    pick = lambda k: groups[k][0].index_select(0, rows)
+    sc_sel = torch.exp(pick("scaling"))
+    stds = sc_sel.repeat(N, 1)
     samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=stds.device), std=stds)
-    rots = build_rotation(groups["rotation"][0][sel]).repeat(N, 1, 1)
+    rot_sel = pick("rotation")
+    rots = build_rotation(rot_sel).repeat(N, 1, 1)
     new = {
-        "xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + groups["xyz"][0][sel].repeat(N, 1),
-        "scaling": torch.log(scaling()[sel].repeat(N, 1) / (0.8 * N)),
-        "rotation": groups["rotation"][0][sel].repeat(N, 1),
-        "f_dc": groups["f_dc"][0][sel].repeat(N, 1, 1),
-        "f_rest": groups["f_rest"][0][sel].repeat(N, 1, 1),
-        "opacity": groups["opacity"][0][sel].repeat(N, 1),
+        "xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + pick("xyz").repeat(N, 1),
+        "scaling": torch.log(sc_sel.repeat(N, 1) / (0.8 * N)),
+        "rotation": rot_sel.repeat(N, 1),
+        "f_dc": pick("f_dc").repeat(N, 1, 1),
+        "f_rest": pick("f_rest").repeat(N, 1, 1),
+        "opacity": pick("opacity").repeat(N, 1),
     }
     _append(groups, stats, new)
-    _prune(groups, stats, torch.cat((sel, torch.zeros(N * int(sel.sum()), device=sel.device, dtype=torch.bool))))
-    # ---- prune
+    # ---- prune: the split parents (prune_points at :372) and the opacity / size test (:396-402) in ONE gather.  Both
+    # masks are row-wise functions of the post-split model, so applying them together equals applying them in turn;
+    # max_radii2D was just zeroed by the postfix (:347), as in the reference.
+    drop = torch.cat((sel, torch.zeros(N * rows.shape[0], device=sel.device, dtype=torch.bool)))
     prune_mask = (torch.sigmoid(groups["opacity"][0]) < min_opacity).squeeze(-1)
     if max_screen_size:
         big_vs = stats.max_radii2D > max_screen_size
         big_ws = scaling().max(dim=1).values > 0.1 * extent
         prune_mask = prune_mask | big_vs | big_ws
-    _prune(groups, stats, prune_mask)
+    _prune(groups, stats, drop | prune_mask)
     return groups["xyz"][0].shape[0]
 
 
