@@ -14,6 +14,8 @@ Vectors:
   G5 image_metrics.npz  ssim, ssim_gray, l1_loss_gray, psnr values
   G7 lr.npz          utils/general_utils.py get_expon_lr_func at steps {0,1,100,7000,30000}
   G8 densify.npz     scene/gaussian_model.py densify_and_prune + reset_opacity on a seeded 256-Gaussian model (torch.manual_seed(77))
+  G10 projection.npz  gaussian_renderer/__init__.py project_points / generate_depth_map (the reference's CPU restatement of
+                     the rasteriser's projection + ndc2Pix) on seeded points under two of the G3 cameras
   G9 colmap_tiny/ + colmap_tiny.npz   a tiny COLMAP model (bin + txt, written here) as parsed by scene/colmap_loader.py,
                      plus the derived R/T/FoV (scene/dataset_readers.py:84-97) and getNerfppNorm (:47-68)
 """
@@ -121,6 +123,25 @@ def main():
         cams[f"center{k}"] = cam.camera_center.contiguous().numpy()
         cams[f"P{k}"] = cam.projection_matrix.contiguous().numpy()
     np.savez(os.path.join(OUT, "cameras.npz"), **cams)
+
+    # ---- G10: the reference's own CPU projection (gaussian_renderer/__init__.py:194-273: project_points and the
+    # ndc2Pix line + int() truncation of generate_depth_map) on seeded points in front of two of the cameras above.
+    # It is the only restatement of the rasteriser's projection the reference tree holds (eps 1e-4 instead of 1e-7).
+    import gaussian_renderer as GR
+    pj = {}
+    g10 = torch.Generator().manual_seed(4321)        # own stream: the vectors below keep their seeds
+    for k in (0, 3):
+        w, h = sizes[k]
+        view = torch.tensor(cams[f"view{k}"]); proj = torch.tensor(cams[f"proj{k}"]); centre = torch.tensor(cams[f"center{k}"])
+        fovx, fovy = cams[f"fov{k}"]
+        z = torch.rand(300, 1, generator=g10) * 5.0 + 1.0
+        xy = (torch.rand(300, 2, generator=g10) * 2 - 1) * torch.tensor([np.tan(fovx / 2), np.tan(fovy / 2)]).float() * 1.1 * z
+        pv = torch.cat((xy, z, torch.ones(300, 1)), 1).double()
+        pw = (pv @ torch.linalg.inv(view.double()))[:, :3].float().contiguous()
+        ndc = GR.project_points(pw.numpy(), proj.numpy())
+        depth = GR.generate_depth_map(pw, centre, proj, (w, h), None)
+        pj[f"points{k}"], pj[f"ndc{k}"], pj[f"depth{k}"], pj[f"cam{k}"] = pw.numpy(), ndc, depth.numpy(), np.int64(k)
+    np.savez(os.path.join(OUT, "projection.npz"), **pj)
 
     # ---- G4: event loss pieces + the train.py:165-203 composition ----
     H, W = 32, 48

@@ -151,3 +151,37 @@ def test_g5_ssim_psnr_gray_loss_restatement():
     assert np.abs(a.grad.numpy() - g["d_a_gray_loss"]).max() <= 1e-5 * np.abs(g["d_a_gray_loss"]).max()
     mse = ((a.detach() - b) ** 2).reshape(3, -1).mean(1)
     assert np.allclose((20 * torch.log10(1.0 / torch.sqrt(mse))).numpy(), g["psnr"].reshape(-1), atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [0, 3])
+def test_g10_projection_matches_reference_cpu_restatement(k):
+    """gaussian_renderer/__init__.py:194-273 is the reference tree's own restatement of the rasteriser's projection:
+    project_points (clip = [p,1] . full_proj, NDC = xy / (w + eps)) and the ndc2Pix line + int() truncation of
+    generate_depth_map.  It differs from the rasteriser by its eps (1e-4 instead of 1e-7), i.e. by |ndc| * size / 2 *
+    1e-4 / w <= 0.05 px here.  This pins the oracle's matrix convention, NDC sign / axis order and pixel-centre formula
+    to something the reference itself holds, although the CUDA source is absent."""
+    g, c = G("projection.npz"), G("cameras.npz")
+    pts, ndc_ref, depth_ref = g[f"points{k}"], g[f"ndc{k}"], g[f"depth{k}"]
+    W, H = (int(v) for v in c[f"size{k}"])
+    fovx, fovy = c[f"fov{k}"]
+    N = pts.shape[0]
+    f = c_oracle.Forward(means3D=pts, opacities=np.full(N, 0.5, np.float32), viewmatrix=c[f"view{k}"],
+                         projmatrix=c[f"proj{k}"], campos=c[f"center{k}"], bg=np.zeros(3, np.float32), width=W, height=H,
+                         tanfovx=math.tan(fovx / 2), tanfovy=math.tan(fovy / 2),
+                         colors_precomp=np.ones((N, 3), np.float32), scales=np.full((N, 3), 0.05, np.float32),
+                         rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (N, 1)))
+    px_ref = np.stack([((ndc_ref[:, 0] + 1) * W - 1) * 0.5, ((ndc_ref[:, 1] + 1) * H - 1) * 0.5], 1)
+    vis = f.radii > 0
+    assert vis.sum() >= 0.6 * N                      # points were sampled inside 1.1x the frustum, z in [1, 6]
+    assert np.abs(f.xy[vis] - px_ref[vis]).max() <= 0.05
+    # the reference's depth map from the oracle's pixel centres: same pixels hit, same (nearest) distance
+    depth = np.full((H, W), np.inf, np.float32)
+    dist = np.linalg.norm(pts - c[f"center{k}"][None], axis=1)
+    for i in np.nonzero(vis)[0]:
+        x, y = int(f.xy[i, 0]), int(f.xy[i, 1])
+        if f.xy[i, 0] >= 0 and f.xy[i, 1] >= 0 and x < W and y < H:
+            depth[y, x] = min(depth[y, x], dist[i])
+    both = np.isfinite(depth) & np.isfinite(depth_ref)
+    assert both.sum() >= 0.97 * max(np.isfinite(depth).sum(), 1)        # a 0.05 px shift may cross a pixel border
+    assert np.abs(depth[both] - depth_ref[both]).max() <= 1e-4 * depth_ref[both].max() or \
+        (np.abs(depth[both] - depth_ref[both]) > 1e-4 * depth_ref[both].max()).mean() <= 0.02
