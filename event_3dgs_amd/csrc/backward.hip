@@ -13,7 +13,8 @@
 constexpr int BWD_WAVES = 4;
 
 extern unsigned long long* g_trace;
-void launch_tile_order(int ntiles, const uint2* ranges, const uint32_t* work, uint32_t* order, hipStream_t s);
+int launch_tile_order(int ntiles, int tiles_per_view, int gx, const uint2* ranges, const uint32_t* work, uint32_t* order,
+                      hipStream_t s);
 __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
@@ -35,8 +36,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     __shared__ float4 sPart[BWD_WAVES][16][3];      // [entry & 15][12 floats]: reduced sums parked until the commit
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * BWD_WAVES + wave;
-    if (unit >= ntiles) return;
+    if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
     const int tile = (int)order[unit];          // global tile id: view * tiles_per_view + local tile
+    if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
     const int tx = ltile % gx, ty = ltile / gx;
@@ -871,9 +873,9 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     ImageState img = ImageState::from(ip, (size_t)W * H * nv, ntiles);
     if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
-        launch_tile_order(ntiles, img.ranges, img.work, img.order_bwd, s);
-        render_bwd_kernel<<<dim3((ntiles + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, ntiles, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+        const int nslots = launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, img.work, img.order_bwd, s);
+        render_bwd_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+            g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
             background, img.final_T, img.n_contrib, bin.perm, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");

@@ -225,6 +225,16 @@ struct BinningState {
     }
 };
 
+// XCD-aware launch order of the compositing kernels: the dispatcher is observed to place workgroup b on XCD b % 8
+// (MI355X_MICROARCH.md, workgroup dispatch), each XCD has its own 4 MiB L2, and a splat's record is gathered by every
+// tile it covers.  Tiles are therefore dealt to 8 regions in B x B-tile blocks, and the launch order is built so that the
+// workgroups landing on XCD r hold tiles of region r only (longest lists first inside a region).
+__host__ __device__ static inline int e3_xcd_region(int tile, int tiles_per_view, int gx, int B) {
+    const int view = tile / tiles_per_view, lt = tile - view * tiles_per_view;
+    const int ty = lt / gx, tx = lt - ty * gx;
+    return ((tx / B) + 3 * (ty / B) + 5 * view) & 7;
+}
+
 struct ImageState {
     uint2* ranges;       // per tile [start, end) into BinningState::perm
     float* final_T;      // per pixel
@@ -242,9 +252,9 @@ struct ImageState {
         s.ranges = carve<uint2>(p, ntiles ? ntiles : 1);
         s.final_T = carve<float>(p, npix ? npix : 1);
         s.n_contrib = carve<uint32_t>(p, npix ? npix : 1);
-        s.order = carve<uint32_t>(p, ntiles ? ntiles : 1);
+        s.order = carve<uint32_t>(p, 2 * ntiles + 64);        // XCD-partitioned orders leave holes (launch_tile_order)
         s.work = carve<uint32_t>(p, ntiles ? ntiles : 1);
-        s.order_bwd = carve<uint32_t>(p, ntiles ? ntiles : 1);
+        s.order_bwd = carve<uint32_t>(p, 2 * ntiles + 64);
         return s;
     }
 };

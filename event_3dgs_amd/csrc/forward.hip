@@ -493,11 +493,95 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const 
     }
 }
 
-void launch_tile_order(int ntiles, const uint2* ranges, const uint32_t* work, uint32_t* order, hipStream_t s) {
+// XCD-partitioned variant: bucket = region * 128 + (127 - work / width); slot of the k-th heaviest tile of region r is
+// (k / 4) * 32 + r * 4 + (k % 4), i.e. the 4-tile workgroup w = slot / 4 belongs to region w % 8.  Unused slots hold ~0u.
+__global__ __launch_bounds__(1024) void tile_order_xcd_kernel(int ntiles, int nslots, int tiles_per_view, int gx, int B,
+                                                              const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ work,
+                                                              uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t start[8];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t smax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t key[ORDER_ITEMS];
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < ORDER_ITEMS; ++i) {
+        const int t = tid + i * 1024;
+        uint32_t k = 0;
+        if (t < ntiles) {
+            if (work) k = work[t];
+            else { const uint2 r = ranges[t]; k = r.y - r.x; }
+        }
+        key[i] = k;
+        m = max(m, k);
+    }
+    m = wave_max_u32(m);
+    if (lane == 0) wsum[wave] = m;
+    hist[tid] = 0;
+    for (int j = tid; j < nslots; j += 1024) order[j] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (tid == 0) { uint32_t x = 0; for (int w = 0; w < 16; ++w) x = max(x, wsum[w]); smax = x; }
+    __syncthreads();
+    const uint32_t width = smax / 128u + 1u;
+    auto bucket = [&](int t, uint32_t k) {
+        return (uint32_t)e3_xcd_region(t, tiles_per_view, gx, B) * 128u + (127u - min(127u, k / width));
+    };
+#pragma unroll
+    for (int i = 0; i < ORDER_ITEMS; ++i)
+        if (tid + i * 1024 < ntiles) atomicAdd(&hist[bucket(tid + i * 1024, key[i])], 1u);
+    __syncthreads();
+    uint32_t v = hist[tid], inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    hist[tid] = woff + inc - v;
+    if ((tid & 127) == 0) start[tid >> 7] = woff + inc - v;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ORDER_ITEMS; ++i) {
+        const int t = tid + i * 1024;
+        if (t < ntiles) {
+            const uint32_t b = bucket(t, key[i]);
+            const uint32_t k = atomicAdd(&hist[b], 1u) - start[b >> 7];
+            order[(k >> 2) * 32u + (b >> 7) * 4u + (k & 3u)] = (uint32_t)t;
+        }
+    }
+}
+
+static int xcd_block() {
+    static const int v = [] { const char* e = getenv("E3DGS_XCD_BLOCK"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+// Returns the number of launch slots (== ntiles unless the XCD-partitioned order is on).
+int launch_tile_order(int ntiles, int tiles_per_view, int gx, const uint2* ranges, const uint32_t* work, uint32_t* order,
+                      hipStream_t s) {
+    const int B = xcd_block();
+    if (B > 0 && ntiles <= ORDER_ITEMS * 1024 && ntiles >= 64) {
+        static thread_local int c_key[4] = {0, 0, 0, 0}, c_slots = 0;
+        if (c_key[0] != ntiles || c_key[1] != tiles_per_view || c_key[2] != gx || c_key[3] != B) {
+            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 0;
+            for (int t = 0; t < ntiles; ++t) ++cnt[e3_xcd_region(t, tiles_per_view, gx, B)];
+            for (int r = 0; r < 8; ++r) mx = cnt[r] > mx ? cnt[r] : mx;
+            c_key[0] = ntiles; c_key[1] = tiles_per_view; c_key[2] = gx; c_key[3] = B;
+            c_slots = ((mx + 3) / 4) * 32;
+        }
+        if (c_slots <= 2 * ntiles + 64) {
+            tile_order_xcd_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, c_slots, tiles_per_view, gx, B, ranges, work, order);
+            return c_slots;
+        }
+    }
     if (ntiles <= ORDER_ITEMS * 1024)
         tile_order_reg_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
     else
         tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
+    return ntiles;
 }
 
 unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
@@ -513,8 +597,9 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
     __shared__ float4 sC[RENDER_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * RENDER_WAVES + wave;
-    if (unit >= ntiles) return;
+    if (unit >= ntiles) return;                 // ntiles = launch slots (holes of an XCD-partitioned order hold ~0u)
     const int tile = (int)order[unit];          // global tile id: view * tiles_per_view + local tile
+    if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     int processed = 0;
     const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
@@ -787,9 +872,10 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         }
         KERNEL_OK("tile_ranges_kernel");
     }
+    int nslots = ntiles;
     {
     ProfScope ps(PS_RANGES, s);
-    launch_tile_order(ntiles, img.ranges, nullptr, img.order, s);
+    nslots = launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, nullptr, img.order, s);
     }
     KERNEL_OK("tile_order_kernel");
     if (dc && P > 0) {
@@ -804,8 +890,8 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         KERNEL_OK("colour_kernel");
     }
     ProfScope ps_render(PS_RENDER_FWD, s);
-    render_fwd_kernel<<<dim3((ntiles + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        g_trace, ntiles, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
+    render_fwd_kernel<<<dim3((nslots + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
+        g_trace, nslots, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
         out_color, img.final_T, img.n_contrib, img.work);
     KERNEL_OK("render_fwd_kernel");
     return 0;

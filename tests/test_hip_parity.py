@@ -309,6 +309,23 @@ def test_frames_of_one_or_two_tiles(W, H):
         assert rel_l2(grads[k], gb[k].reshape(grads[k].shape)) <= GRAD_TOL, k
 
 
+def test_xcd_partitioned_launch_order_is_invisible():
+    """E3DGS_XCD_BLOCK=n (read once per process): the compositing kernels' launch order deals tiles to the 8 XCDs in
+    n x n-tile blocks.  Only scheduling changes: a fresh process with the switch on must still match the oracle bit
+    for bit (single view, several views, trainer layout)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import fuzz_parity as f\n"
+            "bad = [f.check(s) for s in (3, 4, 5, 17)] + [f.check_multi(s) for s in (1, 2, 3)]\n"
+            "bad = [b for b in bad if b[1]]\n"
+            "print(bad); sys.exit(1 if bad else 0)") % (os.path.join(root, "tools"), os.path.join(root, "tests"))
+    env = dict(os.environ, E3DGS_XCD_BLOCK="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_backward_is_deterministic():
     """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
     act, cam = scene(3000, 192, 128, seed=13)
