@@ -185,3 +185,37 @@ def test_g10_projection_matches_reference_cpu_restatement(k):
     assert both.sum() >= 0.97 * max(np.isfinite(depth).sum(), 1)        # a 0.05 px shift may cross a pixel border
     assert np.abs(depth[both] - depth_ref[both]).max() <= 1e-4 * depth_ref[both].max() or \
         (np.abs(depth[both] - depth_ref[both]) > 1e-4 * depth_ref[both].max()).mean() <= 0.02
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_g1_product_eval_sh_in_render_mirror(deg):
+    """event_3dgs_amd.renderer.eval_sh (the torch SH branch render() is forced into at
+    gaussian_renderer/__init__.py:71-81) against the reference's values and autograd gradients."""
+    from event_3dgs_amd import renderer
+    g = G("sh.npz")
+    feats = torch.tensor(g["features"], requires_grad=True)
+    xyz = torch.tensor(g["xyz"], requires_grad=True)
+    campos = torch.tensor(g["campos"])
+    shs_view = feats.transpose(1, 2).reshape(-1, 3, 16)
+    d = xyz - campos.repeat(feats.shape[0], 1)
+    d = d / d.norm(dim=1, keepdim=True)
+    col = torch.clamp_min(renderer.eval_sh(deg, shs_view, d) + 0.5, 0.0)
+    assert np.abs(col.detach().numpy() - g[f"colors_deg{deg}"]).max() <= 1e-6
+    (col * torch.tensor(g["grad_colors"])).sum().backward()
+    assert np.abs(feats.grad.numpy() - g[f"dfeatures_deg{deg}"]).max() <= 1e-6
+    if deg > 0:
+        assert np.abs(xyz.grad.numpy() - g[f"dxyz_deg{deg}"]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["cov3d.npz", "cov3d_mod07.npz"])
+def test_g2_product_build_covariance(name):
+    """renderer.build_covariance (pipe.compute_cov3D_python branch of render()) == scene/gaussian_model.py:27-31."""
+    from event_3dgs_amd import renderer
+    g = G(name)
+    s = torch.tensor(g["scales"], requires_grad=True)
+    q = torch.tensor(g["rotations"], requires_grad=True)
+    cov = renderer.build_covariance(s, q, float(g["mod"]))
+    assert np.abs(cov.detach().numpy() - g["cov"]).max() <= 1e-6 * max(1.0, np.abs(g["cov"]).max())
+    (cov * torch.tensor(g["grad_cov"])).sum().backward()
+    assert np.abs(s.grad.numpy() - g["dscales"]).max() <= 1e-5 * np.abs(g["dscales"]).max()
+    assert np.abs(q.grad.numpy() - g["drotations"]).max() <= 1e-5 * np.abs(g["drotations"]).max()

@@ -528,3 +528,49 @@ def test_sh_gradient_rebuilt_from_colour_views():
     rasterizer.backward_multi(raw, dpix, out)
     torch.cuda.synchronize()
     assert torch.equal(out["colour_views"], full["colour_views"]) and torch.equal(out["means3D"], full["means3D"])
+
+
+def test_render_mirror_matches_fused_path_and_oracle():
+    """event_3dgs_amd.renderer.render / render_depth (gaussian_renderer/__init__.py:20-189): same dict as the
+    reference's wrapper; the torch-SH branch it is forced into, the in-rasteriser SH branch and the fused trainer render
+    agree; the precomputed-covariance branch agrees; gradients reach viewspace_points and the parameters."""
+    from event_3dgs_amd import renderer, synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    from helpers import oracle_kwargs
+    from oracle import c_oracle
+    N, W, H = 2500, 176, 120
+    params = synth.make_scene(N, "trained", seed=12, device=DEV)
+    cam = orbit_camera(2, 16, W, H, device=DEV)
+    bg = torch.tensor([0.2, 0.3, 0.1], device=DEV)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    pc = renderer.GaussianView(leaves, active_sh_degree=2)
+    pipe = renderer.PipelineParams()
+    out = renderer.render(cam, pc, pipe, bg)
+    assert pipe.convert_SHs_python is True                          # the reference forces it (:71)
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
+    assert out["render"].shape == (3, H, W) and out["radii"].dtype == torch.int32
+    assert torch.equal(out["visibility_filter"], out["radii"] > 0) and int(out["visibility_filter"].sum()) > N // 3
+    fused = EventTrainer(params, DEV, active_sh_degree=2).render_raw(cam, bg)
+    in_op = renderer.render(cam, pc, renderer.PipelineParams(), bg, force_python_sh=False)
+    for other in (fused["color"], in_op["render"].detach()):
+        d = (out["render"].detach() - other).abs()
+        assert float(d.mean()) <= 1e-6 and float((d > 1e-4).float().mean()) <= 1e-4      # a few threshold pixels at most
+    cov = renderer.render(cam, pc, renderer.PipelineParams(compute_cov3D_python=True), bg)
+    d = (out["render"].detach() - cov["render"].detach()).abs()
+    assert float(d.mean()) <= 1e-6 and int((out["radii"] != cov["radii"]).sum()) <= 2
+    # gradients: screen-space means (what add_densification_stats reads, train.py:317-320) and every parameter group
+    gw = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).to(DEV)
+    (out["render"] * gw).sum().backward()
+    vg = out["viewspace_points"].grad
+    assert vg is not None and float(vg[:, :2].abs().sum()) > 0 and float(vg[:, 2].abs().max()) == 0.0
+    for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
+        assert leaves[k].grad is not None and torch.isfinite(leaves[k].grad).all() and float(leaves[k].grad.abs().sum()) > 0
+    # depth render == the oracle composited with colour = distance + 0.5
+    dep = renderer.render_depth(cam, renderer.GaussianView(params), renderer.PipelineParams(), bg)
+    act = {k: v.cpu() for k, v in synth.activate(params).items()}
+    act["colors"] = ((act["means3D"] - cam.camera_center.cpu()[None]).norm(dim=1, keepdim=True) + 0.5).repeat(1, 3)
+    cam_cpu = orbit_camera(2, 16, W, H)
+    f = c_oracle.Forward(**oracle_kwargs(act, cam_cpu, tuple(bg.tolist()), False, False))
+    d = np.abs(dep["render"].detach().cpu().numpy() - f.out_color)
+    assert float(d.mean()) <= 1e-5 and float((d > 1e-3).mean()) <= 1e-4
