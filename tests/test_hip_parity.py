@@ -374,6 +374,55 @@ def test_known_answer_scenarios_on_the_gpu(no_tile_cull):
         assert np.array_equal(st["point_list"].cpu().numpy().astype(np.uint32), f.point_list)
 
 
+def test_argument_errors_of_the_operator_and_the_c_abi():
+    """SURVEY 8b "Errors": the operator raises as the upstream one does (exactly one of SHs / colours and of
+    scale+rotation / covariance; means3D must be (P,3); fp32 only), and the C ABI refuses bad arguments with a
+    non-zero code and a message instead of launching."""
+    import ctypes as C
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from event_3dgs_amd import _lib
+    dev = torch.device("cuda:0")
+    act, cam = scene(50, 48, 32, seed=1)
+    rs = _settings(cam, (0, 0, 0), dev)
+    d = {k: act[k].to(dev) for k in ("means3D", "opacities", "shs", "colors", "scales", "rotations")}
+    z = torch.zeros(50, 3, device=dev)
+    R = GaussianRasterizer(rs)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        R(means3D=d["means3D"], means2D=z, opacities=d["opacities"], shs=d["shs"], colors_precomp=d["colors"],
+          scales=d["scales"], rotations=d["rotations"])
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        R(means3D=d["means3D"], means2D=z, opacities=d["opacities"], scales=d["scales"], rotations=d["rotations"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        R(means3D=d["means3D"], means2D=z, opacities=d["opacities"], colors_precomp=d["colors"], scales=d["scales"])
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        R(means3D=d["means3D"][:, :2].contiguous(), means2D=z, opacities=d["opacities"], colors_precomp=d["colors"],
+          scales=d["scales"], rotations=d["rotations"])
+    with pytest.raises(RuntimeError, match="float32"):
+        R(means3D=d["means3D"].double(), means2D=z, opacities=d["opacities"], colors_precomp=d["colors"],
+          scales=d["scales"], rotations=d["rotations"])
+    # C ABI: both colour inputs NULL / SH degree 4 / zero-sized frame -> error code + message, nothing launched
+    L = _lib.lib()
+    n = C.c_int(0)
+    from event_3dgs_amd.rasterizer import _Scratch
+    g, b, i = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    img = torch.empty(3, 32, 48, device=dev); radii = torch.empty(50, dtype=torch.int32, device=dev)
+    bgt = torch.zeros(3, device=dev)
+    view, proj, campos = (cam.world_view_transform.contiguous().to(dev), cam.full_proj_transform.contiguous().to(dev),
+                          cam.camera_center.contiguous().to(dev))
+
+    def call(P=50, D=3, M=16, W=48, H=32, shs=d["shs"], colors=None):
+        return L.e3dgs_rasterize_forward(
+            g.cb, None, b.cb, None, i.cb, None, P, D, M, _lib.ptr(bgt), W, H, _lib.ptr(d["means3D"]), _lib.ptr(shs),
+            _lib.ptr(colors), _lib.ptr(d["opacities"]), _lib.ptr(d["scales"]), 1.0, _lib.ptr(d["rotations"]), None,
+            _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), 0.5, 0.5, 0, _lib.ptr(img), _lib.ptr(radii), 0, 0,
+            C.byref(n), _lib.current_stream())
+    assert call() == 0
+    for kw, msg in ((dict(shs=None), "exactly one of shs"), (dict(D=4), "SH degree"), (dict(W=0), "bad sizes"),
+                    (dict(colors=d["colors"]), "exactly one of shs")):
+        assert call(**kw) != 0
+        assert msg in L.e3dgs_last_error().decode()
+
+
 def test_backward_is_deterministic():
     """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
     act, cam = scene(3000, 192, 128, seed=13)
