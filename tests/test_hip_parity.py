@@ -423,6 +423,37 @@ def test_argument_errors_of_the_operator_and_the_c_abi():
         assert msg in L.e3dgs_last_error().decode()
 
 
+def test_operator_on_a_side_stream_and_interleaved_forwards():
+    """SURVEY 8b "Threading / streams": the op works on torch's CURRENT stream, and three forwards followed by three
+    backwards (what train.py does in one event iteration) keep independent state."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    act, _ = scene(1500, 128, 96, seed=4)
+    from event_3dgs_amd.cameras import orbit_camera
+    cams = [orbit_camera(k, 8, 128, 96, radius=4.0) for k in range(3)]
+    base = {k: act[k].to(dev) for k in ("means3D", "opacities", "colors", "scales", "rotations")}
+
+    def run(stream):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        with torch.cuda.stream(stream):
+            imgs = [GaussianRasterizer(_settings(c, (0.1, 0.1, 0.1), dev))(
+                means3D=leaves["means3D"], means2D=torch.zeros(1500, 3, device=dev), opacities=leaves["opacities"],
+                colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])[0] for c in cams]
+            (imgs[0].sum() * 1.0 + imgs[1].sum() * 2.0 - imgs[2].sum() * 0.5).backward()     # 3 backwards, reverse order
+        stream.synchronize()
+        return [i.detach().clone() for i in imgs], {k: v.grad.clone() for k, v in leaves.items()}
+    torch.cuda.synchronize()
+    imgs_a, g_a = run(torch.cuda.current_stream())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    imgs_b, g_b = run(side)
+    for a, b in zip(imgs_a, imgs_b):
+        assert torch.equal(a, b)
+    assert not torch.equal(imgs_a[0], imgs_a[1])
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), k
+
+
 def test_backward_is_deterministic():
     """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
     act, cam = scene(3000, 192, 128, seed=13)
