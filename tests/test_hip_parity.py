@@ -454,6 +454,47 @@ def test_operator_on_a_side_stream_and_interleaved_forwards():
         assert torch.equal(g_a[k], g_b[k]), k
 
 
+@pytest.mark.parametrize("use_sh,use_cov", [(True, False), (False, True)])
+def test_extension_level_functions(use_sh, use_cov):
+    """diff_gaussian_rasterization._C: upstream's three extension functions -- positional signatures,
+    empty tensor = "not provided", return tuples -- give what the operator gives."""
+    from diff_gaussian_rasterization import _C
+    from oracle import torch_oracle
+    dev = torch.device("cuda:0")
+    act, cam = scene(1200, 144, 96, seed=8)
+    bg = (0.0, 0.2, 0.4)
+    img, radii, grads, gw = _run_hip(act, cam, bg, use_sh, use_cov)
+    E = torch.empty(0, device=dev)
+    t = lambda a: a.to(dev)
+    sh = t(act["shs"]) if use_sh else E
+    colors = E if use_sh else t(act["colors"])
+    cov = t(torch_oracle.build_cov3d(act["scales"], act["rotations"], 1.0)) if use_cov else E
+    scales, rots = (E, E) if use_cov else (t(act["scales"]), t(act["rotations"]))
+    rs = _settings(cam, bg, dev)
+    n, color, rad, geomB, binB, imgB = _C.rasterize_gaussians(
+        rs.bg, t(act["means3D"]), colors, t(act["opacities"]), scales, rots, 1.0, cov, rs.viewmatrix, rs.projmatrix,
+        rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, 3, rs.campos, False, False)
+    assert n > 0 and np.array_equal(color.cpu().numpy(), img) and np.array_equal(rad.cpu().numpy(), radii)
+    assert geomB.dtype == binB.dtype == imgB.dtype == torch.uint8
+    g = _C.rasterize_gaussians_backward(
+        rs.bg, t(act["means3D"]), rad, colors, scales, rots, 1.0, cov, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+        rs.tanfovy, torch.from_numpy(gw).to(dev), sh, 3, rs.campos, geomB, n, binB, imgB, False)
+    d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot = g
+    assert d_m2.shape == (1200, 3) and d_col.shape == (1200, 3) and d_op.shape == (1200, 1) and d_cov.shape == (1200, 6)
+    assert np.array_equal(d_m3.cpu().numpy(), grads["means3D"]) and np.array_equal(d_m2.cpu().numpy(), grads["means2D"])
+    assert np.array_equal(d_op.cpu().numpy().reshape(-1), grads["opacities"].reshape(-1))
+    if use_sh:
+        assert np.array_equal(d_sh.cpu().numpy(), grads["shs"]) and float(d_col.abs().max()) == 0.0
+    else:
+        assert np.array_equal(d_col.cpu().numpy(), grads["colors"])
+    if use_cov:
+        assert np.array_equal(d_cov.cpu().numpy(), grads["cov3D"]) and float(d_sc.abs().max()) == 0.0
+    else:
+        assert np.array_equal(d_sc.cpu().numpy(), grads["scales"]) and np.array_equal(d_rot.cpu().numpy(), grads["rotations"])
+    vis = _C.mark_visible(t(act["means3D"]), rs.viewmatrix, rs.projmatrix)
+    assert vis.dtype == torch.bool and vis.shape == (1200,) and bool((vis | (rad <= 0)).all())
+
+
 def test_backward_is_deterministic():
     """No float atomics in the gradient path: per-instance records + fixed-order per-Gaussian sums."""
     act, cam = scene(3000, 192, 128, seed=13)
