@@ -217,6 +217,42 @@ def main():
                             "region). Compositing is VALU-bound, not HBM-bound (SURVEY 8d, DESIGN.md): alpha evaluations/s = "
                             + f"{256.0 * I / (s['avg_ms'] / 1e3) / 1e9:.1f} G/s"}
 
+    # ---- the contrast-only sub-step north_star words the metric by: renders #2 and #3 forward,
+    # differentialable_event_simu + L1 on the pair, backward through both renders; no intensity render, no optimizer.
+    # Measured after the timed region (it does not enter `value`).
+    contrast = None
+    if world == 1:
+        from event_3dgs_amd import losses, rasterizer
+        v = trainer.views
+        two = [trainer._settings(c, bg) for c in (cam_now, cam_next)]
+        g2 = {k: torch.empty_like(t) for k, t in trainer.grads.items()}
+        out2 = dict(means3D=g2["xyz"], sh=g2["features"], opacities=g2["opacity"], scales=g2["scaling"], rots=g2["rotation"])
+        lbuf = None
+
+        def contrast_step():
+            nonlocal lbuf
+            raw2 = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], two,
+                                            flags=trainer.FWD_FLAGS, pool=trainer._pool)
+            im = raw2["color"]
+            if lbuf is None:
+                lbuf = (torch.empty(8, device=dev), torch.empty_like(im[0]), torch.empty_like(im), torch.empty(
+                    L.e3dgs_event_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev))
+            # the intensity slot gets its own target: its L1 is 0 and only the contrast term drives the two renders
+            losses.event_loss_raw(gts[0], im[0], im[1], trainer.c, gts[0], gts[1], gts[2],
+                                  out=(lbuf[0], lbuf[1], lbuf[2][0], lbuf[2][1], lbuf[3]))
+            rasterizer.backward_multi(raw2, lbuf[2], out2)
+        for _ in range(2):
+            contrast_step()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        reps = max(5, min(args.steps, 20))
+        for _ in range(reps):
+            contrast_step()
+        torch.cuda.synchronize()
+        cms = 1e3 * (time.perf_counter() - tc) / reps
+        contrast = {"ms": round(cms, 3), "per_s": round(1e3 / cms, 1), "renders": 2,
+                    "what": "renders #2,#3 fwd + log-contrast L1 (train.py:159-178) + backward of both; no optimizer"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows)
@@ -242,7 +278,7 @@ def main():
                        "sh_colour_allgather_bytes_per_rank": grad_ag_bytes,
                        "sh_exchange_on_side_stream": bool(trainer.overlap_features), "dp_schedule": dp_schedule,
                        "loss": round(loss_val, 6)},
-            "roofline": roofline, "stages": stages, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "stages": stages, "contrast_only_substep": contrast, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
         }
         print(json.dumps(out))
