@@ -441,9 +441,13 @@ __global__ __launch_bounds__(WAVE) void ssim_finalize_kernel(int nblocks, double
 
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int to_gray, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, const float* __restrict__ partial3,
-                                                       float scale, float* __restrict__ d_img1) {
+                                                       float scale, float* __restrict__ d_img1, float l1_scale,
+                                                       double* __restrict__ l1_sums) {
+    // l1_sums != NULL (e3dgs_image_loss): d_img1 = scale * dSSIM/dimg + l1_scale * sign(img1 - img2) (per channel, or
+    // on the gray values with the channel weights), and sum |img1 - img2| of the block goes to l1_sums[block]
     __shared__ float sp[3][SS_IN][SS_IN + 1];
     __shared__ float h[3][SS_IN][SS_T + 1];
+    __shared__ double wred[4];
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const size_t HW = (size_t)H * W, CHW = (size_t)gridDim.z * HW;
@@ -475,12 +479,46 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
         g0 = FMA(w, h[0][ly + k][lx], g0); g1 = FMA(w, h[1][ly + k][lx], g1); g2 = FMA(w, h[2][ly + k][lx], g2);
     }
     const int x = x0 + lx, y = y0 + ly;
+    double absdiff = 0.0;
     if (x < W && y < H) {
         float u = ss_load(img1, C, to_gray, HW, ch, x, y, W, H), v = ss_load(img2, C, to_gray, HW, ch, x, y, W, H);
         float g = scale * (g0 + 2.0f * u * g1 + v * g2);
+        if (l1_sums) {
+            const float e = u - v;
+            absdiff = (double)fabsf(e);
+            g += l1_scale * (float)((e > 0.0f) - (e < 0.0f));
+        }
         size_t p = (size_t)y * W + x;
         if (to_gray) { d_img1[p] = 0.299f * g; d_img1[HW + p] = 0.587f * g; d_img1[2 * HW + p] = 0.114f * g; }
         else d_img1[ch * HW + p] = g;
+    }
+    if (l1_sums) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) absdiff += __shfl_xor(absdiff, o, 64);
+        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = absdiff;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            l1_sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+    }
+}
+
+// scalars[0] = (1 - lambda) L1 + lambda (1 - SSIM), [1] = L1, [2] = SSIM   (train.py:213-223 / 292-296)
+__global__ __launch_bounds__(256) void image_loss_finalize_kernel(int nblocks, double count, float lambda_dssim,
+                                                                  const double* __restrict__ ssim_sums,
+                                                                  const double* __restrict__ l1_sums,
+                                                                  float* __restrict__ scalars) {
+    __shared__ double red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += ssim_sums[i]; b += l1_sums[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ssim = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / count;
+        const double l1 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / count;
+        scalars[0] = (float)((1.0 - (double)lambda_dssim) * l1 + (double)lambda_dssim * (1.0 - ssim));
+        scalars[1] = (float)l1; scalars[2] = (float)ssim; scalars[3] = 0.0f;
     }
 }
 
@@ -516,7 +554,33 @@ int e3_ssim_impl(int C, int H, int W, int to_gray, const float* img1, const floa
     ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, d_img1 ? partial3 : nullptr, sums);
     ssim_finalize_kernel<<<dim3(1), dim3(WAVE), 0, s>>>((int)nb, (double)Ceff * H * W, sums, out_mean);
     if (d_img1)
-        ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, partial3, 1.0f / ((float)Ceff * H * W), d_img1);
+        ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, partial3, 1.0f / ((float)Ceff * H * W), d_img1,
+                                                   0.0f, nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "ssim kernels");
+}
+
+// (1 - lambda) L1 + lambda (1 - SSIM) and its image gradient in three launches (the --gray and RGB iterations).
+size_t e3_image_loss_scratch_bytes(int C, int H, int W) {
+    size_t nb = (size_t)((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T) * C;
+    return e3_ssim_scratch_bytes(C, H, W) + nb * sizeof(double) + 256;
+}
+int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, const float* img, const float* gt,
+                       float* scalars, float* d_img, char* scratch, hipStream_t s) {
+    if (to_gray && C != 3) return e3_fail(hipErrorInvalidValue, "to_gray needs 3-channel inputs");
+    if (!d_img || !scalars) return e3_fail(hipErrorInvalidValue, "scalars and d_img are required");
+    ssim_upload_window();
+    const int Ceff = to_gray ? 1 : C;
+    dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, Ceff);
+    const size_t nb = (size_t)grid.x * grid.y * grid.z;
+    double* sums = reinterpret_cast<double*>(scratch);
+    float* partial3 = reinterpret_cast<float*>(scratch + align_up(nb * sizeof(double), 256));
+    double* l1_sums = reinterpret_cast<double*>(scratch + align_up(e3_ssim_scratch_bytes(C, H, W), 256));
+    const float n = (float)Ceff * H * W;
+    ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img, gt, partial3, sums);
+    ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img, gt, partial3, -lambda_dssim / n, d_img,
+                                               (1.0f - lambda_dssim) / n, l1_sums);
+    image_loss_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>((int)nb, (double)n, lambda_dssim, sums, l1_sums, scalars);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "image loss kernels");
 }

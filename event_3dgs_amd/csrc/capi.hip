@@ -53,12 +53,14 @@ int e3_event_loss_impl(int, int, const float*, const float*, const float*, const
                        const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
+size_t e3_image_loss_scratch_bytes(int, int, int);
+int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, float, int, int,
                  hipStream_t);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 6; }
+int e3dgs_abi_version(void) { return 7; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -382,6 +384,17 @@ int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* im
     g_err[0] = 0;
     if (channels <= 0 || height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
     return e3_ssim_impl(channels, height, width, to_gray, img1, img2, ssim_mean, d_img1, scratch, (hipStream_t)stream);
+}
+
+size_t e3dgs_image_loss_scratch_bytes(int channels, int height, int width) {
+    return e3_image_loss_scratch_bytes(channels, height, width);
+}
+int e3dgs_image_loss(int channels, int height, int width, int to_gray, float lambda_dssim, const float* image,
+                     const float* gt_image, float* scalars, float* d_image, char* scratch, void* stream) {
+    g_err[0] = 0;
+    if (channels <= 0 || height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
+    return e3_image_loss_impl(channels, height, width, to_gray, lambda_dssim, image, gt_image, scalars, d_image, scratch,
+                              (hipStream_t)stream);
 }
 
 int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,

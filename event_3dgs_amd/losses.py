@@ -113,6 +113,26 @@ class _SSIM(torch.autograd.Function):
         return (d * g).reshape(ctx.shape) if d is not None else None, None, None
 
 
+def image_loss_raw(image, gt_image, gray, lambda_dssim=0.2, out=None):
+    """e3dgs_image_loss: (1 - lambda) L1 + lambda (1 - SSIM) of the --gray (train.py:213-223) or RGB (train.py:292-296)
+    iteration and its gradient w.r.t. `image`, three launches, no autograd.  Returns (scalars[4], d_image): scalars[0] =
+    loss, [1] = L1, [2] = SSIM.  `out` may carry preallocated (scalars, d_image, scratch)."""
+    L = _lib.lib()
+    for t in (image, gt_image):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("image_loss_raw needs contiguous fp32 GPU tensors")
+    C_, H, W = image.shape
+    if out is None:
+        out = (torch.empty(4, dtype=torch.float32, device=image.device), torch.empty_like(image),
+               torch.empty(L.e3dgs_image_loss_scratch_bytes(C_, H, W), dtype=torch.uint8, device=image.device))
+    scalars, d_image, scratch = out
+    with torch.cuda.device(image.device):
+        rc = L.e3dgs_image_loss(C_, H, W, int(bool(gray)), float(lambda_dssim), _lib.ptr(image), _lib.ptr(gt_image),
+                                _lib.ptr(scalars), _lib.ptr(d_image), _lib.ptr(scratch), _lib.current_stream())
+    _lib.check(rc, "e3dgs_image_loss")
+    return scalars, d_image
+
+
 def ssim(img1, img2):
     """utils/loss_utils.py:388-396 (size_average=True)."""
     return _SSIM.apply(img1, img2, False)

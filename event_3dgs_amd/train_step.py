@@ -446,30 +446,18 @@ class EventTrainer:
         img = raw["color"][0]
         gt = gt_image if gt_image.dtype == torch.float32 else gt_image.float()
         gt = gt.contiguous()
-        gray = mode == "gray"
-        L = _lib.lib()
         C, H, W = img.shape
         key = ("img", C, H, W)
         if self._loss_bufs is None or self._loss_bufs[0] != key:
-            self._loss_bufs = (key, torch.empty(1, dtype=torch.float32, device=self.device), torch.empty(1, C, H, W, device=self.device),
-                               torch.empty(L.e3dgs_ssim_scratch_bytes(C, H, W), dtype=torch.uint8, device=self.device))
-        _, ssim_val, dpix, scratch = self._loss_bufs
-        d = dpix[0]
-        with torch.cuda.device(self.device):
-            rc = L.e3dgs_ssim(C, H, W, int(gray), _lib.ptr(img), _lib.ptr(gt), _lib.ptr(ssim_val), _lib.ptr(d),
-                              _lib.ptr(scratch), _lib.current_stream())
-        _lib.check(rc, "e3dgs_ssim")
-        # d holds dSSIM/dimage; loss = (1 - lambda) L1 + lambda (1 - SSIM)
-        if gray:                                   # utils/loss_utils.py:18-23,40-48: L1 on 0.299 R + 0.587 G + 0.114 B
-            w = img.new_tensor([0.299, 0.587, 0.114]).view(3, 1, 1)
-            diff = ((img - gt) * w).sum(0, keepdim=True)
-            l1 = diff.abs().mean()
-            d.mul_(-lambda_dssim).add_(torch.sign(diff) * w, alpha=(1.0 - lambda_dssim) / (H * W))
-        else:                                      # utils/loss_utils.py:270-271
-            diff = img - gt
-            l1 = diff.abs().mean()
-            d.mul_(-lambda_dssim).add_(torch.sign(diff), alpha=(1.0 - lambda_dssim) / diff.numel())
-        loss = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim_val[0])
+            self._loss_bufs = (key, torch.empty(4, dtype=torch.float32, device=self.device),
+                               torch.empty(1, C, H, W, device=self.device),
+                               torch.empty(_lib.lib().e3dgs_image_loss_scratch_bytes(C, H, W), dtype=torch.uint8,
+                                           device=self.device))
+        _, sc, dpix, scratch = self._loss_bufs
+        # (1 - lambda) L1 + lambda (1 - SSIM) and its image gradient, fused (gray: both terms on rgb_to_grayscale,
+        # utils/loss_utils.py:18-23,40-48,368-385; RGB: :270-271,388-396)
+        losses.image_loss_raw(img, gt, mode == "gray", lambda_dssim, out=(sc, dpix[0], scratch))
+        loss = sc[0]
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.track_stats:

@@ -375,6 +375,16 @@ int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* im
                float* ssim_mean, float* d_img1, char* scratch, void* stream);
 
 /*
+ * Loss of the one-render iterations, fused: scalars[0] = (1 - lambda) L1 + lambda (1 - SSIM), [1] = L1, [2] = SSIM and
+ * d_image (C,H,W) = its gradient w.r.t. `image`, in three launches.  to_gray = 0: train.py:292-296 (l1_loss
+ * utils/loss_utils.py:270-271 + ssim :388-396 per channel); to_gray = 1: train.py:213-223 (l1_loss_gray :40-48 and
+ * ssim_gray :368-385 on rgb_to_grayscale :18-23 of both 3-channel images).  scalars: 4 device floats.
+ */
+size_t e3dgs_image_loss_scratch_bytes(int channels, int height, int width);
+int e3dgs_image_loss(int channels, int height, int width, int to_gray, float lambda_dssim, const float* image,
+                     const float* gt_image, float* scalars, float* d_image, char* scratch, void* stream);
+
+/*
  * Fused Adam step over one flat parameter tensor (train.py:330-332; groups
  * scene/gaussian_model.py:154-163; eps 1e-15).  Matches torch.optim.Adam
  * (no amsgrad, no weight decay): bias-corrected with step count `step`.

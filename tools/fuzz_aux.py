@@ -93,6 +93,34 @@ def check_ssim(seed):
     return "ssim seed %d C=%d %dx%d" % (seed, C, W, H), problems
 
 
+def check_image_loss(seed):
+    """e3dgs_image_loss (fused L1 + SSIM loss of the --gray / RGB iterations) against the fp64 restatement."""
+    r = np.random.default_rng(seed)
+    H, W = int(r.choice([1, 7, 16, 17, 40, 75])), int(r.choice([1, 5, 16, 33, 130]))
+    gray = bool(r.random() < 0.5)
+    lam = float(r.choice([0.2, 0.0, 1.0, 0.7]))
+    a = torch.from_numpy(r.random((3, H, W)).astype(np.float32))
+    b = torch.from_numpy(np.clip(a.numpy() + r.normal(0, 0.1, (3, H, W)), 0, 1).astype(np.float32))
+    sc, d = losses.image_loss_raw(a.to(DEV), b.to(DEV), gray, lam)
+    x = a.clone().double().requires_grad_(True)
+    y = b.double()
+    if gray:
+        ref = torch_oracle.gray_iteration_loss(x, y, lam)
+    else:
+        ref = (1.0 - lam) * (x - y).abs().mean() + lam * (1.0 - torch_oracle.ssim(x, y))
+    ref.backward()
+    problems = []
+    if abs(float(sc[0]) - float(ref.detach())) > 3e-5:
+        problems.append("loss %.7g vs %.7g" % (float(sc[0]), float(ref.detach())))
+    g, gr = d.cpu().numpy(), x.grad.numpy()
+    # sign(img - gt) flips where the difference is ~0 in fp32: compare away from those pixels
+    e = (a - b).numpy() if not gray else np.tile((0.299 * (a - b)[0] + 0.587 * (a - b)[1] + 0.114 * (a - b)[2]).numpy()[None], (3, 1, 1))
+    ok = np.abs(e) > 1e-6
+    if ok.any() and float(np.abs(g - gr)[ok].max()) > 2e-4 * max(float(np.abs(gr).max()), 1e-9):
+        problems.append("grad max diff %.3g (scale %.3g)" % (float(np.abs(g - gr)[ok].max()), float(np.abs(gr).max())))
+    return "image_loss seed %d %dx%d gray=%s lambda=%.1f" % (seed, W, H, gray, lam), problems
+
+
 def check_adam(seed):
     r = np.random.default_rng(seed)
     n = int(r.choice([1, 3, 255, 256, 257, 4099, 100_003]))
@@ -113,7 +141,7 @@ def check_adam(seed):
     return "adam seed %d n=%d lr=%g" % (seed, n, lr), problems
 
 
-CHECKS = (check_knn, check_event, check_ssim, check_adam)
+CHECKS = (check_knn, check_event, check_ssim, check_image_loss, check_adam)
 
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
