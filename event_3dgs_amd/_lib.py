@@ -97,6 +97,8 @@ def lib():
     L.e3dgs_ssim_scratch_bytes.argtypes = [C.c_int] * 3
     L.e3dgs_ssim.restype = C.c_int
     L.e3dgs_ssim.argtypes = [C.c_int] * 4 + [_fp] * 4 + [_cp, _vp]
+    L.e3dgs_densify_stats_update.restype = C.c_int
+    L.e3dgs_densify_stats_update.argtypes = [C.c_int, _fp, _ip, _fp, _fp, _fp, _vp]
     L.e3dgs_image_loss_scratch_bytes.restype = C.c_size_t
     L.e3dgs_image_loss_scratch_bytes.argtypes = [C.c_int] * 3
     L.e3dgs_image_loss.restype = C.c_int
@@ -149,5 +151,5 @@ EXPORTED_SYMBOLS = [
     "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi",
     "e3dgs_sh_grad_from_colour",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
-    "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
+    "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

@@ -323,6 +323,29 @@ int e3_event_loss_impl(int W, int H, const float* image, const float* now, const
     return e == hipSuccess ? 0 : e3_fail(e, "event loss kernels");
 }
 
+// ------------------------------------------------------------------------------------ densification statistics
+// train.py:317-320 + scene/gaussian_model.py:405-407 for the Gaussians the render saw (radii > 0):
+// max_radii2D = max(., radii); xyz_gradient_accum += |viewspace gradient (x, y)|; denom += 1.
+__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* __restrict__ viewspace_grad,
+                                                            const int* __restrict__ radii, float* __restrict__ max_radii2D,
+                                                            float* __restrict__ grad_accum, float* __restrict__ denom) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = viewspace_grad[3 * (size_t)i], gy = viewspace_grad[3 * (size_t)i + 1];
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    grad_accum[i] += __builtin_sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+}
+int e3_densify_stats_impl(int P, const float* viewspace_grad, const int* radii, float* max_radii2D, float* grad_accum,
+                          float* denom, hipStream_t s) {
+    if (P <= 0) return 0;
+    densify_stats_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, viewspace_grad, radii, max_radii2D, grad_accum, denom);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "densify_stats_kernel");
+}
+
 // ------------------------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float step_size,

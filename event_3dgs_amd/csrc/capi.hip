@@ -53,6 +53,7 @@ int e3_event_loss_impl(int, int, const float*, const float*, const float*, const
                        const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
+int e3_densify_stats_impl(int, const float*, const int*, float*, float*, float*, hipStream_t);
 size_t e3_image_loss_scratch_bytes(int, int, int);
 int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, float, int, int,
@@ -384,6 +385,13 @@ int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* im
     g_err[0] = 0;
     if (channels <= 0 || height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
     return e3_ssim_impl(channels, height, width, to_gray, img1, img2, ssim_mean, d_img1, scratch, (hipStream_t)stream);
+}
+
+int e3dgs_densify_stats_update(int P, const float* viewspace_grad, const int* radii, float* max_radii2D,
+                               float* xyz_gradient_accum, float* denom, void* stream) {
+    g_err[0] = 0;
+    if (P < 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
+    return e3_densify_stats_impl(P, viewspace_grad, radii, max_radii2D, xyz_gradient_accum, denom, (hipStream_t)stream);
 }
 
 size_t e3dgs_image_loss_scratch_bytes(int channels, int height, int width) {

@@ -36,6 +36,16 @@ class DensifyStats:
     def update(self, viewspace_grad, radii):
         """train.py:319-320 + gaussian_model.py:405-407, without boolean-mask gathers: `viewspace_grad` is the
         (N,3) NDC-unit screen-space gradient of render #1, `radii` its int32 radii (visible <=> radii > 0)."""
+        if viewspace_grad.is_cuda:        # one kernel instead of ten elementwise launches
+            from . import _lib
+            g = viewspace_grad if viewspace_grad.is_contiguous() else viewspace_grad.contiguous()
+            r = radii if (radii.dtype == torch.int32 and radii.is_contiguous()) else radii.to(torch.int32).contiguous()
+            with torch.cuda.device(g.device):
+                rc = _lib.lib().e3dgs_densify_stats_update(g.shape[0], _lib.ptr(g), _lib.ptr(r), _lib.ptr(self.max_radii2D),
+                                                           _lib.ptr(self.xyz_gradient_accum), _lib.ptr(self.denom),
+                                                           _lib.current_stream())
+            _lib.check(rc, "e3dgs_densify_stats_update")
+            return
         vis = radii > 0
         self.max_radii2D = torch.where(vis, torch.maximum(self.max_radii2D, radii.to(self.max_radii2D.dtype)),
                                        self.max_radii2D)

@@ -375,6 +375,14 @@ int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* im
                float* ssim_mean, float* d_img1, char* scratch, void* stream);
 
 /*
+ * Densification statistics of one iteration (train.py:317-320, scene/gaussian_model.py:405-407), in place, for the
+ * Gaussians with radii > 0: max_radii2D (P) = max(., radii); xyz_gradient_accum (P) += |viewspace_grad[:, :2]|
+ * (viewspace_grad (P,3) = the NDC-unit screen-space mean gradient of render #1); denom (P) += 1.
+ */
+int e3dgs_densify_stats_update(int P, const float* viewspace_grad, const int* radii, float* max_radii2D,
+                               float* xyz_gradient_accum, float* denom, void* stream);
+
+/*
  * Loss of the one-render iterations, fused: scalars[0] = (1 - lambda) L1 + lambda (1 - SSIM), [1] = L1, [2] = SSIM and
  * d_image (C,H,W) = its gradient w.r.t. `image`, in three launches.  to_gray = 0: train.py:292-296 (l1_loss
  * utils/loss_utils.py:270-271 + ssim :388-396 per channel); to_gray = 1: train.py:213-223 (l1_loss_gray :40-48 and

@@ -574,3 +574,19 @@ def test_render_mirror_matches_fused_path_and_oracle():
     f = c_oracle.Forward(**oracle_kwargs(act, cam_cpu, tuple(bg.tolist()), False, False))
     d = np.abs(dep["render"].detach().cpu().numpy() - f.out_color)
     assert float(d.mean()) <= 1e-5 and float((d > 1e-3).mean()) <= 1e-4
+
+
+def test_densify_stats_kernel_equals_torch_form():
+    """e3dgs_densify_stats_update == the masked torch form of train.py:317-320 / gaussian_model.py:405-407."""
+    from event_3dgs_amd.densify import DensifyStats
+    g = torch.Generator().manual_seed(0)
+    n = 10_007
+    gpu, cpu = DensifyStats(n, DEV), DensifyStats(n, "cpu")
+    for _ in range(3):
+        grad = torch.randn(n, 3, generator=g) * 1e-3
+        radii = (torch.randint(0, 60, (n,), generator=g, dtype=torch.int32) * (torch.rand(n, generator=g) > 0.4)).to(torch.int32)
+        gpu.update(grad.to(DEV), radii.to(DEV))
+        cpu.update(grad, radii)
+    assert torch.equal(gpu.max_radii2D.cpu(), cpu.max_radii2D) and torch.equal(gpu.denom.cpu(), cpu.denom)
+    assert torch.allclose(gpu.xyz_gradient_accum.cpu(), cpu.xyz_gradient_accum, rtol=1e-6, atol=0)
+    assert float(cpu.denom.max()) == 3.0 and float(cpu.denom.min()) == 0.0
