@@ -377,6 +377,49 @@ int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float l
     return e == hipSuccess ? 0 : e3_fail(e, "adam_kernel");
 }
 
+// All parameter groups of one flat buffer in ONE launch: consecutive segments [end[k-1], end[k]) with their own
+// learning rate and eps (xyz | f_dc | f_rest | opacity | scaling | rotation | c).  Same arithmetic as adam_kernel.
+constexpr int ADAM_MAX_SEG = 8;
+struct AdamSegs { size_t end[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; float eps[ADAM_MAX_SEG]; int n; };
+__global__ __launch_bounds__(256) void adam_segments_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, AdamSegs sg,
+                                                            float b1, float b2, float bc2_sqrt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < ADAM_MAX_SEG - 1; ++j) k += (j < sg.n - 1 && i >= sg.end[j]) ? 1 : 0;
+        float gi = g[i];
+        float mi = m[i] + (1.0f - b1) * (gi - m[i]);
+        float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        float denom = __builtin_sqrtf(vi) / bc2_sqrt + sg.eps[k];
+        p[i] = p[i] - sg.step_size[k] * (mi / denom);
+    }
+}
+int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v, int nseg, const size_t* seg_end,
+                          const float* lr, const float* eps, float b1, float b2, int step, hipStream_t s) {
+    if (n == 0) return 0;
+    if (nseg < 1 || nseg > ADAM_MAX_SEG) return e3_fail(hipErrorInvalidValue, "1..8 segments");
+    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    AdamSegs sg;
+    size_t prev = 0;
+    for (int k = 0; k < ADAM_MAX_SEG; ++k) {
+        const int j = k < nseg ? k : nseg - 1;
+        if (k < nseg && (seg_end[k] < prev || seg_end[k] > n)) return e3_fail(hipErrorInvalidValue, "segment ends must ascend within n");
+        sg.end[k] = seg_end[j]; sg.step_size[k] = (float)((double)lr[j] / bc1); sg.eps[k] = eps[j];
+        if (k < nseg) prev = seg_end[k];
+    }
+    if (seg_end[nseg - 1] != n) return e3_fail(hipErrorInvalidValue, "last segment must end at n");
+    sg.n = nseg;
+    size_t nb = (n + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, sg, b1, b2, (float)sqrt(bc2));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : e3_fail(e, "adam_segments_kernel");
+}
+
 // ------------------------------------------------------------------------------------ SSIM
 // utils/loss_utils.py:359-418: 11x11 Gaussian window (sigma 1.5, normalised), zero padding 5, depthwise,
 // C1 = 0.01^2, C2 = 0.03^2, mean over the map.  `to_gray` applies rgb_to_grayscale (:18-23) to both inputs

@@ -53,6 +53,8 @@ int e3_event_loss_impl(int, int, const float*, const float*, const float*, const
                        const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
+int e3_adam_segments_impl(size_t, float*, const float*, float*, float*, int, const size_t*, const float*, const float*, float,
+                          float, int, hipStream_t);
 int e3_densify_stats_impl(int, const float*, const int*, float*, float*, float*, hipStream_t);
 size_t e3_image_loss_scratch_bytes(int, int, int);
 int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t);
@@ -61,7 +63,7 @@ int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, flo
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 7; }
+int e3dgs_abi_version(void) { return 8; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -385,6 +387,15 @@ int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* im
     g_err[0] = 0;
     if (channels <= 0 || height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
     return e3_ssim_impl(channels, height, width, to_gray, img1, img2, ssim_mean, d_img1, scratch, (hipStream_t)stream);
+}
+
+int e3dgs_adam_step_segments(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int nseg,
+                             const size_t* seg_end, const float* lr, const float* eps, float beta1, float beta2, int step,
+                             void* stream) {
+    g_err[0] = 0;
+    if (!seg_end || !lr || !eps) return e3_fail(hipErrorInvalidValue, "segment tables are required");
+    return e3_adam_segments_impl(n, param, grad, exp_avg, exp_avg_sq, nseg, seg_end, lr, eps, beta1, beta2, step,
+                                 (hipStream_t)stream);
 }
 
 int e3dgs_densify_stats_update(int P, const float* viewspace_grad, const int* radii, float* max_radii2D,

@@ -402,21 +402,15 @@ class EventTrainer:
         losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, eps=eps, **kw)
 
     def _adam(self, it):
-        for name, _ in SEGMENTS + (("c", 1),):
-            off, n = self.seg[name]
-            sl = slice(off, off + n)
-            eps = 1e-15                                             # scene/gaussian_model.py:163
-            if name == "xyz":
-                lr, kw = self.xyz_lr(it), {}
-            elif name == "features":
-                # f_dc rows first, then f_rest rows: "element i uses lr if (i % period) < split" with period = n
-                lr, kw = self.lrs["features"], dict(lr_b=self.lrs["features_rest"], period=n, split=3 * self.N)
-            elif name == "c":
-                lr, kw, eps = self.c_lr, {}, 1e-8                   # torch.optim.Adam([c], lr=0.1), train.py:73
-            else:
-                lr, kw = self.lrs[name], {}
-            losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, eps=eps,
-                              **kw)
+        """All groups in one launch: the flat buffer is xyz | f_dc | f_rest | opacity | scaling | rotation | c."""
+        N = self.N
+        f_off, f_n = self.seg["features"]
+        ends = (self.seg["xyz"][0] + self.seg["xyz"][1], f_off + 3 * N, f_off + f_n,
+                sum(self.seg["opacity"]), sum(self.seg["scaling"]), sum(self.seg["rotation"]), sum(self.seg["c"]))
+        lrs = (self.xyz_lr(it), self.lrs["features"], self.lrs["features_rest"], self.lrs["opacity"], self.lrs["scaling"],
+               self.lrs["rotation"], self.c_lr)
+        eps = (1e-15,) * 6 + (1e-8,)           # scene/gaussian_model.py:163; torch.optim.Adam([c], lr=0.1) train.py:73
+        losses.adam_step_segments_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, ends, lrs, eps, it)
 
     # ------------------------------------------------------------------ the other two training modes of train.py
     def step_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2, sync_grads=True):

@@ -405,6 +405,16 @@ int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg,
                     void* stream);
 
 /*
+ * The same step for SEVERAL parameter groups laid out back to back in one flat buffer, in one launch: segment k covers
+ * elements [seg_end[k-1], seg_end[k]) (seg_end[-1] = 0, seg_end[nseg-1] = n) and uses lr[k] / eps[k]; nseg <= 8.
+ * seg_end / lr / eps are HOST arrays.  (The optimizer of scene/gaussian_model.py:154-163 has six groups, train.py:71-73
+ * a seventh for the contrast threshold.)
+ */
+int e3dgs_adam_step_segments(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int nseg,
+                             const size_t* seg_end, const float* lr, const float* eps, float beta1, float beta2, int step,
+                             void* stream);
+
+/*
  * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * Slots: 0 preprocess, 1 sort_depth, 2 scan_emit, 3 sort_tile, 4 tile_ranges, 5 render_fwd,
  *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set

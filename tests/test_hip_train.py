@@ -590,3 +590,28 @@ def test_densify_stats_kernel_equals_torch_form():
     assert torch.equal(gpu.max_radii2D.cpu(), cpu.max_radii2D) and torch.equal(gpu.denom.cpu(), cpu.denom)
     assert torch.allclose(gpu.xyz_gradient_accum.cpu(), cpu.xyz_gradient_accum, rtol=1e-6, atol=0)
     assert float(cpu.denom.max()) == 3.0 and float(cpu.denom.min()) == 0.0
+
+
+def test_segmented_adam_equals_per_group_adam():
+    """e3dgs_adam_step_segments (all optimizer groups of the flat buffer in one launch) == one e3dgs_adam_step per
+    group, bit for bit; bad segment tables are refused."""
+    from event_3dgs_amd import _lib, losses
+    g = torch.Generator().manual_seed(3)
+    n = 100_003
+    ends = (3000, 9000, 60_001, 61_000, 80_000, 100_002, 100_003)
+    lrs = (1.6e-4, 2.5e-3, 1.25e-4, 0.05, 5e-3, 1e-3, 0.1)
+    eps = (1e-15,) * 6 + (1e-8,)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-3
+    a = [t.clone().to(DEV) for t in (p0, torch.zeros(n), torch.zeros(n))]
+    b = [t.clone().to(DEV) for t in (p0, torch.zeros(n), torch.zeros(n))]
+    grad = gr.to(DEV)
+    for step in range(1, 4):
+        losses.adam_step_segments_(a[0], grad, a[1], a[2], ends, lrs, eps, step)
+        lo = 0
+        for e, lr, ep in zip(ends, lrs, eps):
+            losses.adam_step_(b[0][lo:e], grad[lo:e], b[1][lo:e], b[2][lo:e], lr, step, eps=ep)
+            lo = e
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    with pytest.raises(_lib.HipLibraryError, match="last segment"):
+        losses.adam_step_segments_(a[0], grad, a[1], a[2], ends[:-1], lrs[:-1], eps[:-1], 1)
