@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-substep", action="store_true",
+                    help="skip the contrast-only two-render measurement after the timed region (profiling runs: keeps the "
+                         "kernel statistics to the 3-view launches of the iteration)")
     ap.add_argument("--cpu-rows", type=int, default=3, help="tile rows composited by the CPU baseline sample")
     args = ap.parse_args()
 
@@ -221,7 +224,7 @@ def main():
     # differentialable_event_simu + L1 on the pair, backward through both renders; no intensity render, no optimizer.
     # Measured after the timed region (it does not enter `value`).
     contrast = None
-    if world == 1:
+    if world == 1 and not args.no_substep:
         from event_3dgs_amd import losses, rasterizer
         v = trainer.views
         two = [trainer._settings(c, bg) for c in (cam_now, cam_next)]

@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/pmck_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-substep"
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RE" -d $OUT/fetch -o fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$RE" -d $OUT/write -o write --output-format csv -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \

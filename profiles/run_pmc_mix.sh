@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/pmcm_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-substep"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES \
   --kernel-include-regex "$RE" -d $OUT/a -o a --output-format csv -- $CMD > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES \

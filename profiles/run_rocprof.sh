@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-substep"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
 # PMC passes: own runs, no trace domains besides kernel dispatch (see task notes)
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "render_(fwd|bwd)_kernel" -d $OUT/fetch -o fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1

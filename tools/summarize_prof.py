@@ -8,7 +8,7 @@ shutil.copy(f"{src}/trace/trace_kernel_stats.csv", f"{dst}/kernel_stats.csv")
 rows = list(csv.DictReader(open(f"{src}/trace/trace_kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"{dst}/kernel_stats_top.txt", "w") as f:
-    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline\n")
+    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-substep\n")
     f.write("(one launch of every rasteriser kernel covers the 3 views of an event iteration; the single-view launches in\n"
             " the table's min column come from the ground-truth renders bench.py makes before the timed region)\n\n")
     for r in rows[:25]:
