@@ -3,6 +3,7 @@ backward) against the reference-style composition (torch activations + drop-in o
 EventTrainer.step_autograd) from identical parameters: loss, gradients of every group, dL/dc.
 Random Gaussian counts (1..20000), frames (from 8x8, not tile multiples), SH degree, deblur term, backgrounds,
 camera distances, scale boosts.  Usage (GPU box, repo root):  python tools/fuzz_step.py [cases] [first_seed]
+FUZZ_MODE=image: the one-render gray / RGB iterations (step_image vs step_image_autograd) instead.
 """
 import math
 import os
@@ -73,6 +74,46 @@ def check(seed):
         seed, N, W, H, deg, deblur, boost, radius, bgv), problems
 
 
+def check_image(seed):
+    """The one-render iterations (--gray / RGB): fused step_image against step_image_autograd."""
+    r = np.random.default_rng(50_000 + seed)
+    N = int(r.choice([1, 50, 700, 5000, 20000]))
+    W, H = int(r.integers(8, 260)), int(r.integers(8, 200))
+    deg = int(r.integers(0, 4))
+    mode = str(r.choice(["gray", "rgb"]))
+    lam = float(r.choice([0.2, 0.2, 0.0, 0.8]))
+    boost = float(np.exp(r.uniform(math.log(0.2), math.log(12.0))))
+    bgv = float(r.choice([0.0, 0.5, 1.0]))
+    params = synth.make_scene(N, "trained", seed=seed, device=DEV)
+    params["scaling"] = params["scaling"] + math.log(boost)
+    cam = orbit_camera(int(r.integers(0, 16)), 16, W, H, device=DEV, radius=float(r.choice([1.0, 2.5, 4.0])))
+    bg = torch.full((3,), bgv, device=DEV)
+    gp = dict(params)
+    gp["xyz"] = params["xyz"] + 0.01 * torch.randn(params["xyz"].shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gt = (torch.round(EventTrainer(gp, DEV, active_sh_degree=deg).render_raw(cam, bg)["color"].clamp(0, 1) * 255) / 255).contiguous()
+    a, b = EventTrainer(params, DEV, active_sh_degree=deg), EventTrainer(params, DEV, active_sh_degree=deg)
+    la = a.step_image(cam, gt, bg, mode=mode, lambda_dssim=lam)
+    lb = b.step_image_autograd(cam, gt, bg, mode=mode, lambda_dssim=lam)
+    torch.cuda.synchronize()
+    problems = []
+    loose = N < 500
+    la0, lb0 = float(la.detach()), float(lb.detach())
+    # 1 - SSIM of two nearly equal images is a difference of fp32 numbers close to 1: 1e-6 absolute on the loss
+    if not math.isfinite(la0) or abs(la0 - lb0) > (2e-3 if loose else 2e-4) * max(abs(lb0), 1e-6) + 1e-6:
+        problems.append("loss %.7g vs %.7g" % (la0, lb0))
+    for name in ("xyz", "features", "opacity", "scaling", "rotation"):
+        ga, gb = a.grads[name].cpu().numpy(), b.grads[name].cpu().numpy()
+        if not np.isfinite(ga).all():
+            problems.append("non-finite grad " + name)
+            continue
+        sc = float(np.linalg.norm(gb))
+        err = rel_l2(ga, gb) if sc > 1e-9 else float(np.abs(ga).max())
+        if err > (3e-2 if loose else 3e-3):
+            problems.append("grad %s err %.3g (|ref| %.3g)" % (name, err, sc))
+    return "image seed %d: N=%d %dx%d deg=%d mode=%s lambda=%.1f boost %.2f bg=%.1f" % (
+        seed, N, W, H, deg, mode, lam, boost, bgv), problems
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -80,7 +121,7 @@ if __name__ == "__main__":
     for seed in range(first, first + cases):
         if os.environ.get("FUZZ_VERBOSE") == "1":
             print("seed", seed, flush=True)
-        desc, problems = check(seed)
+        desc, problems = (check_image if os.environ.get("FUZZ_MODE") == "image" else check)(seed)
         if problems:
             bad += 1
             print("FAIL", desc, "|", "; ".join(problems), flush=True)
