@@ -59,8 +59,12 @@ def main():
     ap.add_argument("--no-substep", action="store_true",
                     help="skip the contrast-only two-render measurement after the timed region (profiling runs: keeps the "
                          "kernel statistics to the 3-view launches of the iteration)")
-    ap.add_argument("--cpu-rows", type=int, default=3, help="tile rows composited by the CPU baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=3, help="tile rows composited by the C-oracle sample")
+    ap.add_argument("--torch-rows", type=int, default=1, help="tile rows composited by the PyTorch CPU baseline sample")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU); rank 0 of the children prints the line
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -73,8 +77,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # test hooks (one-GPU boxes): E3DGS_BENCH_BACKEND=gloo + E3DGS_BENCH_DEVICE=0 run the N>1 code path with all
     # ranks sharing one device; the driver's runs use neither (one rank per GPU over RCCL)
@@ -119,6 +122,7 @@ def main():
     # have one GPU).  If its first step raises on this backend, every rank falls back to the plain schedule (one
     # blocking mean of the gradient buffer per chunk, no side stream) instead of losing the run; the JSON says which.
     dp_schedule = "single rank" if world == 1 else "side-stream SH exchange + factorised SH gradient"
+    dp_fallback = False
     warm = args.warmup
     if world > 1:
         err = None
@@ -136,6 +140,7 @@ def main():
             os.environ["E3DGS_OVERLAP"] = "0"
             trainer = EventTrainer(params, dev)
             dp_schedule = "fallback (plain chunked all-reduce): " + (err or "another rank failed")
+            dp_fallback = True
         else:
             warm = max(0, warm - 1)       # the probe step was the first warm-up step
     for _ in range(warm):
@@ -258,7 +263,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows)
+        cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows, args.torch_rows)
 
     # gradient exchange per iteration and rank: mean of the non-SH groups (+ of the SH gradient unless it is rebuilt
     # from the all-gathered per-view colour gradients, EventTrainer.factorize_sh)
@@ -283,50 +288,160 @@ def main():
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "contrast_only_substep": contrast, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
+            # ranks the communicator itself reports (1: no process group) and whether the factorised / overlapped
+            # exchange had to be replaced by the plain schedule (a failing exchange must not hide in a slower number)
+            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "comm_backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
+            "dp_fallback": dp_fallback,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(trainer, cams, bg, W, H, rows):
+def self_launch(n):
+    """Re-run this command under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port); stdout/stderr are inherited, so the one JSON line of rank 0 is this process's output too."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def _oracle_inputs(trainer):
+    """The trained parameters on the host, activated with torch on the CPU (what both CPU legs and the parity leg use)."""
+    import numpy as np
+    import torch
+    v = {k: t.detach().cpu() for k, t in trainer.views.items()}
+    return dict(means=v["xyz"].numpy(), scales=torch.exp(v["scaling"]).numpy(),
+                rots=torch.nn.functional.normalize(v["rotation"]).numpy(), opac=torch.sigmoid(v["opacity"]).numpy(),
+                shs=np.ascontiguousarray(v["features"].t().reshape(-1, 16, 3).numpy()))   # (48,N) planar -> (N,16,3)
+
+
+def _pick_threads():
+    """Thread count for the PyTorch CPU leg: all host cores unless a smaller team is faster on the op mix of the per-tile
+    compositing (hundreds of small elementwise / cumprod ops, where a 256-thread barrier costs more than it saves)."""
+    import torch
+    ncpu = os.cpu_count() or 1
+    best, best_t = ncpu, None
+    x = torch.rand(1200, 256)
+    for n in sorted({ncpu, min(ncpu, 64), min(ncpu, 16)}, reverse=True):
+        torch.set_num_threads(n)
+        for _ in range(2):
+            torch.cumprod(1.0 - 0.01 * torch.exp(-x * x), 0)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            torch.cumprod(1.0 - 0.01 * torch.exp(-x * x), 0)
+        t = time.perf_counter() - t0
+        if best_t is None or t < 0.9 * best_t:
+            best, best_t = n, t
+    torch.set_num_threads(best)
+    return best
+
+
+def run_torch_cpu_baseline(inp, cams, bg, W, H, rows, budget_s=90.0):
+    """The baseline north_star names: the pure-PyTorch rasteriser (oracle/torch_oracle.py: vectorised per tile, gradients
+    from autograd) on the host cores.  Sample: projection of ALL Gaussians, binning + compositing forward and backward
+    on `rows` tile rows around the image centre, per-Gaussian backward of all Gaussians; the binning / compositing
+    times are extrapolated linearly in tile instances to the whole frame (rectangle binning, as the reference)."""
+    import numpy as np
+    import torch
+    from oracle import torch_oracle
+    threads = _pick_threads()
+    gy = (H + 15) // 16
+    r0 = max(0, gy // 2 - rows // 2)
+    total, detail = 0.0, []
+    t_begin = time.perf_counter()
+    for cam in cams:
+        if detail and time.perf_counter() - t_begin > budget_s:       # slow host: remaining views cost what the mean did
+            total += sum(d["est_s"] for d in detail) / len(detail)
+            detail.append({"skipped": True})
+            continue
+        leaves = [torch.from_numpy(inp[k]).clone().requires_grad_(True) for k in ("means", "opac", "shs", "scales", "rots")]
+        tm = {}
+        img, radii, aux = torch_oracle.rasterize(
+            leaves[0], leaves[1], viewmatrix=cam.world_view_transform.cpu(), projmatrix=cam.full_proj_transform.cpu(),
+            campos=cam.camera_center.cpu(), bg=bg.cpu(), width=W, height=H, tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), shs=leaves[2], sh_degree=3, scales=leaves[3], rotations=leaves[4],
+            tile_rows=(r0, r0 + rows), timings=tm, return_aux=True)
+        mids = aux["diff"]
+        t1 = time.perf_counter()
+        g_mid = torch.autograd.grad(img.sum(), mids, retain_graph=True, allow_unused=True)      # compositing backward
+        t2 = time.perf_counter()
+        keep = [(m, g) for m, g in zip(mids, g_mid) if g is not None and m.requires_grad]
+        torch.autograd.backward([m for m, _ in keep], [g for _, g in keep])                    # per-Gaussian backward
+        t3 = time.perf_counter()
+        pre, binning = tm["preprocess_done"] - tm["start"], tm["binning_done"] - tm["preprocess_done"]
+        comp = tm["composite_done"] - tm["binning_done"]
+        rect = aux["rect"].numpy()
+        full_I = int(aux["tiles_touched"].sum())
+        scale = full_I / max(aux["num_rendered"], 1)
+        est = pre + (binning + comp + (t2 - t1)) * scale + (t3 - t2)
+        total += est
+        detail.append({"pre_s": round(pre, 3), "bin_s": round(binning, 3), "comp_fwd_s": round(comp, 3),
+                       "comp_bwd_s": round(t2 - t1, 3), "geom_bwd_s": round(t3 - t2, 3),
+                       "row_instances": int(aux["num_rendered"]), "frame_instances": full_I, "extrap": round(scale, 2),
+                       "est_s": round(est, 2)})
+        del img, aux, leaves, g_mid, keep, rect
+    return {"value": round(1.0 / total, 6), "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"pure-PyTorch CPU rasteriser (oracle/torch_oracle.py, autograd, {threads} threads of {os.cpu_count()} host "
+                      f"CPUs): 3 views, projection + per-Gaussian backward of all Gaussians, binning + compositing fwd+bwd on "
+                      f"{rows} of {gy} tile rows extrapolated by tile instances; loss/Adam excluded",
+            "host_cpus": os.cpu_count(), "detail": detail}
+
+
+def run_c_oracle_baseline(trainer, inp, cams, bg, W, H, rows):
     """C oracle (single thread) on a bounded sample of the same workload: full preprocess + binning of
     all Gaussians for the three views, compositing fwd+bwd restricted to `rows` tile rows around the image
-    centre, extrapolated linearly in tile instances to the whole image."""
+    centre, extrapolated linearly in tile instances to the whole image.  The same leg checks the HIP operator
+    against the oracle on the sampled rows: image (bit for bit expected) and, per Gaussian, the gradients of a
+    pixel gradient that is non-zero on those rows only."""
     import numpy as np
     import torch
     from event_3dgs_amd import rasterizer
     from oracle import c_oracle
-    v = {k: t.detach().cpu() for k, t in trainer.views.items()}
-    means = v["xyz"].numpy()
-    scales = torch.exp(v["scaling"]).numpy()
-    rots = torch.nn.functional.normalize(v["rotation"]).numpy()
-    opac = torch.sigmoid(v["opacity"]).numpy()
-    shs = np.ascontiguousarray(v["features"].t().reshape(-1, 16, 3).numpy())     # (48,N) planar -> reference (N,16,3)
+    from oracle.metrics import per_gaussian_err, rel_l2
+    means, scales, rots, opac, shs = (inp[k] for k in ("means", "scales", "rots", "opac", "shs"))
+    dev = trainer.device
     gy = (H + 15) // 16
     r0 = max(0, gy // 2 - rows // 2)
+    y0, y1 = r0 * 16, min(H, (r0 + rows) * 16)
     total = 0.0
-    detail = []
-    diffs = []
+    detail, diffs, gerr = [], [], {}
+    gw = np.zeros((3, H, W), np.float32)
+    gw[:, y0:y1] = np.random.default_rng(7).standard_normal((3, y1 - y0, W)).astype(np.float32)
+    gw_dev = torch.from_numpy(gw).to(dev)
+    dev_in = [torch.from_numpy(x).to(dev) for x in (means, shs, opac, scales, rots)]
     for cam in cams:
-        t0 = time.perf_counter()
         f = c_oracle.Forward(means3D=means, opacities=opac, viewmatrix=cam.world_view_transform.contiguous().cpu().numpy(),
                              projmatrix=cam.full_proj_transform.cpu().numpy(),
                              campos=cam.camera_center.contiguous().cpu().numpy(), bg=bg.cpu().numpy(), width=W,
                              height=H, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), shs=shs,
                              sh_degree=3, scales=scales, rotations=rots, tile_rows=(r0, r0 + rows))
         t1 = time.perf_counter()
-        # parity on the sampled rows: the HIP image of the same parameters against the oracle's ("PSNR vs ref")
-        y0, y1 = r0 * 16, min(H, (r0 + rows) * 16)
-        dev = trainer.device                   # the operator path on EXACTLY the oracle's inputs (torch-CPU activations)
-        hip = rasterizer.forward_raw(*(torch.from_numpy(x).to(dev) for x in (means, shs)), None,
-                                     *(torch.from_numpy(x).to(dev) for x in (opac, scales, rots)), None,
-                                     trainer._settings(cam, bg))
-        hip_rows = hip["color"][:, y0:y1].cpu().numpy()
-        diffs.append(float(np.abs(hip_rows - f.out_color[:, y0:y1]).max()))
-        gw = np.ones((3, H, W), np.float32)
-        f.backward(gw)
+        gb = f.backward(gw)                      # timed alone: windowed compositing backward + per-Gaussian backward
         t2 = time.perf_counter()
+        # ---- parity on the sampled rows: the operator path on EXACTLY the oracle's inputs (torch-CPU activations)
+        hip = rasterizer.forward_raw(dev_in[0], dev_in[1], None, dev_in[2], dev_in[3], dev_in[4], None,
+                                     trainer._settings(cam, bg))
+        diffs.append(float(np.abs(hip["color"][:, y0:y1].cpu().numpy() - f.out_color[:, y0:y1]).max()))
+        P = means.shape[0]
+        e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        out = dict(means2D=e(P, 3), opacities=e(P, 1), means3D=e(P, 3), sh=e(P, 16, 3), scales=e(P, 3), rots=e(P, 4))
+        rasterizer.backward_raw(hip, gw_dev, out)
+        pairs = dict(means3D=(out["means3D"], gb["means3D"]), means2D=(out["means2D"], gb["means2D"]),
+                     opacities=(out["opacities"], gb["opacities"]), shs=(out["sh"], gb["shs"]),
+                     scales=(out["scales"], gb["scales"]), rotations=(out["rots"], gb["rotations"]))
+        for name, (a, b) in pairs.items():
+            a = a.cpu().numpy()
+            cur = gerr.setdefault(name, [0.0, 0.0])
+            cur[0] = max(cur[0], rel_l2(a.reshape(P, -1), np.asarray(b).reshape(P, -1)))
+            cur[1] = max(cur[1], per_gaussian_err(a, np.asarray(b).reshape(a.shape)))
+        del hip, out
         tm = f.timings            # preprocess, binning, composite seconds
         ranges = f.ranges.reshape(gy, -1, 2)
         inst_rows = int((ranges[r0:r0 + rows, :, 1] - ranges[r0:r0 + rows, :, 0]).sum())
@@ -336,14 +451,28 @@ def run_cpu_baseline(trainer, cams, bg, W, H, rows):
         detail.append({"pre_s": round(tm[0], 3), "bin_s": round(tm[1], 3), "comp_fwd_s": round(tm[2], 3),
                        "bwd_s": round(t2 - t1, 3), "row_instances": inst_rows, "extrap": round(scale, 2)})
         f.close()
-    return {"value": round(1.0 / total, 5), "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"C oracle (oracle/gs_oracle.c, 1 thread): 3 views, full preprocess+sort of all Gaussians, "
-                      f"compositing fwd+bwd on {rows} of {gy} tile rows extrapolated by tile instances; loss/Adam excluded",
-            "host_cpus": os.cpu_count(), "detail": detail,
-            "parity_vs_oracle": {"rows_checked": rows * 16 * len(cams), "max_abs_diff": max(diffs),
-                                 "psnr_db": None if max(diffs) == 0.0 else round(-20.0 * math.log10(max(diffs)), 1),
-                                 "note": "HIP operator vs C oracle on identical inputs (the trained parameters after the timed "
-                                         "steps), sampled tile rows of the three views; 0.0 = bit-identical (PSNR unbounded)"}}
+    c_part = {"value": round(1.0 / total, 5), "unit": "iters/s", "cores": 1, "kind": "port",
+              "sample": f"C oracle (oracle/gs_oracle.c, 1 thread): 3 views, full preprocess+sort of all Gaussians, "
+                        f"compositing fwd+bwd on {rows} of {gy} tile rows extrapolated by tile instances; loss/Adam excluded",
+              "detail": detail}
+    parity = {"rows_checked": rows * 16 * len(cams), "max_abs_diff": max(diffs),
+              "psnr_db": None if max(diffs) == 0.0 else round(-20.0 * math.log10(max(diffs)), 1),
+              "grad_rel_l2": {k: float("%.3g" % v[0]) for k, v in gerr.items()},
+              "grad_per_gaussian_max": {k: float("%.3g" % v[1]) for k, v in gerr.items()},
+              "note": "HIP operator vs C oracle on identical inputs (the trained parameters after the timed steps), sampled "
+                      "tile rows of the three views; image: 0.0 = bit-identical (PSNR unbounded); gradients of a random pixel "
+                      "gradient supported on those rows: global relative L2 and max over Gaussians of "
+                      "|d_i| / (|ref_i| + 1e-3 max_j |ref_j|)"}
+    return c_part, parity
+
+
+def run_cpu_baseline(trainer, cams, bg, W, H, rows, torch_rows):
+    inp = _oracle_inputs(trainer)
+    c_part, parity = run_c_oracle_baseline(trainer, inp, cams, bg, W, H, rows)
+    out = run_torch_cpu_baseline(inp, cams, bg, W, H, torch_rows)
+    out["c_oracle_single_thread"] = c_part
+    out["parity_vs_oracle"] = parity
+    return out
 
 
 if __name__ == "__main__":

@@ -41,6 +41,11 @@ SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633
          1.445305721320277, -0.5900435899266435]
 
 
+def _now():
+    import time
+    return time.perf_counter()
+
+
 def eval_sh_colors(deg, shs, dirs):
     """shs (P,M,3), dirs (P,3) unit -> (P,3) = max(sum_k Y_k sh_k + 0.5, 0).  utils/sh_utils.py:57-112."""
     x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
@@ -73,16 +78,20 @@ def build_cov3d(scales, rotations, mod):
 
 def rasterize(means3D, opacities, *, viewmatrix, projmatrix, campos, bg, width, height, tanfovx, tanfovy,
               colors_precomp=None, shs=None, sh_degree=0, scales=None, rotations=None, cov3D_precomp=None,
-              scale_modifier=1.0, means2D=None, return_aux=False):
+              scale_modifier=1.0, means2D=None, return_aux=False, tile_rows=None, timings=None):
     """Differentiable forward.  Returns (color (3,H,W), radii (P,) int32[, aux dict]).
 
     If `means2D` (P,3, requires_grad) is given it receives the NDC-unit screen-space
     gradient exactly like the reference's `screenspace_points`
     (gaussian_renderer/__init__.py:28-32).
+    `tile_rows=(r0, r1)`: only tile rows [r0, r1) are binned and composited (pixels outside keep 0);
+    `timings`: dict that receives perf_counter stamps of the stages.
     """
     dt = means3D.dtype
     P = means3D.shape[0]
     W, H = int(width), int(height)
+    if timings is not None:
+        timings["start"] = _now()
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     V = viewmatrix.to(dt).reshape(4, 4)   # row-vector layout: p_row @ V
     Pm = projmatrix.to(dt).reshape(4, 4)
@@ -140,17 +149,25 @@ def rasterize(means3D, opacities, *, viewmatrix, projmatrix, campos, bg, width, 
         colors = colors_precomp.to(dt)
     opac = opacities.reshape(-1).to(dt)
 
+    if timings is not None:
+        timings["preprocess_done"] = _now()
     # ---- binning: instances sorted by (tile, depth bits, index) ----
+    # vectorised: instance k of Gaussian g covers tile (ymin + k // w, xmin + k % w); with a tile-row window only the
+    # rows [r0, r1) of each rectangle are generated (bench.py's bounded CPU sample)
+    r0, r1 = (0, gy) if tile_rows is None else (max(0, int(tile_rows[0])), min(gy, int(tile_rows[1])))
     vis = torch.nonzero(visible).reshape(-1).numpy()
-    xmin_n, ymin_n, xmax_n, ymax_n = (t.numpy() for t in (xmin, ymin, xmax, ymax))
+    xmin_n, xmax_n = xmin.numpy()[vis], xmax.numpy()[vis]
+    ylo_n, yhi_n = np.maximum(ymin.numpy()[vis], r0), np.minimum(ymax.numpy()[vis], r1)
+    wid = xmax_n - xmin_n
+    cnt = wid * np.maximum(yhi_n - ylo_n, 0)
     depth_n = vz.detach().to(torch.float32).numpy()
-    tiles, gids = [], []
-    for g in vis:
-        ys, xs = np.meshgrid(np.arange(ymin_n[g], ymax_n[g]), np.arange(xmin_n[g], xmax_n[g]), indexing="ij")
-        t = (ys * gx + xs).reshape(-1)
-        tiles.append(t); gids.append(np.full(t.shape, g, np.int64))
-    tiles = np.concatenate(tiles) if tiles else np.zeros(0, np.int64)
-    gids = np.concatenate(gids) if gids else np.zeros(0, np.int64)
+    if cnt.sum() > 0:
+        rep = np.repeat(np.arange(vis.shape[0]), cnt)
+        k = np.arange(rep.shape[0]) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        tiles = (ylo_n[rep] + k // wid[rep]) * gx + xmin_n[rep] + k % wid[rep]
+        gids = vis[rep].astype(np.int64)
+    else:
+        tiles, gids = np.zeros(0, np.int64), np.zeros(0, np.int64)
     order = np.lexsort((gids, depth_n[gids].view(np.uint32), tiles))
     tiles, gids = tiles[order], gids[order]
     starts = np.searchsorted(tiles, np.arange(gx * gy), "left")
@@ -160,7 +177,9 @@ def rasterize(means3D, opacities, *, viewmatrix, projmatrix, campos, bg, width, 
     final_T = torch.ones(H, W, dtype=dt)
     n_contrib = torch.zeros(H, W, dtype=torch.int64)
     rows = []
-    for t in range(gx * gy):
+    if timings is not None:
+        timings["binning_done"] = _now()
+    for t in range(r0 * gx, r1 * gx):
         tyi, txi = divmod(t, gx)
         y0, x0 = tyi * TILE, txi * TILE
         y1, x1 = min(y0 + TILE, H), min(x0 + TILE, W)
@@ -191,12 +210,17 @@ def rasterize(means3D, opacities, *, viewmatrix, projmatrix, campos, bg, width, 
         final_T[y0:y1, x0:x1] = Tf.detach().reshape(y1 - y0, x1 - x0)
         idx1 = torch.arange(1, ids.numel() + 1)[:, None] * keep
         n_contrib[y0:y1, x0:x1] = idx1.max(0).values.reshape(y1 - y0, x1 - x0)
+    if timings is not None:
+        timings["composite_done"] = _now()
     if not return_aux:
         return out, radii
     aux = {"xy": pix.detach(), "conic": conic.detach(), "depth": vz.detach(), "rect": torch.stack([xmin, ymin, xmax, ymax], -1),
            "tiles_touched": torch.where(visible, area, torch.zeros_like(area)), "point_list": gids, "tile_list": tiles,
            "ranges": np.stack([starts, ends], -1), "final_T": final_T, "n_contrib": n_contrib, "cov3d": S.detach(),
-           "colors": colors.detach(), "num_rendered": int(tiles.shape[0])}
+           "colors": colors.detach(), "num_rendered": int(tiles.shape[0]),
+           # the per-Gaussian tensors the compositing reads, still attached to the graph: lets a caller time / inspect the
+           # compositing backward (d/d these) apart from the per-Gaussian backward (these -> inputs)
+           "diff": (pix, conic, colors, opac)}
     return out, radii, aux
 
 

@@ -36,7 +36,4 @@ def oracle_kwargs(act, cam, bg, use_sh, use_cov, sh_degree=3, scale_modifier=1.0
     return kw
 
 
-def rel_l2(a, b):
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+from oracle.metrics import per_gaussian_err, rel_l2  # noqa: E402,F401

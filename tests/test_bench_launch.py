@@ -1,0 +1,52 @@
+"""bench.py's launch contract: `python bench.py --gpus N` must not exit at argument parsing (it re-launches itself
+under torch.distributed.run, one rank per GPU) and rank 0 prints exactly one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_self_launch_builds_the_torchrun_command(monkeypatch):
+    """CPU: the launcher re-runs the same arguments under torch.distributed.run on 127.0.0.1."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+
+
+def test_mismatched_world_size_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_fallback", [False, True])
+def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback):
+    """The driver's command form on a one-GPU box: both ranks share cuda:0 and talk over gloo (test hooks of bench.py)."""
+    env = dict(os.environ, E3DGS_BENCH_BACKEND="gloo", E3DGS_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    if force_fallback:
+        env["E3DGS_BENCH_FORCE_FALLBACK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["comm_backend"] == "gloo"
+    assert out["scaling"] == "weak" and out["value"] > 0
+    assert out["dp_fallback"] is force_fallback
+    assert out["config"]["workload"] == "tiny"
