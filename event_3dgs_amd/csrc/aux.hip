@@ -216,8 +216,10 @@ __global__ __launch_bounds__(EV_THREADS) void event_reduce_kernel(
     const float c = c_ptr[0];
     double acc[EV_NSUM] = {0, 0, 0, 0, 0};
     for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
-        float D = (__logf(lum3(next, HW, p) + 1e-8f) - __logf(lum3(now, HW, p) + 1e-8f)) / c;
-        float Dg = (__logf(lum3(gt_next, HW, p) + 1e-8f) - __logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
+        // logf, not the fast __logf: the mask rho = count(D* != 0) and sign(D - D*) hinge on exact zeros / ties, and the
+        // reference's torch.log is the 1-ulp device logf (equal luminances give exactly D* = 0 with any deterministic log)
+        float D = (logf(lum3(next, HW, p) + 1e-8f) - logf(lum3(now, HW, p) + 1e-8f)) / c;
+        float Dg = (logf(lum3(gt_next, HW, p) + 1e-8f) - logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
         float e = D - Dg;
         acc[0] += fabsf(e);
         acc[1] += (Dg != 0.0f) ? 1.0 : 0.0;
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     const float wch[3] = {0.4124f, 0.35758f, 0.1804f};
     for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
         float yn = lum3(next, HW, p) + 1e-8f, yo = lum3(now, HW, p) + 1e-8f;
-        float D = (__logf(yn) - __logf(yo)) / c;
-        float Dg = (__logf(lum3(gt_next, HW, p) + 1e-8f) - __logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
+        float D = (logf(yn) - logf(yo)) / c;
+        float Dg = (logf(lum3(gt_next, HW, p) + 1e-8f) - logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
         float e = D - Dg;
         float k = kE * (float)((e > 0.0f) - (e < 0.0f)) / c;
 #pragma unroll
@@ -380,42 +382,51 @@ int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float l
 // All parameter groups of one flat buffer in ONE launch: consecutive segments [end[k-1], end[k]) with their own
 // learning rate and eps (xyz | f_dc | f_rest | opacity | scaling | rotation | c).  Same arithmetic as adam_kernel.
 constexpr int ADAM_MAX_SEG = 8;
-struct AdamSegs { size_t end[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; float eps[ADAM_MAX_SEG]; int n; };
+struct AdamSegs { size_t end[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; float eps[ADAM_MAX_SEG];
+                  float bc2_sqrt[ADAM_MAX_SEG]; int n; unsigned skip; };
 __global__ __launch_bounds__(256) void adam_segments_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, AdamSegs sg,
-                                                            float b1, float b2, float bc2_sqrt) {
+                                                            float b1, float b2) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         int k = 0;
 #pragma unroll
         for (int j = 0; j < ADAM_MAX_SEG - 1; ++j) k += (j < sg.n - 1 && i >= sg.end[j]) ? 1 : 0;
+        if ((sg.skip >> k) & 1u) continue;       // a group torch.optim.Adam would skip (its .grad is None): untouched
         float gi = g[i];
         float mi = m[i] + (1.0f - b1) * (gi - m[i]);
         float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        float denom = __builtin_sqrtf(vi) / bc2_sqrt + sg.eps[k];
+        float denom = __builtin_sqrtf(vi) / sg.bc2_sqrt[k] + sg.eps[k];
         p[i] = p[i] - sg.step_size[k] * (mi / denom);
     }
 }
+// steps[k]: the 1-based Adam step of segment k (torch keeps one `step` per parameter; groups that were skipped on some
+// iterations lag behind), <= 0: skip the segment (parameter and moments untouched).  steps == NULL: `step` for all.
 int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v, int nseg, const size_t* seg_end,
-                          const float* lr, const float* eps, float b1, float b2, int step, hipStream_t s) {
+                          const float* lr, const float* eps, float b1, float b2, int step, const int* steps,
+                          hipStream_t s) {
     if (n == 0) return 0;
     if (nseg < 1 || nseg > ADAM_MAX_SEG) return e3_fail(hipErrorInvalidValue, "1..8 segments");
-    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     AdamSegs sg;
+    sg.skip = 0u;
     size_t prev = 0;
     for (int k = 0; k < ADAM_MAX_SEG; ++k) {
         const int j = k < nseg ? k : nseg - 1;
         if (k < nseg && (seg_end[k] < prev || seg_end[k] > n)) return e3_fail(hipErrorInvalidValue, "segment ends must ascend within n");
+        const int st = steps ? steps[j] : step;
+        if (st <= 0) sg.skip |= 1u << k;
+        const double bc1 = 1.0 - pow((double)b1, st > 0 ? st : 1), bc2 = 1.0 - pow((double)b2, st > 0 ? st : 1);
         sg.end[k] = seg_end[j]; sg.step_size[k] = (float)((double)lr[j] / bc1); sg.eps[k] = eps[j];
+        sg.bc2_sqrt[k] = (float)sqrt(bc2);
         if (k < nseg) prev = seg_end[k];
     }
     if (seg_end[nseg - 1] != n) return e3_fail(hipErrorInvalidValue, "last segment must end at n");
     sg.n = nseg;
     size_t nb = (n + 255) / 256;
     if (nb > 8192) nb = 8192;
-    adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, sg, b1, b2, (float)sqrt(bc2));
+    adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, sg, b1, b2);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "adam_segments_kernel");
 }
@@ -426,7 +437,7 @@ int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v
 // first (ssim_gray :368-385).  Forward writes the three partials dm/dmu1, dm/ds11, dm/ds12 per pixel; the
 // backward pass blurs them (the window is symmetric) and applies the chain rule of mu1, E[x^2], E[xy].
 constexpr int SS_T = 16, SS_R = 5, SS_IN = SS_T + 2 * SS_R;   // 16x16 outputs from a 26x26 input patch
-__constant__ float c_ssim_w[11];
+struct SsimWin { float w[11]; };      // the 11 taps travel as a kernel argument: no per-device / per-process state
 
 __device__ __forceinline__ float ss_load(const float* __restrict__ img, int C, int to_gray, size_t HW, int ch, int x, int y,
                                          int W, int H) {
@@ -436,7 +447,7 @@ __device__ __forceinline__ float ss_load(const float* __restrict__ img, int C, i
     return img[ch * HW + p];
 }
 
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int to_gray, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWin win, int C, int H, int W, int to_gray, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ partial3,
                                                        double* __restrict__ block_sums) {
     __shared__ float s1[SS_IN][SS_IN + 1], s2[SS_IN][SS_IN + 1];
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
         float a = 0, b = 0, aa = 0, bb = 0, ab = 0;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
-            float w = c_ssim_w[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
+            float w = win.w[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
             a = FMA(w, u, a); b = FMA(w, v, b); aa = FMA(w, u * u, aa); bb = FMA(w, v * v, bb); ab = FMA(w, u * v, ab);
         }
         h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
@@ -466,7 +477,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
     float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {                                    // vertical pass
-        float w = c_ssim_w[k];
+        float w = win.w[k];
         mu1 = FMA(w, h[0][ly + k][lx], mu1); mu2 = FMA(w, h[1][ly + k][lx], mu2);
         e11 = FMA(w, h[2][ly + k][lx], e11); e22 = FMA(w, h[3][ly + k][lx], e22); e12 = FMA(w, h[4][ly + k][lx], e12);
     }
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(WAVE) void ssim_finalize_kernel(int nblocks, double
     if (threadIdx.x == 0) out_mean[0] = (float)(a / count);
 }
 
-__global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int to_gray, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWin win, int C, int H, int W, int to_gray, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, const float* __restrict__ partial3,
                                                        float scale, float* __restrict__ d_img1, float l1_scale,
                                                        double* __restrict__ l1_sums) {
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
         float a = 0, b = 0, c = 0;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
-            float w = c_ssim_w[k];
+            float w = win.w[k];
             a = FMA(w, sp[0][ly][lx + k], a); b = FMA(w, sp[1][ly][lx + k], b); c = FMA(w, sp[2][ly][lx + k], c);
         }
         h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
     float g0 = 0, g1 = 0, g2 = 0;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-        float w = c_ssim_w[k];
+        float w = win.w[k];
         g0 = FMA(w, h[0][ly + k][lx], g0); g1 = FMA(w, h[1][ly + k][lx], g1); g2 = FMA(w, h[2][ly + k][lx], g2);
     }
     const int x = x0 + lx, y = y0 + ly;
@@ -588,19 +599,13 @@ __global__ __launch_bounds__(256) void image_loss_finalize_kernel(int nblocks, d
     }
 }
 
-static void ssim_upload_window() {
-    static bool done = false;
-    if (done) return;
-    double w[11], s = 0;
-    for (int i = 0; i < 11; ++i) { w[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += w[i]; }
-    float wf[11];
-    // the reference builds the window in fp32 (torch.Tensor of python floats, then / sum)
+static SsimWin ssim_window() {
+    // the reference builds the window in fp32 (torch.Tensor of python floats, then / sum): utils/loss_utils.py:359-367
+    SsimWin win;
     float fs = 0.0f;
-    for (int i = 0; i < 11; ++i) { wf[i] = (float)w[i]; fs += wf[i]; }
-    for (int i = 0; i < 11; ++i) wf[i] = wf[i] / fs;
-    (void)s;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_ssim_w), wf, sizeof wf);
-    done = true;
+    for (int i = 0; i < 11; ++i) { win.w[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); fs += win.w[i]; }
+    for (int i = 0; i < 11; ++i) win.w[i] = win.w[i] / fs;
+    return win;
 }
 
 size_t e3_ssim_scratch_bytes(int C, int H, int W) {
@@ -611,16 +616,16 @@ size_t e3_ssim_scratch_bytes(int C, int H, int W) {
 int e3_ssim_impl(int C, int H, int W, int to_gray, const float* img1, const float* img2, float* out_mean, float* d_img1,
                  char* scratch, hipStream_t s) {
     if (to_gray && C != 3) return e3_fail(hipErrorInvalidValue, "to_gray needs 3-channel inputs");
-    ssim_upload_window();
+    const SsimWin win = ssim_window();
     const int Ceff = to_gray ? 1 : C;
     dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, Ceff);
     size_t nb = (size_t)grid.x * grid.y * grid.z;
     double* sums = reinterpret_cast<double*>(scratch);
     float* partial3 = reinterpret_cast<float*>(scratch + align_up(nb * sizeof(double), 256));
-    ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, d_img1 ? partial3 : nullptr, sums);
+    ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img1, img2, d_img1 ? partial3 : nullptr, sums);
     ssim_finalize_kernel<<<dim3(1), dim3(WAVE), 0, s>>>((int)nb, (double)Ceff * H * W, sums, out_mean);
     if (d_img1)
-        ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img1, img2, partial3, 1.0f / ((float)Ceff * H * W), d_img1,
+        ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img1, img2, partial3, 1.0f / ((float)Ceff * H * W), d_img1,
                                                    0.0f, nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "ssim kernels");
@@ -635,7 +640,7 @@ int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, con
                        float* scalars, float* d_img, char* scratch, hipStream_t s) {
     if (to_gray && C != 3) return e3_fail(hipErrorInvalidValue, "to_gray needs 3-channel inputs");
     if (!d_img || !scalars) return e3_fail(hipErrorInvalidValue, "scalars and d_img are required");
-    ssim_upload_window();
+    const SsimWin win = ssim_window();
     const int Ceff = to_gray ? 1 : C;
     dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, Ceff);
     const size_t nb = (size_t)grid.x * grid.y * grid.z;
@@ -643,8 +648,8 @@ int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, con
     float* partial3 = reinterpret_cast<float*>(scratch + align_up(nb * sizeof(double), 256));
     double* l1_sums = reinterpret_cast<double*>(scratch + align_up(e3_ssim_scratch_bytes(C, H, W), 256));
     const float n = (float)Ceff * H * W;
-    ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img, gt, partial3, sums);
-    ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(C, H, W, to_gray, img, gt, partial3, -lambda_dssim / n, d_img,
+    ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img, gt, partial3, sums);
+    ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img, gt, partial3, -lambda_dssim / n, d_img,
                                                (1.0f - lambda_dssim) / n, l1_sums);
     image_loss_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>((int)nb, (double)n, lambda_dssim, sums, l1_sums, scalars);
     hipError_t e = hipGetLastError();

@@ -2,11 +2,13 @@
 //
 //   render_bwd_kernel  a19  one wave per tile, 4 pixels per lane, back-to-front walk over the same
 //                           sorted list; per list entry the 9 partial sums (mean2D 2, conic 3,
-//                           opacity 1, colour 3) are reduced across the wave with DPP adds and
-//                           committed with ONE atomic per value per (tile, Gaussian) -- instead of
-//                           the reference's one atomic per pixel per value.
+//                           opacity 1, colour 3) are reduced across the wave through LDS and stored as
+//                           ONE 48-byte record at the instance's slot -- plain stores, no atomics
+//                           (the reference adds every value of every pixel with atomicAdd).
+//   run_reduce_kernel  ---  per-splat sum of its (contiguous) instance records, fixed order.
 //   geom_bwd_kernel    a20+a21 fused: conic -> Sigma2 -> Sigma3 and view-space mean, NDC mean through
-//                           the projection, SH backward, Sigma3 -> scale / quaternion.
+//                           the projection, SH backward, Sigma3 -> scale / quaternion
+//                           (geom_bwd_multi_kernel: all views of an iteration in one pass).
 #include "common.h"
 #include <stdlib.h>
 

@@ -14,10 +14,11 @@ from .train_step import EventTrainer
 HELD_OUT = (5, 25, 45, 65, 85)       # evaluation views, train.py:129-131 / eval.py:118
 
 
-def sample_index(n_cameras, event=True, rng=randint):
-    """train.py:116-131: randint(2, n-4) in event mode (n-3 otherwise); held-out views shift down by one."""
-    index = rng(2, n_cameras - 4) if event else rng(2, n_cameras - 3)
-    if index in HELD_OUT:
+def sample_index(n_cameras, mode="event", rng=randint):
+    """train.py:116-131: randint(2, n-4) in event mode, randint(2, n-3) otherwise; the held-out views (5, 25, 45, 65, 85)
+    shift down by one in event and gray mode only (:129-131) -- plain RGB training samples them."""
+    index = rng(2, n_cameras - 4) if mode == "event" else rng(2, n_cameras - 3)
+    if mode in ("event", "gray") and index in HELD_OUT:
         index -= 1
     return index
 
@@ -36,7 +37,14 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
     stay bit-identical through clone / split / prune.
 
     mode: "event" (train.py:149-212, the north-star path), "gray" (train.py:213-223) or "rgb" (train.py:292-296);
-    the last two render one camera per iteration and need no event cameras (event_cameras may be None)."""
+    the last two render one camera per iteration and need no event cameras (event_cameras may be None).
+
+    Order inside an iteration, as train.py:144-332: forward + loss + backward; optimizer_c.step() (event mode, :212);
+    densification statistics; densify_and_prune / reset_opacity; THEN the Gaussian optimizer step.  Densification and
+    the opacity reset replace the parameters before optimizer.step(), so torch finds no gradient on them: on a
+    densification iteration none of the six Gaussian groups is updated (their step counts stall too), on a reset
+    iteration the opacity group is not, and the last iteration (`iteration < opt.iterations`, :330) has no Gaussian
+    step at all.  The contrast threshold c steps on every event iteration."""
     if mode not in ("event", "gray", "rgb"):
         raise ValueError("mode must be 'event', 'gray' or 'rgb'")
     if opacity_reset_interval is None:              # train.py:119 forces 10000 in event mode; arguments/__init__.py: 3000
@@ -50,21 +58,30 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
         if iteration % sh_ramp_interval == 0 and tr.active_sh_degree < max_sh_degree:      # train.py:99-100
             tr.active_sh_degree += 1
         if world > 1:
-            index = parallel.rank_camera_indices(rank, world, len(train_cameras), iteration, seed, HELD_OUT)
-            index = min(index, len(train_cameras) - 4)                                      # index + 1 must exist
+            index = parallel.rank_camera_indices(rank, world, len(train_cameras), iteration, seed, HELD_OUT, mode=mode)
         else:
-            index = sample_index(len(train_cameras), mode == "event", rng)
+            index = sample_index(len(train_cameras), mode, rng)
         cam = train_cameras[index]
         if mode == "event":
             now, nxt = event_cameras[index], event_cameras[index + 1]
             blur = blurry_cameras[index].original_image if blurry_cameras else None         # train.py:197-203
-            scalars = tr.step(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image, bg,
-                              gt_blur=blur)
+            scalars = tr.compute_gradients(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image,
+                                           bg, gt_blur=blur)
         else:
-            scalars = tr.step_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim)
+            scalars = tr.compute_gradients_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim)
+        scalars = scalars.clone()
         upd, dens, size_thr, reset = densify.densification_schedule(
             iteration, densify_until_iter, densify_from_iter, densification_interval, opacity_reset_interval,
             white_background)
+        skip = set() if mode == "event" else {"c"}
+        if dens or iteration == iterations:
+            skip.add("gaussians")
+        if reset:
+            skip.add("opacity")
+        if "gaussians" in skip and "c" not in skip:
+            # optimizer_c.step() comes right after backward (train.py:212), before the parameters are replaced; the
+            # Gaussian gradients of this iteration are dropped, as torch drops them with the replaced tensors
+            tr.apply_update(skip=("gaussians",))
         if upd:                                                                             # train.py:317-327
             stats.update(tr.viewspace_grad, tr.last_radii)
             if dens:
@@ -74,6 +91,10 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
                 tr.densify_and_prune(stats, densify_grad_threshold, 0.005, cameras_extent, size_thr, percent_dense)
             if reset:
                 tr.reset_opacity()
+        if "gaussians" not in skip:
+            tr.apply_update(skip=tuple(skip))                                               # train.py:330-332
+        elif "c" in skip:
+            tr.iteration += 1                                    # nothing steps, the learning-rate clock still advances
         if on_iteration is not None:
             on_iteration(iteration, tr, scalars)
     return tr

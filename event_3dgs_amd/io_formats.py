@@ -133,11 +133,13 @@ def fetch_pointcloud_ply(path):
 def capture_checkpoint(groups, stats, active_sh_degree, spatial_lr_scale, lrs, step, eps=1e-15):
     """The 12-tuple of GaussianModel.capture() (scene/gaussian_model.py:61-75) incl. a torch.optim.Adam
     state_dict with the reference's six groups in its order (:154-163), so `torch.save((tuple, iteration), path)`
-    (train.py:334-336) yields a file the reference's restore() accepts."""
+    (train.py:334-336) yields a file the reference's restore() accepts.  `step`: one count, or a dict group -> count
+    (EventTrainer.steps: the opacity group lags after resets)."""
     order = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
     state, pg = {}, []
     for i, name in enumerate(order):
-        state[i] = {"step": torch.tensor(float(step)), "exp_avg": groups[name][1].clone(), "exp_avg_sq": groups[name][2].clone()}
+        st = step[name] if isinstance(step, dict) else step     # torch keeps one step count per parameter
+        state[i] = {"step": torch.tensor(float(st)), "exp_avg": groups[name][1].clone(), "exp_avg_sq": groups[name][2].clone()}
         pg.append({"lr": lrs[name], "name": name, "betas": (0.9, 0.999), "eps": eps, "weight_decay": 0, "amsgrad": False,
                    "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                    "params": [i]})

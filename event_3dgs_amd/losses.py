@@ -86,17 +86,24 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.99
 
 def adam_step_segments_(param, grad, exp_avg, exp_avg_sq, seg_end, lrs, eps, step, beta1=0.9, beta2=0.999):
     """In-place fused Adam over consecutive segments of one flat fp32 tensor, each with its own learning rate and eps, in
-    one launch (e3dgs_adam_step_segments).  seg_end: ascending element offsets, the last one == param.numel()."""
+    one launch.  seg_end: ascending element offsets, the last one == param.numel().  `step`: one int for all segments
+    (e3dgs_adam_step_segments) or one per segment, <= 0 = leave that segment untouched (e3dgs_adam_step_groups: torch's
+    per-parameter step counts and its skipping of parameters without a gradient)."""
     import ctypes as C
     for t in (param, grad, exp_avg, exp_avg_sq):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError("adam_step_segments_ needs contiguous fp32 GPU tensors")
     k = len(seg_end)
+    common = (param.numel(), _lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), k,
+              (C.c_size_t * k)(*[int(e) for e in seg_end]), (C.c_float * k)(*[float(x) for x in lrs]),
+              (C.c_float * k)(*[float(x) for x in eps]), beta1, beta2)
     with torch.cuda.device(param.device):
-        rc = _lib.lib().e3dgs_adam_step_segments(
-            param.numel(), _lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), k,
-            (C.c_size_t * k)(*[int(e) for e in seg_end]), (C.c_float * k)(*[float(x) for x in lrs]),
-            (C.c_float * k)(*[float(x) for x in eps]), beta1, beta2, int(step), _lib.current_stream())
+        if isinstance(step, (tuple, list)):
+            if len(step) != k:
+                raise ValueError("one step count per segment")
+            rc = _lib.lib().e3dgs_adam_step_groups(*common, (C.c_int * k)(*[int(x) for x in step]), _lib.current_stream())
+        else:
+            rc = _lib.lib().e3dgs_adam_step_segments(*common, int(step), _lib.current_stream())
     _lib.check(rc, "e3dgs_adam_step_segments")
 
 

@@ -78,11 +78,13 @@ def allgather_async_(out, local, group=None):
     return PendingGather(out, work)
 
 
-def rank_camera_indices(rank, world, n_cameras, iteration, seed=0, exclude=(5, 25, 45, 65, 85)):
-    """Deterministic per-rank camera draw mirroring train.py:116-131: index in [2, n-4], the held-out
-    evaluation views shifted down by one.  Every rank can recompute every other rank's draw."""
+def rank_camera_indices(rank, world, n_cameras, iteration, seed=0, exclude=(5, 25, 45, 65, 85), mode="event"):
+    """Deterministic per-rank camera draw mirroring train.py:116-131: index in [2, n-4] in event mode ([2, n-3]
+    otherwise), the held-out evaluation views shifted down by one in event / gray mode.  Every rank can recompute
+    every other rank's draw."""
     g = torch.Generator().manual_seed(seed * 1000003 + iteration * 131 + rank)
-    idx = int(torch.randint(2, max(3, n_cameras - 3), (1,), generator=g))
-    if idx in exclude:
+    hi = n_cameras - 4 if mode == "event" else n_cameras - 3          # inclusive, as random.randint
+    idx = int(torch.randint(2, max(3, hi + 1), (1,), generator=g))
+    if mode in ("event", "gray") and idx in exclude:
         idx -= 1
     return idx

@@ -72,6 +72,11 @@ class EventTrainer:
                         rotation=rotation_lr)
         self.active_sh_degree = active_sh_degree
         self.iteration = 0
+        # torch.optim.Adam keeps one step count PER PARAMETER and skips parameters without a gradient.  In the reference
+        # the six Gaussian groups share a count that stalls on densification iterations, opacity additionally stalls
+        # on reset iterations (train.py:317-332), and c has its own optimizer that steps on event iterations only
+        # (train.py:71-73,210-212).
+        self.steps = {"gauss": 0, "opacity": 0, "c": 0}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.track_stats = track_densification_stats
@@ -185,10 +190,16 @@ class EventTrainer:
         return self.N
 
     def reset_opacity(self):
-        from . import densify
-        groups = self.export_groups()
-        densify.reset_opacity(groups)
-        self.import_groups(groups)
+        """scene/gaussian_model.py:210-213 + replace_tensor_to_optimizer (:258-271): opacity = logit(min(sigmoid, 0.01)),
+        its Adam moments zeroed -- in place on the opacity segment (the other groups, their moments and this
+        iteration's gradients stay, as in the reference, where only the opacity parameter is replaced)."""
+        self.sync_features()
+        o = self.views["opacity"]
+        x = torch.min(torch.sigmoid(o), torch.ones_like(o) * 0.01)
+        o.copy_(torch.log(x / (1 - x)))
+        off, n = self.seg["opacity"]
+        self.exp_avg[off:off + n].zero_()
+        self.exp_avg_sq[off:off + n].zero_()
 
     # ---- raster settings for one view (gaussian_renderer/__init__.py:35-51)
     @staticmethod
@@ -228,20 +239,39 @@ class EventTrainer:
         (the instance count)."""
         scalars = self.compute_gradients(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur)
         self.apply_update(sync_grads)
-        return scalars
+        return scalars.clone()        # compute_gradients' result lives in a buffer the next step overwrites
 
-    def apply_update(self, sync_grads=True):
-        """Gradient averaging over the ranks (if any) + Adam (train.py:330-332) for the iteration whose gradients
-        compute_gradients() left in the flat buffer."""
+    def apply_update(self, sync_grads=True, skip=()):
+        """Gradient averaging over the ranks (if any) + Adam (train.py:210-212,330-332) for the iteration whose gradients
+        compute_gradients() left in the flat buffer.  `skip` names what torch would leave untouched this iteration:
+        "gaussians" (all six groups: a densification iteration or the last iteration), "opacity" (a reset iteration),
+        "c" (an iteration without the event loss)."""
         self.iteration += 1
         it = self.iteration
+        skip = set(skip)
+        if "gaussians" in skip:
+            skip.add("opacity")
+        st = {}
+        for name, key in (("gauss", "gaussians"), ("opacity", "opacity"), ("c", "c")):
+            if key in skip:
+                st[name] = 0
+            else:
+                self.steps[name] += 1
+                st[name] = self.steps[name]
         dist_on = self.world > 1 and sync_grads
-        if self.overlap_features or self.factorize_sh:
-            self._update_overlapped(it, dist_on)
+        if "gaussians" in skip:
+            if st["c"]:
+                if dist_on:
+                    parallel.allreduce_mean_(self.c_grad, self.pg)
+                so, sn = self.seg["c"]
+                self._adam_range(so, sn, self.c_lr, st["c"], eps=1e-8)
+            self._packed_views = 0
+        elif self.overlap_features or self.factorize_sh:
+            self._update_overlapped(it, dist_on, st)
         elif dist_on:
-            self._allreduce_and_adam(it)                           # 59 floats/Gaussian + c, pipelined with Adam
+            self._allreduce_and_adam(it, st)                       # 59 floats/Gaussian + c, pipelined with Adam
         else:
-            self._adam(it)
+            self._adam(it, st)
 
     def sync_features(self):
         """Make the current stream wait for the SH-coefficient update still running on the side stream (call before
@@ -250,7 +280,7 @@ class EventTrainer:
             torch.cuda.current_stream(self.device).wait_event(self._feat_event)
             self._feat_event = None
 
-    def _update_overlapped(self, it, dist_on):
+    def _update_overlapped(self, it, dist_on, st):
         """xyz / opacity / scaling / rotation / c: mean over the ranks + Adam on the main stream.  SH coefficients:
         exchange (factorised: all-gather of the per-view colour gradients + local rebuild; otherwise chunked mean of
         the SH gradient) + Adam, on the side stream when overlap_features is set, else on the main stream."""
@@ -283,7 +313,7 @@ class EventTrainer:
         for c, p in pend_small:
             if p is not None:
                 p.wait()
-            self._adam_chunk(c, it)
+            self._adam_chunk(c, it, st)
         with torch.cuda.stream(side):
             if fact:
                 if gather is not None:
@@ -295,17 +325,19 @@ class EventTrainer:
                                                planar=True)
                 self._packed_views = 0
                 for c in feats:
-                    self._adam_chunk(c, it)
+                    self._adam_chunk(c, it, st)
             else:
                 for c, p in pend_feat:
                     if p is not None:
                         p.wait()
-                    self._adam_chunk(c, it)
+                    self._adam_chunk(c, it, st)
             if self.overlap_features:
                 self._feat_event = side.record_event()
 
     def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None):
-        """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer."""
+        """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer.
+        The returned scalars tensor, `last_scalars` and `last_radii` are VIEWS of persistent buffers that the next
+        iteration overwrites (step() / step_image() return clones)."""
         if self._counts is None:
             self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
         v = self.views
@@ -370,38 +402,40 @@ class EventTrainer:
         chunks.append(("tail", t_off, self.flat.numel() - t_off))
         return chunks
 
-    def _allreduce_and_adam(self, it):
+    def _allreduce_and_adam(self, it, st):
         chunks = self._comm_chunks()
         pend = [parallel.allreduce_mean_async_(self.flat_grad[off:off + n], self.pg) for _, off, n in chunks]
         for c, p in zip(chunks, pend):
             p.wait()
-            self._adam_chunk(c, it)
+            self._adam_chunk(c, it, st)
 
-    def _adam_chunk(self, chunk, it):
+    def _adam_chunk(self, chunk, it, st):
         kind, off, n = chunk
         f_off, _ = self.seg["features"]
         if kind == "xyz":
-            self._adam_range(off, n, self.xyz_lr(it), it)
+            self._adam_range(off, n, self.xyz_lr(it), st["gauss"])
         elif kind == "features":
             # f_dc rows (the first 3N elements of the segment) use feature_lr, everything after feature_lr / 20
             dc_left = max(0, f_off + 3 * self.N - off)
             if dc_left > 0:
-                self._adam_range(off, n, self.lrs["features"], it, lr_b=self.lrs["features_rest"], period=n,
+                self._adam_range(off, n, self.lrs["features"], st["gauss"], lr_b=self.lrs["features_rest"], period=n,
                                  split=min(dc_left, n))
             else:
-                self._adam_range(off, n, self.lrs["features_rest"], it)
+                self._adam_range(off, n, self.lrs["features_rest"], st["gauss"])
         else:
             for name in ("opacity", "scaling", "rotation"):
                 so, sn = self.seg[name]
-                self._adam_range(so, sn, self.lrs[name], it)
+                self._adam_range(so, sn, self.lrs[name], st["opacity" if name == "opacity" else "gauss"])
             so, sn = self.seg["c"]
-            self._adam_range(so, sn, self.c_lr, it, eps=1e-8)
+            self._adam_range(so, sn, self.c_lr, st["c"], eps=1e-8)
 
-    def _adam_range(self, off, n, lr, it, eps=1e-15, **kw):
+    def _adam_range(self, off, n, lr, step, eps=1e-15, **kw):
+        if step <= 0:               # a group without a gradient this iteration: torch leaves it untouched
+            return
         sl = slice(off, off + n)
-        losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, it, eps=eps, **kw)
+        losses.adam_step_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, step, eps=eps, **kw)
 
-    def _adam(self, it):
+    def _adam(self, it, st=None):
         """All groups in one launch: the flat buffer is xyz | f_dc | f_rest | opacity | scaling | rotation | c."""
         N = self.N
         f_off, f_n = self.seg["features"]
@@ -410,7 +444,12 @@ class EventTrainer:
         lrs = (self.xyz_lr(it), self.lrs["features"], self.lrs["features_rest"], self.lrs["opacity"], self.lrs["scaling"],
                self.lrs["rotation"], self.c_lr)
         eps = (1e-15,) * 6 + (1e-8,)           # scene/gaussian_model.py:163; torch.optim.Adam([c], lr=0.1) train.py:73
-        losses.adam_step_segments_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, ends, lrs, eps, it)
+        if st is None:
+            steps = it
+        else:
+            g, o, c = st["gauss"], st["opacity"], st["c"]
+            steps = g if (g == o == c) else (g, g, g, o, g, g, c)
+        losses.adam_step_segments_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, ends, lrs, eps, steps)
 
     # ------------------------------------------------------------------ the other two training modes of train.py
     def step_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2, sync_grads=True):
@@ -420,8 +459,8 @@ class EventTrainer:
         if mode not in ("gray", "rgb"):
             raise ValueError("mode must be 'gray' or 'rgb'")
         loss = self.compute_gradients_image(cam, gt_image, bg, mode, lambda_dssim)
-        self.apply_update(sync_grads)
-        return loss
+        self.apply_update(sync_grads, skip=("c",))     # optimizer_c only steps on event iterations (train.py:210-212)
+        return loss.clone()
 
     def compute_gradients_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):
         if self._counts is None:
@@ -482,7 +521,8 @@ class EventTrainer:
         loss.backward()
         for k, v in leaves.items():
             self.grads[k].copy_(v.grad)
-        self._adam(it)
+        self.steps["gauss"] += 1; self.steps["opacity"] += 1
+        self._adam(it, {"gauss": self.steps["gauss"], "opacity": self.steps["opacity"], "c": 0})
         return loss.detach()
 
     # ------------------------------------------------------------------ reference-style path (autograd)
@@ -509,5 +549,7 @@ class EventTrainer:
         for k, v in leaves.items():
             self.grads[k].copy_(v.grad)
         self.c_grad.copy_(c.grad)
-        self._adam(it)
+        for k in self.steps:
+            self.steps[k] += 1
+        self._adam(it, dict(self.steps))
         return loss

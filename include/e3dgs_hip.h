@@ -415,6 +415,17 @@ int e3dgs_adam_step_segments(size_t n, float* param, const float* grad, float* e
                              void* stream);
 
 /*
+ * As above with ONE STEP COUNT PER GROUP (host array steps[nseg]).  torch.optim.Adam keeps `step` per parameter and skips
+ * parameters whose .grad is None: in the reference that happens to all six Gaussian groups on every densification
+ * iteration (train.py:317-332 replaces the parameters before optimizer.step()) and to the opacity group on reset
+ * iterations (scene/gaussian_model.py:210-213,258-271), so the groups' bias corrections drift apart.  steps[k] <= 0
+ * skips group k: parameter and both moments stay untouched.
+ */
+int e3dgs_adam_step_groups(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int nseg,
+                           const size_t* seg_end, const float* lr, const float* eps, float beta1, float beta2,
+                           const int* steps, void* stream);
+
+/*
  * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * Slots: 0 preprocess, 1 sort_depth, 2 scan_emit, 3 sort_tile, 4 tile_ranges, 5 render_fwd,
  *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set

@@ -306,3 +306,20 @@ def look_at_camera(eye, target, up, fovx, width, height, znear=0.01, zfar=100.0,
     proj = (view.unsqueeze(0).bmm(Pj.transpose(0, 1).unsqueeze(0))).squeeze(0)
     campos = view.inverse()[3, :3].contiguous()
     return view.to(dtype), proj.to(dtype), campos.to(dtype), tx, ty
+
+
+def psnr(img1, img2):
+    """utils/image_utils.py:19-21"""
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def eval_gray_psnr(render_fn, cameras_with_gt, index_list=(5, 25, 45, 65, 85)):
+    """eval.py:118-152 (the PSNR half): clamp, rgb_to_grayscale on render and ground truth, mean over the held-out views.
+    `cameras_with_gt`: list of (camera, gt (3,H,W) CPU tensor)."""
+    total = 0.0
+    for index in index_list:
+        cam, gt = cameras_with_gt[index]
+        img = to_gray(torch.clamp(render_fn(cam), 0.0, 1.0))
+        total += float(psnr(img, to_gray(torch.clamp(gt, 0.0, 1.0))).mean())
+    return total / len(index_list)
