@@ -100,8 +100,10 @@ def window_parity(trainer, cam, bg, tile_rows, grad_seed=7):
 def assert_window_parity(res, grad_l2=1e-3, grad_pg=1e-3):
     assert res["radii_equal"], "radii differ from the oracle"
     assert res["image_max_abs"] == 0.0, res["image_max_abs"]            # bit-exact forward (DESIGN: arithmetic contract)
-    assert res["final_T_equal"] and res["n_contrib_equal"]
+    assert res["final_T_equal"]
     assert res["hip_instances"] <= res["oracle_instances"]                 # exact tile culling only ever drops instances
+    if res["hip_instances"] == res["oracle_instances"]:                    # n_contrib counts list POSITIONS: equal lists only
+        assert res["n_contrib_equal"]
     for name, (l2, pg) in res["grad"].items():
         assert l2 <= grad_l2, (name, "rel L2", l2)
         assert pg <= grad_pg, (name, "per-Gaussian", pg)

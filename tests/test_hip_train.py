@@ -615,3 +615,75 @@ def test_segmented_adam_equals_per_group_adam():
         assert torch.equal(x, y)
     with pytest.raises(_lib.HipLibraryError, match="last segment"):
         losses.adam_step_segments_(a[0], grad, a[1], a[2], ends[:-1], lrs[:-1], eps[:-1], 1)
+
+
+def test_event_mask_on_quantised_ground_truth_matches_torch():
+    """rho = count(D* != 0) and sign(D - D*) hinge on exact zeros: on 8-bit ground-truth frames the kernel's mask must be
+    the torch formula's (utils/loss_utils.py:234-249 + train.py:165-175), pixel for pixel in the count."""
+    from event_3dgs_amd import losses
+    from oracle import torch_oracle
+    g = torch.Generator().manual_seed(5)
+    H, W = 96, 160
+    q8 = lambda t: torch.round(t.clamp(0, 1) * 255) / 255
+    gt_now = q8(torch.rand(3, H, W, generator=g))
+    gt_next = gt_now.clone()
+    changed = torch.rand(H, W, generator=g) < 0.3                    # 30 % of the pixels see an event
+    gt_next[:, changed] = q8(torch.rand(3, int(changed.sum()), generator=g))
+    # a few pixels whose channels change but whose luminance may not (ties the float formula has to reproduce)
+    gt_next[0, :2, :8] = gt_now[0, :2, :8] + 1.0 / 255
+    gt_int = q8(torch.rand(3, H, W, generator=g))
+    imgs = [torch.rand(3, H, W, generator=g) * 0.9 + 0.05 for _ in range(3)]
+    c = torch.tensor([0.21])
+    ref_gt = torch_oracle.event_frame(gt_now, gt_next, 0.17)
+    rho_ref = float((ref_gt != 0).float().mean())
+    sc, *_ = losses.event_loss_raw(*(t.to(DEV) for t in imgs), c.to(DEV), gt_int.to(DEV), gt_now.to(DEV), gt_next.to(DEV), None)
+    assert abs(float(sc[2]) * H * W - rho_ref * H * W) < 0.5, (float(sc[2]), rho_ref)     # identical COUNT
+    ref = torch_oracle.event_iteration_loss(imgs[0], imgs[1], imgs[2], gt_int, gt_now, gt_next, float(c))
+    assert abs(float(sc[0]) - float(ref)) <= 2e-6 * abs(float(ref))
+
+
+def test_apply_update_skips_like_torch_adam():
+    """train.py:317-332: densification / opacity reset replace parameters BEFORE optimizer.step(), so torch skips them
+    (their .grad is None) and their per-parameter step count stalls; optimizer_c steps on event iterations only.
+    Emulated here with torch.optim.Adam on copies of the flat segments."""
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene(N=1500, W=96, H=64)
+    bg = torch.zeros(3, device=DEV)
+    gts = _gts(params, cams, bg)
+    tr = EventTrainer(params, DEV)
+    names = ("xyz", "features", "opacity", "scaling", "rotation", "c")
+    seg = lambda buf, n: buf[tr.seg[n][0]:tr.seg[n][0] + tr.seg[n][1]]
+    ref = {n: torch.nn.Parameter(seg(tr.flat, n).clone()) for n in names}
+    N = tr.N
+    lr_feat = torch.full((48 * N,), tr.lrs["features_rest"], device=DEV)
+    lr_feat[:3 * N] = tr.lrs["features"]
+    plan = [(), ("gaussians",), ("opacity",), ("c",), ()]
+    steps = {n: 0 for n in names}
+    m = {n: torch.zeros_like(ref[n]) for n in names}
+    v = {n: torch.zeros_like(ref[n]) for n in names}
+    for it, skip in enumerate(plan, start=1):
+        tr.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
+        grads = {n: seg(tr.flat_grad, n).clone() for n in names}
+        tr.apply_update(skip=skip)
+        for n in names:
+            if n == "c":
+                skipped = "c" in skip
+            else:
+                skipped = "gaussians" in skip or (n == "opacity" and "opacity" in skip)
+            if skipped:
+                continue
+            steps[n] += 1
+            lr = {"xyz": tr.xyz_lr(it), "features": lr_feat, "c": tr.c_lr}.get(n, tr.lrs.get(n))
+            eps = 1e-8 if n == "c" else 1e-15
+            g_ = grads[n].double()
+            m[n] = (0.9 * m[n].double() + 0.1 * g_).float()
+            v[n] = (0.999 * v[n].double() + 0.001 * g_ * g_).float()
+            bc1, bc2 = 1 - 0.9 ** steps[n], 1 - 0.999 ** steps[n]
+            upd = (m[n].double() / bc1) / ((v[n].double() / bc2).sqrt() + eps)
+            ref[n].data = (ref[n].data.double() - (lr if torch.is_tensor(lr) else float(lr)) * upd).float()
+    torch.cuda.synchronize()
+    assert tr.steps == {"gauss": 4, "opacity": 3, "c": 4}
+    for n in names:
+        a, b = seg(tr.flat, n), ref[n].data
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), n
+        assert rel_l2(seg(tr.exp_avg, n).cpu().numpy(), m[n].cpu().numpy()) <= 1e-6, n
