@@ -12,7 +12,9 @@ OUT = os.path.join(HERE, "libe3dgs_hip.so")
 SOURCES = ["capi.hip", "forward.hip", "backward.hip", "scan_sort.hip", "aux.hip", "densify.hip"]
 # -ffp-contract=off is part of the arithmetic contract (bit-exact forward vs the oracle):
 # only explicit FMA() fuses.  (No float atomics anywhere in the library.)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# -fno-slp-vectorize: the SLP pass pairs scalar fp32 ops into v_pk_* instructions (1.7x the issue cost of one op) and pays
+# for it with v_mov shuffles -- a net loss in the compositing kernels (measured -3 % on render_bwd_kernel).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
 
 
 def build(force=False, verbose=False):

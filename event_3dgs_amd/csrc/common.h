@@ -206,6 +206,8 @@ struct BinningState {
     uint32_t* keys;       // tile ids
     uint32_t* keys_alt;
     uint32_t* emit_gid;   // splat id of each slot (= emission position)                       [read by fwd + bwd]
+    uint8_t* strip_mask;  // per LIST POSITION: bit k = the forward evaluated this entry on the tile's 16x4 pixel strip k
+                          // (written by render_fwd_kernel for the entries it visited, read by render_bwd_kernel)
     uint32_t* scratch;
     static size_t required(size_t I) {
         char* p = nullptr;
@@ -220,6 +222,7 @@ struct BinningState {
         b.keys = carve<uint32_t>(p, n);
         b.keys_alt = carve<uint32_t>(p, n);
         b.emit_gid = carve<uint32_t>(p, n);
+        b.strip_mask = carve<uint8_t>(p, n + 64);
         b.scratch = carve<uint32_t>(p, sort_scratch_words(n));
         return b;
     }

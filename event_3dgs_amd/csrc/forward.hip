@@ -586,19 +586,25 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, const uint2* range
 
 unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
 
-__global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
+#ifndef E3_FWD_WAVES
+#define E3_FWD_WAVES 1
+#endif
+__global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ perm,
     const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work, uint8_t* __restrict__ strip_mask) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
     __shared__ float4 sB[RENDER_WAVES][WAVE];
     __shared__ float4 sC[RENDER_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * RENDER_WAVES + wave;
     if (unit >= ntiles) return;                 // ntiles = launch slots (holes of an XCD-partitioned order hold ~0u)
-    const int tile = (int)order[unit];          // global tile id: view * tiles_per_view + local tile
+    // (wave-uniform values are made scalar explicitly: the compiler cannot see that `wave` is uniform, and a loop whose
+    // trip count sits in a VGPR is compiled as a divergent loop -- exec-mask bookkeeping per iteration, and every
+    // scalar the loop carries copied to VGPRs at the latch)
+    const int tile = __builtin_amdgcn_readfirstlane((int)order[unit]);   // global tile id: view * tiles_per_view + local tile
     if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     int processed = 0;
@@ -619,7 +625,8 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
         T[k] = inside[k] ? 1.0f : -1.0f;
         C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
     }
-    const uint2 range = ranges[tile];
+    uint2 range = ranges[tile];
+    range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
     const int n = (int)(range.y - range.x);
     int live_strips = 0;      // wave-uniform (SALU): (entry, 16x4 strip) pairs that were evaluated
 
@@ -645,6 +652,11 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
         }
         if (base + 2 * WAVE + lane < n) id_next = emit_gid[e_next2];
         if (base + 3 * WAVE + lane < n) e_next2 = perm[range.x + base + 3 * WAVE + lane];
+        // Which 16x4 strips evaluated which entry lets the backward walk skip its own per-strip liveness tests (and
+        // whole entries): an entry that reached no pixel of a strip here (all its pixels finished, or below 1/255)
+        // composited nothing there.  Bit j of sm[k] (an SGPR pair per strip) = entry j of this round evaluated strip k:
+        // one scalar bit-set per evaluated strip, and one byte per entry stored per round.
+        unsigned long long sm[4] = {0ull, 0ull, 0ull, 0ull};
         for (int j = 0; j < cnt; ++j) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
@@ -666,6 +678,9 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 const unsigned long long live_mask = __builtin_amdgcn_fcmpf(T[k], 0.0f, 2 /* OGT */) &
                                                      __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
                 if (live_mask != 0ull) {
+#ifndef E3_NO_STRIP_MASK
+                    sm[k] |= 1ull << j;
+#endif
                     live_strips += 2;                    // cost model of tile_work below: an evaluated strip ~ 2 entries
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
@@ -685,6 +700,15 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE) void render_fwd_kernel(
                 }
             }
         }
+#ifndef E3_NO_STRIP_MASK
+        if (lane < cnt) {
+            const uint32_t mine = (__builtin_amdgcn_inverse_ballot_w64(sm[0]) ? 1u : 0u) |
+                                  (__builtin_amdgcn_inverse_ballot_w64(sm[1]) ? 2u : 0u) |
+                                  (__builtin_amdgcn_inverse_ballot_w64(sm[2]) ? 4u : 0u) |
+                                  (__builtin_amdgcn_inverse_ballot_w64(sm[3]) ? 8u : 0u);
+            strip_mask[range.x + base + lane] = (uint8_t)mine;
+        }
+#endif
         wave_sync();
     }
 #pragma unroll
@@ -892,7 +916,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((nslots + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
         g_trace, nslots, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
-        out_color, img.final_T, img.n_contrib, img.work);
+        out_color, img.final_T, img.n_contrib, img.work, bin.strip_mask);
     KERNEL_OK("render_fwd_kernel");
     return 0;
 }
