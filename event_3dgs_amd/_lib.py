@@ -104,6 +104,14 @@ def lib():
     L.e3dgs_adam_step_groups.argtypes = [C.c_size_t] + [_fp] * 4 + [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_float),
                                                                      C.POINTER(C.c_float), C.c_float, C.c_float,
                                                                      C.POINTER(C.c_int), _vp]
+    L.e3dgs_densify_scratch_bytes.restype = C.c_size_t
+    L.e3dgs_densify_scratch_bytes.argtypes = [C.c_int]
+    L.e3dgs_densify_plan.restype = C.c_int
+    L.e3dgs_densify_plan.argtypes = [C.c_int, _fp, _fp, _fp] + [C.c_float] * 4 + [C.c_int, _cp, C.POINTER(C.c_int), _vp]
+    L.e3dgs_densify_split_rows.restype = C.c_void_p
+    L.e3dgs_densify_split_rows.argtypes = [C.c_int, _cp]
+    L.e3dgs_densify_apply.restype = C.c_int
+    L.e3dgs_densify_apply.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)] + [_fp] * 7 + [_cp, _vp]
     L.e3dgs_densify_stats_update.restype = C.c_int
     L.e3dgs_densify_stats_update.argtypes = [C.c_int, _fp, _ip, _fp, _fp, _fp, _vp]
     L.e3dgs_image_loss_scratch_bytes.restype = C.c_size_t
@@ -158,5 +166,5 @@ EXPORTED_SYMBOLS = [
     "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi",
     "e3dgs_sh_grad_from_colour",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
-    "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
+    "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
 ]

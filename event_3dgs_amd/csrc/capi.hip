@@ -60,6 +60,12 @@ size_t e3_image_loss_scratch_bytes(int, int, int);
 int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, float, int, int,
                  hipStream_t);
+size_t e3_densify_scratch_bytes(int);
+int e3_densify_plan_impl(int, const float*, const float*, const float*, float, float, float, float, int, char*, int*,
+                         hipStream_t);
+int e3_densify_apply_impl(int, int, const int*, const float*, const float*, const float*, const float*, float*, float*,
+                          float*, char*, hipStream_t);
+const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
@@ -430,6 +436,29 @@ int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, f
     g_err[0] = 0;
     return e3_adam_impl(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, lr_b, period, split,
                         (hipStream_t)stream);
+}
+
+size_t e3dgs_densify_scratch_bytes(int P) { return e3_densify_scratch_bytes(P); }
+int e3dgs_densify_plan(int P, const float* flat_param, const float* xyz_gradient_accum, const float* denom,
+                       float max_grad, float min_opacity, float extent, float percent_dense, int size_prune, char* scratch,
+                       int* counts_host4, void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || !counts_host4) return e3_fail(hipErrorInvalidValue, "bad arguments");
+    if (P > 0 && (!flat_param || !xyz_gradient_accum || !denom || !scratch)) return e3_fail(hipErrorInvalidValue, "null pointer");
+    return e3_densify_plan_impl(P, flat_param, xyz_gradient_accum, denom, max_grad, min_opacity, extent, percent_dense,
+                                size_prune, scratch, counts_host4, (hipStream_t)stream);
+}
+const int* e3dgs_densify_split_rows(int P, char* scratch) { return e3_densify_split_rows(P, scratch); }
+int e3dgs_densify_apply(int P, int P_new, const int* counts4, const float* param, const float* exp_avg,
+                        const float* exp_avg_sq, const float* samples, float* param_new, float* exp_avg_new,
+                        float* exp_avg_sq_new, char* scratch, void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || P_new < 0 || !counts4) return e3_fail(hipErrorInvalidValue, "bad arguments");
+    if (P > 0 && (!param || !exp_avg || !exp_avg_sq || !param_new || !exp_avg_new || !exp_avg_sq_new || !scratch))
+        return e3_fail(hipErrorInvalidValue, "null pointer");
+    if (counts4[2] > 0 && !samples) return e3_fail(hipErrorInvalidValue, "samples are required when rows are split");
+    return e3_densify_apply_impl(P, P_new, counts4, param, exp_avg, exp_avg_sq, samples, param_new, exp_avg_new,
+                                 exp_avg_sq_new, scratch, (hipStream_t)stream);
 }
 
 extern unsigned long long* g_trace;

@@ -112,14 +112,12 @@ class EventTrainer:
     def _build(self, groups, c_value, c_moments=None):
         """(Re)creates the flat buffers from reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]."""
         N = groups["xyz"][0].shape[0]
-        self.N = N
         # one flat buffer each for parameters / gradients / Adam moments; the last element is the threshold c
         nflat = N * FLOATS_PER_GAUSSIAN + 1
         self.flat = torch.empty(nflat, dtype=torch.float32, device=self.device)
-        self.flat_grad = torch.zeros_like(self.flat)
+        self.flat_grad = None
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.views, self.grads, self.seg = {}, {}, {}
         # features are stored coefficient-major, (16*3, N) (E3DGS_FLAG_SH_PLANAR): rows 0..2 = f_dc, 3..47 = f_rest
         shapes = {"xyz": (N, 3), "features": (48, N), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
 
@@ -133,26 +131,42 @@ class EventTrainer:
         off = 0
         for name, per in SEGMENTS:
             n = N * per
-            self.seg[name] = (off, n)
             self.flat[off:off + n].view(shapes[name]).copy_(src[name])
             if has_m:
                 self.exp_avg[off:off + n].view(shapes[name]).copy_(m_src[name])
                 self.exp_avg_sq[off:off + n].view(shapes[name]).copy_(v_src[name])
+            off += n
+        self.flat[off] = float(c_value)
+        if c_moments is not None:
+            self.exp_avg[off] = c_moments[0]; self.exp_avg_sq[off] = c_moments[1]
+        self._bind(N)
+
+    def _bind(self, N):
+        """Typed views into the flat buffers of N Gaussians + everything else that depends on N."""
+        self.N = N
+        assert self.flat.numel() == N * FLOATS_PER_GAUSSIAN + 1
+        if self.flat_grad is None or self.flat_grad.numel() != self.flat.numel():
+            self.flat_grad = torch.zeros_like(self.flat)
+        self.views, self.grads, self.seg = {}, {}, {}
+        shapes = {"xyz": (N, 3), "features": (48, N), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+        off = 0
+        for name, per in SEGMENTS:
+            n = N * per
+            self.seg[name] = (off, n)
             self.views[name] = self.flat[off:off + n].view(shapes[name])
             self.grads[name] = self.flat_grad[off:off + n].view(shapes[name])
             off += n
         self.seg["c"] = (off, 1)
         self.c = self.flat[off:off + 1]
-        self.c.fill_(float(c_value))
-        if c_moments is not None:
-            self.exp_avg[off] = c_moments[0]; self.exp_avg_sq[off] = c_moments[1]
         self.c_grad = self.flat_grad[off:off + 1]
         # scratch that depends on N
         self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if self.track_stats else None
         self._loss_bufs = None
         self._counts = None
-        # scratch of the rasteriser calls of step(): persistent, grows geometrically (no allocator traffic per step)
-        self._pool = rasterizer.ScratchPool(self.device)
+        # scratch of the rasteriser calls of step(): persistent, grows geometrically (no allocator traffic per step);
+        # it survives densification (the buffers are sized by bytes, not by N)
+        if getattr(self, "_pool", None) is None:
+            self._pool = rasterizer.ScratchPool(self.device)
         self.last_radii = None
         self.last_scalars = None
 
@@ -181,12 +195,46 @@ class EventTrainer:
         self._build(groups, c_value=c_val, c_moments=c_mom)
 
     def densify_and_prune(self, stats, max_grad=0.0002, min_opacity=0.005, extent=1.0, max_screen_size=None,
-                          percent_dense=0.01):
-        """scene/gaussian_model.py:389-403 on the trainer's buffers (densify.py holds the algorithm)."""
-        from . import densify
-        groups = self.export_groups()
-        densify.densify_and_prune(groups, stats, max_grad, min_opacity, extent, max_screen_size, percent_dense)
-        self.import_groups(groups)
+                          percent_dense=0.01, sampler=None):
+        """scene/gaussian_model.py:389-403 on the device (e3dgs_densify_plan / _apply): one plan pass, one pass that
+        compacts parameters and both Adam moments from the old flat buffers into new ones and appends clones and split
+        children; no export / import through the reference layout.  `sampler(stds) -> (2 n_split, 3)` draws the split
+        offsets (default: the reference's torch.normal(zeros, stds) on the device, :358-360).
+        densify.densify_and_prune is the same algorithm in torch on the reference layout (golden-pinned)."""
+        import ctypes as C
+        self.sync_features()
+        L = _lib.lib()
+        N, dev = self.N, self.device
+        scratch = torch.empty(L.e3dgs_densify_scratch_bytes(N), dtype=torch.uint8, device=dev)
+        counts = (C.c_int * 4)()
+        acc, den = stats.xyz_gradient_accum.contiguous(), stats.denom.contiguous()
+        with torch.cuda.device(dev):
+            rc = L.e3dgs_densify_plan(N, _lib.ptr(self.flat), _lib.ptr(acc), _lib.ptr(den), float(max_grad),
+                                      float(min_opacity), float(extent), float(percent_dense),
+                                      1 if max_screen_size else 0, _lib.ptr(scratch), counts, _lib.current_stream())
+        _lib.check(rc, "e3dgs_densify_plan")
+        n_orig, n_clone, n_split, n_child = (int(c) for c in counts)
+        M = n_orig + n_clone + 2 * n_child
+        samples = None
+        if n_split:
+            off = L.e3dgs_densify_split_rows(N, _lib.ptr(scratch)) - scratch.data_ptr()
+            rows = scratch[off:off + 4 * n_split].view(torch.int32).long()
+            stds = torch.exp(self.views["scaling"].index_select(0, rows)).repeat(2, 1)
+            if sampler is None:
+                samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+            else:
+                samples = sampler(stds).to(device=dev, dtype=torch.float32)
+            samples = samples.contiguous()
+        new = [torch.empty(M * FLOATS_PER_GAUSSIAN + 1, dtype=torch.float32, device=dev) for _ in range(3)]
+        with torch.cuda.device(dev):
+            rc = L.e3dgs_densify_apply(N, M, counts, _lib.ptr(self.flat), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                       _lib.ptr(samples), _lib.ptr(new[0]), _lib.ptr(new[1]), _lib.ptr(new[2]),
+                                       _lib.ptr(scratch), _lib.current_stream())
+        _lib.check(rc, "e3dgs_densify_apply")
+        self.flat, self.exp_avg, self.exp_avg_sq = new
+        self.flat_grad = None
+        self._bind(M)
+        stats._zero(M, dev)                      # densification_postfix (:329-347) zeroes all three statistics
         return self.N
 
     def reset_opacity(self):

@@ -426,6 +426,33 @@ int e3dgs_adam_step_groups(size_t n, float* param, const float* grad, float* exp
                            const int* steps, void* stream);
 
 /*
+ * Adaptive density control on the device: GaussianModel.densify_and_prune (scene/gaussian_model.py:389-403 = clone
+ * :374-387 + split :349-372 + prune :273-305,396-402; schedule train.py:317-327) as ONE plan pass and ONE apply pass over
+ * the flat training buffers -- parameters and both Adam moments compacted together, clones and split children appended
+ * in the reference's row order [kept originals | kept clones | kept first children | kept second children], new rows
+ * with zero moments.  Flat buffer of P Gaussians (floats): xyz 3P | SH coefficient-major (48, P) | opacity P |
+ * scaling 3P | rotation 4P | c 1  (pre-activation values, scene/gaussian_model.py:44-59).
+ *
+ *   plan:  decisions + exclusive scans; ONE host wait; counts_host4 = {kept originals, kept clones, rows selected for
+ *          the split, split rows whose children are kept}.  New size = counts[0] + counts[1] + 2 * counts[3].
+ *          size_prune != 0 applies the world-space size test (max scale > 0.1 extent, :399); the screen-space half of
+ *          that test reads max_radii2D AFTER the postfix zeroed it (:347) and can never fire, as in the reference.
+ *   split_rows: device pointer (inside `scratch`) to the int32 indices of the counts[2] selected rows, ascending --
+ *          the caller draws the split offsets for them (torch.normal(0, exp(scaling[rows]).repeat(2, 1)), :358-360) so
+ *          that the random stream stays torch's.
+ *   apply: writes the three new flat buffers (P_new Gaussians).  samples: (2 * counts[2], 3) float32, row j and
+ *          counts[2] + j belong to the j-th selected row.
+ */
+size_t e3dgs_densify_scratch_bytes(int P);
+int e3dgs_densify_plan(int P, const float* flat_param, const float* xyz_gradient_accum, const float* denom,
+                       float max_grad, float min_opacity, float extent, float percent_dense, int size_prune, char* scratch,
+                       int* counts_host4, void* stream);
+const int* e3dgs_densify_split_rows(int P, char* scratch);
+int e3dgs_densify_apply(int P, int P_new, const int* counts4, const float* param, const float* exp_avg,
+                        const float* exp_avg_sq, const float* samples, float* param_new, float* exp_avg_new,
+                        float* exp_avg_sq_new, char* scratch, void* stream);
+
+/*
  * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * Slots: 0 preprocess, 1 sort_depth, 2 scan_emit, 3 sort_tile, 4 tile_ranges, 5 render_fwd,
  *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set

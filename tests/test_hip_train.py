@@ -687,3 +687,98 @@ def test_apply_update_skips_like_torch_adam():
         a, b = seg(tr.flat, n), ref[n].data
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), n
         assert rel_l2(seg(tr.exp_avg, n).cpu().numpy(), m[n].cpu().numpy()) <= 1e-6, n
+
+
+def _trainer_from_groups(groups, c=0.17):
+    from event_3dgs_amd.train_step import EventTrainer
+    params = {"xyz": groups["xyz"][0], "features_dc": groups["f_dc"][0], "features_rest": groups["f_rest"][0],
+              "opacity": groups["opacity"][0], "scaling": groups["scaling"][0], "rotation": groups["rotation"][0]}
+    tr = EventTrainer({k: v.to(DEV) for k, v in params.items()}, DEV, c_init=c)
+    tr._build({k: [t.to(DEV) for t in v] for k, v in groups.items()}, c_value=c, c_moments=(0.25, 0.5))
+    return tr
+
+
+def test_g8_densification_golden_replayed_on_the_device():
+    """Golden G8 (the reference's own GaussianModel.densify_and_prune, tests/golden/make_golden.py) through the HIP
+    plan / apply kernels: same rows, same order, same parameters, Adam moments and statistics."""
+    from event_3dgs_amd import densify
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    g = np.load(os.path.join(GOLDEN, "densify.npz"))
+    groups = {n: [torch.tensor(g[f"in_{n}"]), torch.tensor(g[f"in_{n}_m"]), torch.tensor(g[f"in_{n}_v"])] for n in names}
+    tr = _trainer_from_groups(groups)
+    stats = densify.DensifyStats(256, DEV)
+    stats.xyz_gradient_accum = torch.tensor(g["in_accum"]).to(DEV)
+    stats.denom = torch.tensor(g["in_denom"]).to(DEV)
+    stats.max_radii2D = torch.tensor(g["in_maxr"]).to(DEV)
+    max_grad, min_opacity, extent, max_screen, pdense = (float(v) for v in g["args"])
+
+    def cpu_sampler(stds):                       # the golden run drew the split offsets from torch's CPU generator
+        torch.manual_seed(77)
+        stds = stds.cpu()
+        return torch.normal(mean=torch.zeros((stds.size(0), 3)), std=stds)
+    n = tr.densify_and_prune(stats, max_grad, min_opacity, extent, max_screen, pdense, sampler=cpu_sampler)
+    assert n == g["out_xyz"].shape[0] and n != 256
+    out = tr.export_groups()
+    for name in names:
+        for j, suf in enumerate(("", "_m", "_v")):
+            ref = g[f"out_{name}{suf}"]
+            got = out[name][j].cpu().numpy()
+            assert got.shape == ref.shape, (name, suf)
+            assert np.allclose(got, ref, rtol=2e-6, atol=1e-7), (name, suf, np.abs(got - ref).max())
+    assert np.array_equal(stats.xyz_gradient_accum.cpu().numpy(), g["out_accum"])
+    assert np.array_equal(stats.denom.cpu().numpy(), g["out_denom"])
+    assert np.array_equal(stats.max_radii2D.cpu().numpy(), g["out_maxr"])
+    off, _ = tr.seg["c"]
+    assert abs(float(tr.c) - 0.17) < 1e-7 and float(tr.exp_avg[off]) == 0.25 and float(tr.exp_avg_sq[off]) == 0.5
+    tr.reset_opacity()
+    out = tr.export_groups()
+    assert np.allclose(out["opacity"][0].cpu().numpy(), g["reset_opacity"], rtol=2e-6, atol=1e-7)
+    assert float(out["opacity"][1].abs().sum()) == 0.0
+    assert np.allclose(out["xyz"][1].cpu().numpy(), g["reset_xyz_m"])
+
+
+@pytest.mark.parametrize("size_prune", [None, 20])
+def test_device_densification_equals_the_torch_form(size_prune):
+    """50 k Gaussians with trained-looking statistics: the kernels against densify.densify_and_prune (the golden-pinned
+    torch form) on the exported groups, fed the same split noise."""
+    from event_3dgs_amd import densify
+    from event_3dgs_amd.train_step import EventTrainer
+    params, _ = _scene(N=50_000)
+    tr = EventTrainer(params, DEV)
+    g = torch.Generator().manual_seed(4)
+    tr.exp_avg.copy_(torch.randn(tr.flat.shape, generator=g)); tr.exp_avg_sq.copy_(torch.rand(tr.flat.shape, generator=g))
+    N = tr.N
+    mk = lambda: densify.DensifyStats(N, DEV)
+    sa, sb = mk(), mk()
+    den = torch.randint(0, 5, (N, 1), generator=g).float()
+    acc = torch.rand(N, 1, generator=g) * 6e-4 * den
+    for s in (sa, sb):
+        s.xyz_gradient_accum = acc.to(DEV).clone(); s.denom = den.to(DEV).clone()
+    extent = 2.0                                  # percent_dense * extent = 0.02: about half of the selected rows split
+    groups = tr.export_groups()
+    noise = {}
+
+    def sampler(stds):
+        noise["z"] = torch.normal(mean=torch.zeros((stds.size(0), 3), device=DEV), std=stds)
+        return noise["z"]
+    n_dev = tr.densify_and_prune(sa, 0.0002, 0.005, extent, size_prune, 0.01, sampler=sampler)
+    real_normal = torch.normal
+    try:
+        torch.normal = lambda mean, std: noise["z"]          # the torch form draws inside; hand it the same numbers
+        n_ref = densify.densify_and_prune(groups, sb, 0.0002, 0.005, extent, size_prune, 0.01)
+    finally:
+        torch.normal = real_normal
+    assert n_dev == n_ref and n_dev != N and noise["z"].shape[0] > 100
+    out = tr.export_groups()
+    for name in groups:
+        for j in range(3):
+            a, b = out[name][j], groups[name][j]
+            assert a.shape == b.shape, name
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (name, j, float((a - b).abs().max()))
+    assert torch.equal(sa.denom, sb.denom) and sa.max_radii2D.shape == (n_dev,)
+    # and the trainer keeps training on the new buffers
+    cams = _scene(N=10)[1]
+    bg = torch.zeros(3, device=DEV)
+    gts = [tr.render_raw(c, bg)["color"].clone() for c in cams]
+    sc = tr.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
+    assert torch.isfinite(sc).all() and torch.isfinite(tr.flat).all()
