@@ -539,6 +539,25 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
                      C3[4] * 8.0f * xz);
                 term(14, C3[5] * z * (xx - yy), C3[5] * 2.0f * xz, C3[5] * -2.0f * yz, C3[5] * (xx - yy));
                 term(15, C3[6] * x * (xx - 3.0f * yy), C3[6] * (3.0f * xx - 3.0f * yy), C3[6] * -6.0f * xy, 0.0f);
+                if (D > 3) {     // utils/sh_utils.py:97-110: partial derivatives of the polynomials as written there
+                    const float C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
+                                         -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
+                                         0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
+                    term(16, C4[0] * xy * (xx - yy), C4[0] * y * (3.0f * xx - yy), C4[0] * x * (xx - 3.0f * yy), 0.0f);
+                    term(17, C4[1] * yz * (3.0f * xx - yy), C4[1] * 6.0f * xy * z, C4[1] * z * (3.0f * xx - 3.0f * yy),
+                         C4[1] * y * (3.0f * xx - yy));
+                    term(18, C4[2] * xy * (7.0f * zz - 1.0f), C4[2] * y * (7.0f * zz - 1.0f), C4[2] * x * (7.0f * zz - 1.0f),
+                         C4[2] * 14.0f * xy * z);
+                    term(19, C4[3] * yz * (7.0f * zz - 3.0f), 0.0f, C4[3] * z * (7.0f * zz - 3.0f), C4[3] * y * (21.0f * zz - 3.0f));
+                    term(20, C4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f), 0.0f, 0.0f, C4[4] * z * (140.0f * zz - 60.0f));
+                    term(21, C4[5] * xz * (7.0f * zz - 3.0f), C4[5] * z * (7.0f * zz - 3.0f), 0.0f, C4[5] * x * (21.0f * zz - 3.0f));
+                    term(22, C4[6] * (xx - yy) * (7.0f * zz - 1.0f), C4[6] * 2.0f * x * (7.0f * zz - 1.0f),
+                         C4[6] * -2.0f * y * (7.0f * zz - 1.0f), C4[6] * 14.0f * z * (xx - yy));
+                    term(23, C4[7] * xz * (xx - 3.0f * yy), C4[7] * z * (3.0f * xx - 3.0f * yy), C4[7] * -6.0f * xy * z,
+                         C4[7] * x * (xx - 3.0f * yy));
+                    term(24, C4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy)), C4[8] * x * (4.0f * xx - 12.0f * yy),
+                         C4[8] * y * (4.0f * yy - 12.0f * xx), 0.0f);
+                }
             }
         }
     }

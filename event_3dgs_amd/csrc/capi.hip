@@ -98,16 +98,20 @@ static int make_batch(int nviews, int P, const float* const* viewmatrix, const f
     return 0;
 }
 
+// max_degree: 4 for the single-view operator (utils/sh_utils.py:57-112 goes that far), 3 for the several-views-in-one-pass
+// entry points (their per-Gaussian backward keeps 16 coefficients per channel; the trainer's layout is 16 too)
 static int check_forward_args(int P, int D, int M, int width, int height, const float* shs, const float* colors_precomp,
-                              const float* scales, const float* rotations, const float* cov3D_precomp, int flags) {
+                              const float* scales, const float* rotations, const float* cov3D_precomp, int flags,
+                              int max_degree = 4) {
     if (P < 0 || width <= 0 || height <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
     if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
         return e3_fail(hipErrorInvalidValue, "provide exactly one of shs / colors_precomp");
     if (((scales == nullptr || rotations == nullptr) == (cov3D_precomp == nullptr)) && P > 0)
         return e3_fail(hipErrorInvalidValue, "provide exactly one of scales+rotations / cov3D_precomp");
     if ((flags & E3_FLAG_PREACT) && cov3D_precomp) return e3_fail(hipErrorInvalidValue, "PREACT needs scales+rotations");
-    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1)))
-        return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
+    if (shs && (D < 0 || D > max_degree || M < (D + 1) * (D + 1)))
+        return e3_fail(hipErrorInvalidValue, max_degree == 4 ? "SH degree must be 0..4 and M >= (D+1)^2"
+                                                             : "SH degree must be 0..3 and M >= (D+1)^2");
     if ((width + 15) / 16 > 65535 || (height + 15) / 16 > 65535)
         return e3_fail(hipErrorInvalidValue, "image too large for 16-bit tile coordinates");
     return 0;
@@ -236,7 +240,7 @@ int e3dgs_rasterize_forward_multi(e3dgs_alloc_fn geom_alloc, void* geom_user, e3
                                   const float* tan_fovy, float* out_color, int* radii, int debug, int flags,
                                   int* num_rendered_host, void* stream) {
     g_err[0] = 0;
-    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags, 3);
     if (rc) return rc;
     ViewBatch vb;
     rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
@@ -256,7 +260,7 @@ int e3dgs_rasterize_forward_multi_begin(e3dgs_alloc_fn geom_alloc, void* geom_us
                                         const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy,
                                         int* radii, int debug, int flags, int* num_rendered_host, void* stream) {
     g_err[0] = 0;
-    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags);
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags, 3);
     if (rc) return rc;
     ViewBatch vb;
     rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);

@@ -53,6 +53,20 @@ __device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, s
                     r = FMA(C34 * x * (FMA(4.0f, zz, -xx) - yy), sh[(size_t)(13 * 3 + ch) * st], r);
                     r = FMA(C35 * z * (xx - yy), sh[(size_t)(14 * 3 + ch) * st], r);
                     r = FMA(C36 * x * FMA(-3.0f, yy, xx), sh[(size_t)(15 * 3 + ch) * st], r);
+                    if (D > 3) {     // utils/sh_utils.py:97-110 (25 coefficients)
+                        const float C40 = 2.5033429417967046f, C41 = -1.7701307697799304f, C42 = 0.9461746957575601f,
+                                    C43 = -0.6690465435572892f, C44 = 0.10578554691520431f, C45 = -0.6690465435572892f,
+                                    C46 = 0.47308734787878004f, C47 = -1.7701307697799304f, C48 = 0.6258357354491761f;
+                        r = FMA(C40 * xy * (xx - yy), sh[(size_t)(16 * 3 + ch) * st], r);
+                        r = FMA(C41 * yz * FMA(3.0f, xx, -yy), sh[(size_t)(17 * 3 + ch) * st], r);
+                        r = FMA(C42 * xy * FMA(7.0f, zz, -1.0f), sh[(size_t)(18 * 3 + ch) * st], r);
+                        r = FMA(C43 * yz * FMA(7.0f, zz, -3.0f), sh[(size_t)(19 * 3 + ch) * st], r);
+                        r = FMA(C44 * FMA(zz, FMA(35.0f, zz, -30.0f), 3.0f), sh[(size_t)(20 * 3 + ch) * st], r);
+                        r = FMA(C45 * xz * FMA(7.0f, zz, -3.0f), sh[(size_t)(21 * 3 + ch) * st], r);
+                        r = FMA(C46 * (xx - yy) * FMA(7.0f, zz, -1.0f), sh[(size_t)(22 * 3 + ch) * st], r);
+                        r = FMA(C47 * xz * FMA(-3.0f, yy, xx), sh[(size_t)(23 * 3 + ch) * st], r);
+                        r = FMA(C48 * (xx * FMA(-3.0f, yy, xx) - yy * FMA(3.0f, xx, -yy)), sh[(size_t)(24 * 3 + ch) * st], r);
+                    }
                 }
             }
         }

@@ -23,12 +23,14 @@ _C1 = 0.4886025119029199
 _C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
 _C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
        1.445305721320277, -0.5900435899266435)
+_C4 = (2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892, 0.10578554691520431,
+       -0.6690465435572892, 0.47308734787878004, -1.7701307697799304, 0.6258357354491761)
 
 
 def eval_sh(deg, sh, dirs):
-    """utils/sh_utils.py:57-112 for deg 0..3: sh (..., C, (max_deg+1)^2), dirs (..., 3) unit vectors -> (..., C)."""
-    if not 0 <= deg <= 3:
-        raise ValueError("SH degree must be 0..3")
+    """utils/sh_utils.py:57-112 for deg 0..4: sh (..., C, (max_deg+1)^2), dirs (..., 3) unit vectors -> (..., C)."""
+    if not 0 <= deg <= 4:
+        raise ValueError("SH degree must be 0..4")
     if sh.shape[-1] < (deg + 1) ** 2:
         raise ValueError("not enough SH coefficients for this degree")
     res = _C0 * sh[..., 0]
@@ -46,6 +48,12 @@ def eval_sh(deg, sh, dirs):
                        + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
                        + _C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + _C3[5] * z * (xx - yy) * sh[..., 14]
                        + _C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+                if deg > 3:                                      # utils/sh_utils.py:97-110
+                    res = (res + _C4[0] * xy * (xx - yy) * sh[..., 16] + _C4[1] * yz * (3 * xx - yy) * sh[..., 17]
+                           + _C4[2] * xy * (7 * zz - 1) * sh[..., 18] + _C4[3] * yz * (7 * zz - 3) * sh[..., 19]
+                           + _C4[4] * (zz * (35 * zz - 30) + 3) * sh[..., 20] + _C4[5] * xz * (7 * zz - 3) * sh[..., 21]
+                           + _C4[6] * (xx - yy) * (7 * zz - 1) * sh[..., 22] + _C4[7] * xz * (xx - 3 * yy) * sh[..., 23]
+                           + _C4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)) * sh[..., 24])
     return res
 
 

@@ -390,6 +390,10 @@ class EventTrainer:
             self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
         v = self.views
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
+        sizes = {(int(s.image_height), int(s.image_width)) for s in settings}
+        if len(sizes) != 1:
+            # the reference sizes every image on its own (utils/camera_utils.py:19-52): a triplet may mix resolutions
+            return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
         # ---- the three renders (train.py:144,159,161)
         flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
         if self.overlap_features:
@@ -429,6 +433,48 @@ class EventTrainer:
         rasterizer.backward_multi(raw, dpix, out)
         self.c_grad.copy_(scalars[1:2])
         self.last_radii = raw["radii"][0]
+        self.last_scalars = scalars
+        return scalars
+
+    def _compute_gradients_separate(self, settings, gt_int, gt_now, gt_next, gt_blur):
+        """The same iteration with one rasteriser call per camera, for triplets whose frames differ in size (the fused
+        multi-view pass renders all views of a call at one resolution).  The event pair must share a size (the contrast
+        is a per-pixel difference, utils/loss_utils.py:234-249); the intensity frame is free.  Slower (three forward /
+        backward passes, gradients accumulated with E3DGS_FLAG_ACCUMULATE), same mathematics:
+        loss = 0.9 L1(contrast) rho + 0.1 L1(intensity) (1 - rho)  [+ deblur], train.py:165-203."""
+        self.sync_features()
+        v = self.views
+        if (settings[1].image_height, settings[1].image_width) != (settings[2].image_height, settings[2].image_width):
+            raise ValueError("the two event frames of an iteration must have the same size")
+        raws = [rasterizer.forward_raw(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None, s,
+                                       flags=self.FWD_FLAGS) for s in settings]
+        img, now, nxt = (r["color"] for r in raws)
+        f32 = lambda t: t.to(torch.float32).contiguous()
+        # contrast term with the event-loss kernel (intensity slot fed its own target: L1 = 0 there) -> rho, dL/dc
+        sc, _, d_now, d_next = losses.event_loss_raw(now, now, nxt, self.c, now, f32(gt_now), f32(gt_next), None)
+        rho = sc[2]
+        e_int = img - f32(gt_int)
+        l1_int = e_int.abs().mean()
+        d_img = (0.1 * (1.0 - rho) / e_int.numel()) * torch.sign(e_int)
+        loss = sc[0] + 0.1 * l1_int * (1.0 - rho)
+        dc = sc[1]
+        if gt_blur is not None:                                            # train.py:197-203
+            e_b = img - f32(gt_blur)
+            loss = 0.5 * loss + 0.5 * e_b.abs().mean()
+            d_img = 0.5 * d_img + (0.5 / e_b.numel()) * torch.sign(e_b)
+            d_now, d_next, dc = 0.5 * d_now, 0.5 * d_next, 0.5 * dc
+        scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+        scalars[0], scalars[1], scalars[2], scalars[3], scalars[4] = loss, dc, rho, sc[3], l1_int
+        g = self.grads
+        self.flat_grad.zero_()
+        for k, (raw, dpix) in enumerate(zip(raws, (d_img, d_now, d_next))):
+            out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
+            if self.track_stats and k == 0:
+                out["means2D"] = self.viewspace_grad        # densification statistics use render #1 only (train.py:145)
+            rasterizer.backward_raw(raw, dpix.contiguous(), out, flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE)
+        self.c_grad.copy_(scalars[1:2])
+        self._packed_views = 0                          # several ranks: the SH gradient itself is exchanged
+        self.last_radii = raws[0]["radii"]
         self.last_scalars = scalars
         return scalars
 

@@ -106,6 +106,10 @@ void gso_set_tile_rows(int r0, int r1) { g_row0 = r0; g_row1 = r1; }
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 /* ---------- SH colour (only when `shs` is given; render() never does) ---------- */
+/* degree 4: utils/sh_utils.py:38-48 (constants), :97-110 (terms) */
+static const float SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f, -0.6690465435572892f,
+                               0.10578554691520431f, -0.6690465435572892f, 0.47308734787878004f, -1.7701307697799304f,
+                               0.6258357354491761f};
 static void sh_to_rgb(const GsoCtx *c, int idx, float *rgb, uint8_t *clamped) {
     const float *sh = c->shs + (size_t)idx * c->M * 3;
     float dx = c->means[3 * idx + 0] - c->campos[0];
@@ -134,6 +138,17 @@ static void sh_to_rgb(const GsoCtx *c, int idx, float *rgb, uint8_t *clamped) {
                     r = FMA(SH_C3[4] * x * (FMA(4.0f, zz, -xx) - yy), sh[13 * 3 + ch], r);
                     r = FMA(SH_C3[5] * z * (xx - yy), sh[14 * 3 + ch], r);
                     r = FMA(SH_C3[6] * x * FMA(-3.0f, yy, xx), sh[15 * 3 + ch], r);
+                    if (c->D > 3) {
+                        r = FMA(SH_C4[0] * xy * (xx - yy), sh[16 * 3 + ch], r);
+                        r = FMA(SH_C4[1] * yz * FMA(3.0f, xx, -yy), sh[17 * 3 + ch], r);
+                        r = FMA(SH_C4[2] * xy * FMA(7.0f, zz, -1.0f), sh[18 * 3 + ch], r);
+                        r = FMA(SH_C4[3] * yz * FMA(7.0f, zz, -3.0f), sh[19 * 3 + ch], r);
+                        r = FMA(SH_C4[4] * FMA(zz, FMA(35.0f, zz, -30.0f), 3.0f), sh[20 * 3 + ch], r);
+                        r = FMA(SH_C4[5] * xz * FMA(7.0f, zz, -3.0f), sh[21 * 3 + ch], r);
+                        r = FMA(SH_C4[6] * (xx - yy) * FMA(7.0f, zz, -1.0f), sh[22 * 3 + ch], r);
+                        r = FMA(SH_C4[7] * xz * FMA(-3.0f, yy, xx), sh[23 * 3 + ch], r);
+                        r = FMA(SH_C4[8] * (xx * FMA(-3.0f, yy, xx) - yy * FMA(3.0f, xx, -yy)), sh[24 * 3 + ch], r);
+                    }
                 }
             }
         }
@@ -475,7 +490,7 @@ static void sh_backward(const GsoCtx *c, int idx, const float *dL_drgb_in, float
     for (int ch = 0; ch < 3; ++ch) g[ch] = c->clamped[3 * idx + ch] ? 0.0f : dL_drgb_in[ch];
     float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
     /* basis values and their gradients w.r.t. (x,y,z) */
-    float Y[16], Yx[16], Yy[16], Yz[16];
+    float Y[25], Yx[25], Yy[25], Yz[25];
     memset(Yx, 0, sizeof Yx); memset(Yy, 0, sizeof Yy); memset(Yz, 0, sizeof Yz); memset(Y, 0, sizeof Y);
     Y[0] = SH_C0;
     Y[1] = -SH_C1 * y; Yy[1] = -SH_C1;
@@ -493,6 +508,16 @@ static void sh_backward(const GsoCtx *c, int idx, const float *dL_drgb_in, float
     Y[13] = SH_C3[4] * x * (4.0f * zz - xx - yy); Yx[13] = SH_C3[4] * (4.0f * zz - 3.0f * xx - yy); Yy[13] = SH_C3[4] * -2.0f * xy; Yz[13] = SH_C3[4] * 8.0f * xz;
     Y[14] = SH_C3[5] * z * (xx - yy); Yx[14] = SH_C3[5] * 2.0f * xz; Yy[14] = SH_C3[5] * -2.0f * yz; Yz[14] = SH_C3[5] * (xx - yy);
     Y[15] = SH_C3[6] * x * (xx - 3.0f * yy); Yx[15] = SH_C3[6] * (3.0f * xx - 3.0f * yy); Yy[15] = SH_C3[6] * -6.0f * xy;
+    /* degree 4: partial derivatives of the polynomials AS WRITTEN in utils/sh_utils.py:101-109 (x, y, z independent) */
+    Y[16] = SH_C4[0] * xy * (xx - yy); Yx[16] = SH_C4[0] * y * (3.0f * xx - yy); Yy[16] = SH_C4[0] * x * (xx - 3.0f * yy);
+    Y[17] = SH_C4[1] * yz * (3.0f * xx - yy); Yx[17] = SH_C4[1] * 6.0f * xy * z; Yy[17] = SH_C4[1] * z * (3.0f * xx - 3.0f * yy); Yz[17] = SH_C4[1] * y * (3.0f * xx - yy);
+    Y[18] = SH_C4[2] * xy * (7.0f * zz - 1.0f); Yx[18] = SH_C4[2] * y * (7.0f * zz - 1.0f); Yy[18] = SH_C4[2] * x * (7.0f * zz - 1.0f); Yz[18] = SH_C4[2] * 14.0f * xy * z;
+    Y[19] = SH_C4[3] * yz * (7.0f * zz - 3.0f); Yy[19] = SH_C4[3] * z * (7.0f * zz - 3.0f); Yz[19] = SH_C4[3] * y * (21.0f * zz - 3.0f);
+    Y[20] = SH_C4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f); Yz[20] = SH_C4[4] * z * (140.0f * zz - 60.0f);
+    Y[21] = SH_C4[5] * xz * (7.0f * zz - 3.0f); Yx[21] = SH_C4[5] * z * (7.0f * zz - 3.0f); Yz[21] = SH_C4[5] * x * (21.0f * zz - 3.0f);
+    Y[22] = SH_C4[6] * (xx - yy) * (7.0f * zz - 1.0f); Yx[22] = SH_C4[6] * 2.0f * x * (7.0f * zz - 1.0f); Yy[22] = SH_C4[6] * -2.0f * y * (7.0f * zz - 1.0f); Yz[22] = SH_C4[6] * 14.0f * z * (xx - yy);
+    Y[23] = SH_C4[7] * xz * (xx - 3.0f * yy); Yx[23] = SH_C4[7] * z * (3.0f * xx - 3.0f * yy); Yy[23] = SH_C4[7] * -6.0f * xy * z; Yz[23] = SH_C4[7] * x * (xx - 3.0f * yy);
+    Y[24] = SH_C4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy)); Yx[24] = SH_C4[8] * x * (4.0f * xx - 12.0f * yy); Yy[24] = SH_C4[8] * y * (4.0f * yy - 12.0f * xx);
     int ncoef = (c->D + 1) * (c->D + 1);
     for (int k = 0; k < ncoef; ++k)
         for (int ch = 0; ch < 3; ++ch) {

@@ -39,6 +39,8 @@ SH_C1 = 0.4886025119029199
 SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
 SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
          1.445305721320277, -0.5900435899266435]
+SH_C4 = [2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892, 0.10578554691520431,
+         -0.6690465435572892, 0.47308734787878004, -1.7701307697799304, 0.6258357354491761]
 
 
 def _now():
@@ -61,6 +63,12 @@ def eval_sh_colors(deg, shs, dirs):
              + SH_C3[2] * y * (4 * zz - xx - yy) * shs[:, 11] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * shs[:, 12]
              + SH_C3[4] * x * (4 * zz - xx - yy) * shs[:, 13] + SH_C3[5] * z * (xx - yy) * shs[:, 14]
              + SH_C3[6] * x * (xx - 3 * yy) * shs[:, 15])
+    if deg > 3:                                              # utils/sh_utils.py:97-110
+        r = (r + SH_C4[0] * xy * (xx - yy) * shs[:, 16] + SH_C4[1] * yz * (3 * xx - yy) * shs[:, 17]
+             + SH_C4[2] * xy * (7 * zz - 1) * shs[:, 18] + SH_C4[3] * yz * (7 * zz - 3) * shs[:, 19]
+             + SH_C4[4] * (zz * (35 * zz - 30) + 3) * shs[:, 20] + SH_C4[5] * xz * (7 * zz - 3) * shs[:, 21]
+             + SH_C4[6] * (xx - yy) * (7 * zz - 1) * shs[:, 22] + SH_C4[7] * xz * (xx - 3 * yy) * shs[:, 23]
+             + SH_C4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)) * shs[:, 24])
     return torch.clamp_min(r + 0.5, 0.0)
 
 

@@ -219,3 +219,56 @@ def test_g2_product_build_covariance(name):
     (cov * torch.tensor(g["grad_cov"])).sum().backward()
     assert np.abs(s.grad.numpy() - g["dscales"]).max() <= 1e-5 * np.abs(g["dscales"]).max()
     assert np.abs(q.grad.numpy() - g["drotations"]).max() <= 1e-5 * np.abs(g["drotations"]).max()
+
+
+def test_sh_degree4_against_reference_golden():
+    """utils/sh_utils.py:97-110 (25 coefficients): the torch oracle, the C oracle's in-rasteriser SH path and the product's
+    renderer.eval_sh against the reference's values and autograd gradients."""
+    from event_3dgs_amd import renderer
+    g = G("sh_deg4.npz")
+    campos = torch.tensor(g["campos"])
+    for fn in ("oracle", "product"):
+        feats = torch.tensor(g["features"], requires_grad=True)
+        xyz = torch.tensor(g["xyz"], requires_grad=True)
+        d = xyz - campos[None]
+        d = d / d.norm(dim=1, keepdim=True)
+        if fn == "oracle":
+            col = torch_oracle.eval_sh_colors(4, feats, d)
+        else:
+            col = torch.clamp_min(renderer.eval_sh(4, feats.transpose(1, 2).reshape(-1, 3, 25), d) + 0.5, 0.0)
+        assert np.abs(col.detach().numpy() - g["colors_deg4"]).max() <= 2e-6, fn
+        (col * torch.tensor(g["grad_colors"])).sum().backward()
+        assert np.abs(feats.grad.numpy() - g["dfeatures_deg4"]).max() <= 2e-6, fn
+        assert np.abs(xyz.grad.numpy() - g["dxyz_deg4"]).max() <= 1e-5, fn
+    # C oracle: colours through the rasteriser's preprocess
+    xyz = g["xyz"].copy()
+    N = xyz.shape[0]
+    view, proj, _, tx, ty = torch_oracle.look_at_camera([0.3, -0.2, 6.0], [0, 0, 0], [0, 1, 0], 0.9, 64, 64)
+    f = c_oracle.Forward(means3D=xyz, opacities=np.full(N, 0.5, np.float32), viewmatrix=view.numpy(),
+                         projmatrix=proj.numpy(), campos=g["campos"], bg=np.zeros(3, np.float32), width=64, height=64,
+                         tanfovx=tx, tanfovy=ty, shs=g["features"], sh_degree=4,
+                         scales=np.full((N, 3), 0.05, np.float32), rotations=np.tile([1, 0, 0, 0], (N, 1)).astype(np.float32))
+    vis = f.radii > 0
+    assert vis.sum() >= N // 2
+    assert np.abs(f.rgb[vis] - g["colors_deg4"][vis]).max() <= 3e-6
+
+
+def test_sh_degree4_c_oracle_backward_matches_autograd():
+    """The C oracle's hand-derived degree-4 SH backward against autograd of the torch oracle (whole rasteriser)."""
+    from helpers import oracle_kwargs, rel_l2, scene
+    act, cam = scene(300, 96, 64, seed=5)
+    g0 = torch.Generator().manual_seed(9)
+    act["shs"] = torch.cat((act["shs"], 0.05 * torch.randn(300, 9, 3, generator=g0)), dim=1)        # 25 coefficients
+    kw = oracle_kwargs(act, cam, [0.1, 0.2, 0.3], True, False, sh_degree=4)
+    f = c_oracle.Forward(**kw)
+    gw = torch.randn(3, 64, 96, generator=g0)
+    gb = f.backward(gw.numpy())
+    leaves = {k: act[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    img, _ = torch_oracle.rasterize(leaves["means3D"], leaves["opacities"], viewmatrix=cam.world_view_transform,
+                                    projmatrix=cam.full_proj_transform, campos=cam.camera_center, bg=torch.tensor([0.1, 0.2, 0.3]),
+                                    width=96, height=64, tanfovx=kw["tanfovx"], tanfovy=kw["tanfovy"], shs=leaves["shs"],
+                                    sh_degree=4, scales=leaves["scales"], rotations=leaves["rotations"])
+    assert np.abs(img.detach().numpy() - f.out_color).max() <= 2e-5
+    (img * gw).sum().backward()
+    assert rel_l2(gb["shs"], leaves["shs"].grad.numpy()) <= 2e-5
+    assert rel_l2(gb["means3D"], leaves["means3D"].grad.numpy()) <= 2e-4

@@ -544,3 +544,27 @@ def test_multi_view_pass_against_oracle(nviews, W, H):
     for mine, theirs in pairs.items():
         got = out[mine].cpu().numpy()
         assert rel_l2(got, ref[theirs].reshape(got.shape)) <= GRAD_TOL, mine
+
+
+@pytest.mark.parametrize("use_cov", [False, True])
+def test_sh_degree_4(use_cov):
+    """25 SH coefficients per channel (utils/sh_utils.py:97-110; golden sh_deg4.npz pins the oracle): the operator against
+    the C oracle, forward bit for bit, gradients to tolerance (incl. the per-Gaussian measure)."""
+    from helpers import per_gaussian_err
+    from oracle import c_oracle
+    N, W, H = 1500, 144, 96
+    act, cam = scene(N, W, H, seed=44)
+    act["shs"] = torch.cat((act["shs"], 0.05 * torch.randn(N, 9, 3, generator=torch.Generator().manual_seed(4))), dim=1)
+    bg = (0.2, 0.1, 0.0)
+    img, radii, grads, gw = _run_hip(act, cam, bg, True, use_cov, sh_degree=4)
+    f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, use_cov, sh_degree=4))
+    assert np.array_equal(radii, f.radii) and np.array_equal(img, f.out_color)
+    gb = f.backward(gw)
+    assert grads["shs"].shape == (N, 25, 3) and np.abs(gb["shs"][:, 16:]).max() > 0
+    for k in ("means3D", "shs", "opacities"):
+        ref = gb[k].reshape(grads[k].shape)
+        assert rel_l2(grads[k], ref) <= GRAD_TOL, k
+        assert per_gaussian_err(grads[k], ref) <= 1e-3, k
+    # degree 3 on the same 25-coefficient tensor ignores (and zero-fills the gradient of) the rest
+    img3, _, grads3, _ = _run_hip(act, cam, bg, True, use_cov, sh_degree=3)
+    assert np.abs(grads3["shs"][:, 16:]).max() == 0.0 and not np.array_equal(img3, img)

@@ -782,3 +782,42 @@ def test_device_densification_equals_the_torch_form(size_prune):
     gts = [tr.render_raw(c, bg)["color"].clone() for c in cams]
     sc = tr.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
     assert torch.isfinite(sc).all() and torch.isfinite(tr.flat).all()
+
+
+def test_triplet_with_mixed_resolutions_falls_back_to_per_view_calls():
+    """utils/camera_utils.py:19-52 sizes every image on its own: an intensity frame at another resolution than the event
+    pair.  The trainer renders the three views separately; gradients equal the autograd composition of the reference's
+    formulas (torch) over the drop-in operator."""
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.rasterizer import rasterize_gaussians
+    from event_3dgs_amd.train_step import EventTrainer
+    from oracle import torch_oracle
+    params, _ = _scene(N=2500)
+    cams = [orbit_camera(0, 16, 176, 128, device=DEV), orbit_camera(0, 16, 128, 96, device=DEV, daz=0.004),
+            orbit_camera(0, 16, 128, 96, device=DEV, daz=0.012)]
+    bg = torch.ones(3, device=DEV)
+    gts = _gts(params, cams, bg)
+    gts[2][:, :, :48] = gts[1][:, :, :48]          # no event on a third of the frame: rho < 1, the intensity term is live
+    for blur in (None, (0.9 * gts[0]).contiguous()):
+        tr = EventTrainer(params, DEV, track_densification_stats=True)
+        sc = tr.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+        leaves = {k: t.detach().clone().requires_grad_(True) for k, t in tr.views.items()}
+        c = tr.c.detach().clone().requires_grad_(True)
+        feats = leaves["features"].t().reshape(tr.N, 16, 3)
+        imgs = []
+        for cam in cams:
+            m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
+            img, _ = rasterize_gaussians(leaves["xyz"], m2, feats, None, torch.sigmoid(leaves["opacity"]),
+                                         torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"]),
+                                         None, tr._settings(cam, bg))
+            imgs.append(img)
+        ref = torch_oracle.event_iteration_loss(imgs[0], imgs[1], imgs[2], gts[0], gts[1], gts[2], c, gt_blur=blur)
+        ref.backward()
+        assert abs(float(sc[0]) - float(ref)) <= 2e-5 * abs(float(ref))
+        assert abs(float(tr.c_grad) - float(c.grad)) <= 2e-4 * abs(float(c.grad))
+        for name in ("xyz", "features", "opacity", "scaling", "rotation"):
+            a, b = tr.grads[name].cpu().numpy(), leaves[name].grad.cpu().numpy()
+            assert rel_l2(a, b) <= 1e-3, (name, rel_l2(a, b))
+        assert float(tr.viewspace_grad.abs().max()) > 0
+        tr.apply_update()
+        assert torch.isfinite(tr.flat).all()
