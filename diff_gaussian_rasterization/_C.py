@@ -6,6 +6,10 @@ import torch
 
 from event_3dgs_amd import rasterizer as _r
 
+# The compiled module (csrc/ext.cpp, built by build_ext.py / __graft_entry__.build()) exports the same three functions;
+# when it is present they ARE this module's functions, otherwise the ctypes implementations below serve.
+_native = _r.native_ext()
+
 
 def _opt(t):
     return None if t is None or t.numel() == 0 else t
@@ -56,3 +60,9 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     if pos is None:
         return torch.zeros(0, dtype=torch.bool, device=means3D.device)
     return _r._mark_visible(pos, _r._prep(viewmatrix, "viewmatrix"), _r._prep(projmatrix, "projmatrix")).bool()
+
+
+if _native is not None:
+    rasterize_gaussians = _native.rasterize_gaussians
+    rasterize_gaussians_backward = _native.rasterize_gaussians_backward
+    mark_visible = _native.mark_visible

@@ -36,6 +36,29 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+_NATIVE = None
+
+
+def native_ext():
+    """The compiled torch extension diff_gaussian_rasterization._C_native (csrc/ext.cpp: torch::Tensor <-> C ABI in C++), or
+    None when it has not been built or E3DGS_NATIVE_EXT=0.  The autograd operator goes through it when present -- the
+    tensor marshalling of one forward + backward costs ~20 us in C++ against ~120 us through ctypes; results are
+    identical (same C ABI underneath)."""
+    global _NATIVE
+    if _NATIVE is None:
+        import os
+        _NATIVE = False
+        if os.environ.get("E3DGS_NATIVE_EXT", "1") != "0":
+            try:
+                _lib.lib()                                  # loud failure if the HIP library itself is missing
+                from diff_gaussian_rasterization import _C_native
+                if _C_native.abi_version() == _lib.ABI_VERSION:
+                    _NATIVE = _C_native
+            except ImportError:
+                _NATIVE = False
+    return _NATIVE or None
+
+
 def _prep(t, name, device=None):
     """fp32, contiguous, on the GPU.  Inputs may arrive strided (scene/cameras.py:54-57)."""
     if t is None or t.numel() == 0:
@@ -279,20 +302,76 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        ext = native_ext()
+        if ext is not None:
+            return _RasterizeGaussians._forward_native(ctx, ext, args, means3D, sh, colors_precomp, opacities, scales,
+                                                       rotations, cov3Ds_precomp, rs)
         raw = _debug_guard(rs.debug, args, "snapshot_fw.dump", "forward", lambda: forward_raw(
             means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings))
         ctx.raster_settings = raster_settings
         ctx.num_rendered = raw["num_rendered"]
         ctx.consts = raw["consts"]
         ctx.M = raw["M"]
+        ctx.native = False
         ctx.save_for_backward(*raw["inputs"], raw["radii"], raw["geom"], raw["binning"], raw["image"])
         ctx.mark_non_differentiable(raw["radii"])
         return raw["color"], raw["radii"]
 
     @staticmethod
+    def _forward_native(ctx, ext, args, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+        """Upstream's own Python layer, verbatim in structure: empty tensor = not provided, the extension returns
+        (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer)."""
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        if not means3D.is_cuda:
+            raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+        P = means3D.shape[0]
+        empty = means3D.new_empty(0)
+        e = lambda t: empty if t is None else t
+        if P:
+            if opacities is None or opacities.numel() != P:
+                raise RuntimeError("opacities must have P elements")
+            if (sh is None or sh.numel() == 0) == (colors_precomp is None or colors_precomp.numel() == 0):
+                raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
+            has_sr = scales is not None and rotations is not None and scales.numel() and rotations.numel()
+            if bool(has_sr) == (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0):
+                raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        def call():
+            # (the caller's promise is checked first: upstream's kernel traps the device on a violation, see forward_raw)
+            if rs.prefiltered and P and not bool(ext.mark_visible(means3D, rs.viewmatrix, rs.projmatrix).all()):
+                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+            return ext.rasterize_gaussians(
+                rs.bg, means3D, e(colors_precomp), e(opacities), e(scales), e(rotations), float(rs.scale_modifier),
+                e(cov3Ds_precomp), rs.viewmatrix, rs.projmatrix, float(rs.tanfovx), float(rs.tanfovy),
+                int(rs.image_height), int(rs.image_width), e(sh), int(rs.sh_degree), rs.campos, bool(rs.prefiltered),
+                bool(rs.debug))
+        num_rendered, color, radii, geomB, binB, imgB = _debug_guard(rs.debug, args, "snapshot_fw.dump", "forward", call)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.native = True
+        ctx.save_for_backward(means3D, e(sh), e(colors_precomp), e(scales), e(rotations), e(cov3Ds_precomp), radii, geomB,
+                              binB, imgB)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
         means3D, sh, colors, scales, rots, cov, radii, geomB, binB, imgB = ctx.saved_tensors
+        if ctx.native:
+            ext = native_ext()
+            g = grad_out_color if grad_out_color.dtype == torch.float32 else grad_out_color.float()
+            args = (rs.bg, means3D, radii, colors, scales, rots, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix,
+                    rs.tanfovx, rs.tanfovy, g, sh, rs.sh_degree, rs.campos, geomB, ctx.num_rendered, binB, imgB, rs.debug)
+            (d_means2D, d_colors, d_opac, d_means3D, d_cov, d_sh, d_scales, d_rots) = _debug_guard(
+                rs.debug, args, "snapshot_bw.dump", "backward", lambda: ext.rasterize_gaussians_backward(
+                    rs.bg, means3D, radii, colors, scales, rots, float(rs.scale_modifier), cov, rs.viewmatrix,
+                    rs.projmatrix, float(rs.tanfovx), float(rs.tanfovy), g, sh, int(rs.sh_degree), rs.campos, geomB,
+                    int(ctx.num_rendered), binB, imgB, bool(rs.debug)))
+            n = lambda t, inp: t if inp.numel() else None
+            has_cov = cov.numel() != 0
+            return (d_means3D, d_means2D, n(d_sh, sh), n(d_colors, colors), d_opac, None if has_cov else d_scales,
+                    None if has_cov else d_rots, d_cov if has_cov else None, None)
         dev = means3D.device
         P, M = means3D.shape[0], ctx.M
         e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # kernels write every element

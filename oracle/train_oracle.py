@@ -95,4 +95,4 @@ class OracleTrainer:
         self.opt_c.step()
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
-        return float(loss)
+        return float(loss.detach())

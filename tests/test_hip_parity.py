@@ -233,7 +233,14 @@ def test_prefiltered_and_debug_contracts(tmp_path, monkeypatch):
     from event_3dgs_amd import rasterizer
     def boom(*a, **k):
         raise RuntimeError("injected")
-    monkeypatch.setattr(rasterizer, "backward_raw", boom)
+    monkeypatch.setattr(rasterizer, "backward_raw", boom)                    # the ctypes path ...
+    real = rasterizer.native_ext()
+    if real is not None:                                                     # ... and the compiled extension's
+        class Proxy:
+            rasterize_gaussians_backward = staticmethod(boom)
+            def __getattr__(self, name):
+                return getattr(real, name)
+        monkeypatch.setattr(rasterizer, "_NATIVE", Proxy())
     with pytest.raises(RuntimeError, match="injected"):
         img.sum().backward()
     snap = torch.load(tmp_path / "snapshot_bw.dump", weights_only=False)
@@ -568,3 +575,35 @@ def test_sh_degree_4(use_cov):
     # degree 3 on the same 25-coefficient tensor ignores (and zero-fills the gradient of) the rest
     img3, _, grads3, _ = _run_hip(act, cam, bg, True, use_cov, sh_degree=3)
     assert np.abs(grads3["shs"][:, 16:]).max() == 0.0 and not np.array_equal(img3, img)
+
+
+def test_compiled_extension_and_ctypes_paths_are_identical():
+    """The autograd operator through diff_gaussian_rasterization._C_native (torch::Tensor marshalling in C++, csrc/ext.cpp)
+    and through ctypes call the same C ABI: bit-identical images, radii and gradients, for every input variant."""
+    from event_3dgs_amd import rasterizer
+    ext = rasterizer.native_ext()
+    assert ext is not None, "the compiled extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    act, cam = scene(1200, 112, 80, seed=8)
+    for use_sh, use_cov in ((True, False), (False, False), (True, True), (False, True)):
+        a = _run_hip(act, cam, (0.1, 0.0, 0.2), use_sh, use_cov)
+        saved = rasterizer._NATIVE
+        rasterizer._NATIVE = False
+        try:
+            b = _run_hip(act, cam, (0.1, 0.0, 0.2), use_sh, use_cov)
+        finally:
+            rasterizer._NATIVE = saved
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[2].keys() == b[2].keys()
+        for k in a[2]:
+            assert np.array_equal(a[2][k], b[2][k]), k
+    # empty scene and the argument errors behave alike
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    rs = _settings(cam, (0.5, 0.25, 0.0), dev)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    img, radii = GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3),
+                                        scales=z(0, 3), rotations=z(0, 4))
+    assert radii.numel() == 0 and torch.equal(img[:, 0, 0].cpu(), torch.tensor([0.5, 0.25, 0.0]))
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(rs)(means3D=z(5, 2), means2D=z(5, 3), opacities=z(5, 1), colors_precomp=z(5, 3),
+                               scales=z(5, 3), rotations=z(5, 4))
