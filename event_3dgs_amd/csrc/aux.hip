@@ -372,7 +372,7 @@ int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float l
     if (n == 0) return 0;
     double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     size_t nb = (n + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    if (nb > 65536) nb = 65536;      // measured at 59 M floats: 8192 -> 4.8 TB/s, 65536 -> 5.85 TB/s, no cap 5.7
     adam_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, (float)(lr / bc1), b1, b2, (float)sqrt(bc2), eps,
                                                          (float)(lr_b / bc1), period, split);
     hipError_t e = hipGetLastError();
@@ -425,7 +425,7 @@ int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v
     if (seg_end[nseg - 1] != n) return e3_fail(hipErrorInvalidValue, "last segment must end at n");
     sg.n = nseg;
     size_t nb = (n + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    if (nb > 65536) nb = 65536;      // measured at 59 M floats: 8192 -> 4.8 TB/s, 65536 -> 5.85 TB/s, no cap 5.7
     adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, sg, b1, b2);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "adam_segments_kernel");

@@ -1095,6 +1095,78 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int P, int nranks, i
     for (int k = 3 * nk; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
 }
 
+// The same rebuild fused with the optimizer step of the SH coefficients: the gradient never reaches memory -- it goes
+// straight into torch.optim.Adam's update (f_dc / f_rest learning rates, scene/gaussian_model.py:156-157).  One
+// streaming pass that reads 3 colour-gradient floats per (Gaussian, view) instead of writing and re-reading 48
+// gradients.  blockIdx.y selects four coefficients (12 elements): a workgroup streams 36 planes of the
+// coefficient-major arrays (all 144 at once ran at 3.9 TB/s: too many concurrent DRAM streams), the moments and
+// parameters are requested before the gradient is computed, and the colour gradients re-read by the four y-slices come
+// from L2 / Infinity Cache.  Same arithmetic as sh_grad_views_kernel + adam_segments_kernel: bit-identical results.
+struct ShAdam { float* m; float* v; float ss_dc, ss_rest, bc2s, b1, b2, eps; };
+__global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
+                                                            const float* __restrict__ means,
+                                                            const float* __restrict__ packed, size_t rank_stride,
+                                                            float scale, float* __restrict__ sh, int planar, ShAdam ad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int k0 = 4 * (int)blockIdx.y;                  // this slice: coefficients k0 .. k0 + 3
+    const size_t st = planar ? (size_t)P : (size_t)1;
+    const size_t e0 = (planar ? (size_t)i : (size_t)i * M * 3) + (size_t)(3 * k0) * st;
+    float m0[12], v0[12], p0[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { m0[j] = ad.m[e0 + j * st]; v0[j] = ad.v[e0 + j * st]; p0[j] = sh[e0 + j * st]; }
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float acc[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    const int nk = (D + 1) * (D + 1);
+#pragma unroll 1
+    for (int r = 0; r < nranks; ++r) {
+        const float* blk = packed + (size_t)r * rank_stride;
+        const float* cams = blk + (size_t)views_per_rank * P * 3;
+#pragma unroll 1
+        for (int v = 0; v < views_per_rank; ++v) {
+            const float* gp = blk + ((size_t)v * P + i) * 3;
+            const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;          // culled / clamped in this view
+            const float ox = mx - cams[3 * v], oy = my - cams[3 * v + 1], oz = mz - cams[3 * v + 2];
+            const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+            const float x = ox / len, y = oy / len, z = oz / len;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (k0 + kk < nk) {                                         // (uniform per workgroup)
+                    float Y, Yx, Yy, Yz;
+                    sh_basis(k0 + kk, x, y, z, Y, Yx, Yy, Yz);
+                    acc[kk][0] = FMA(Y, g0, acc[kk][0]); acc[kk][1] = FMA(Y, g1, acc[kk][1]); acc[kk][2] = FMA(Y, g2, acc[kk][2]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const float g = (k0 + j / 3 < nk) ? acc[j / 3][j % 3] * scale : 0.0f;     // inactive degrees: zero gradient, moments decay
+        const float mi = m0[j] + (1.0f - ad.b1) * (g - m0[j]);
+        const float vi = v0[j] * ad.b2 + (1.0f - ad.b2) * g * g;
+        ad.m[e0 + j * st] = mi; ad.v[e0 + j * st] = vi;
+        sh[e0 + j * st] = p0[j] - ((k0 == 0 && j < 3) ? ad.ss_dc : ad.ss_rest) * (mi / (__builtin_sqrtf(vi) / ad.bc2s + ad.eps));
+    }
+}
+
+int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
+                          size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                          float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s) {
+    if (P <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    ShAdam ad;
+    ad.m = exp_avg; ad.v = exp_avg_sq; ad.ss_dc = (float)((double)lr_dc / bc1); ad.ss_rest = (float)((double)lr_rest / bc1);
+    ad.bc2s = (float)sqrt(bc2); ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
+    sh_adam_views_kernel<<<dim3((P + 255) / 256, M / 4), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
+                                                                           rank_stride, scale, sh,
+                                                                           (flags & E3_FLAG_SH_PLANAR) != 0, ad);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* dL_dsh, int flags, hipStream_t s) {
     if (P <= 0) return 0;

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary declared in include/e3dgs_hip.h.
 #include "common.h"
 #include "../../include/e3dgs_hip.h"
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,7 +70,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 9; }
+int e3dgs_abi_version(void) { return 10; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -347,6 +348,22 @@ int e3dgs_sh_grad_from_colour(int P, int nranks, int views_per_rank, int D, int 
     int rc = e3_sh_grad_views_impl(P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, dL_dsh, flags,
                                    (hipStream_t)stream);
     return rc ? e3_fail((hipError_t)rc, "sh_grad_views_kernel") : 0;
+}
+
+int e3dgs_sh_adam_from_colour(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
+                              const float* packed, size_t rank_stride, float scale, float* sh, float* exp_avg,
+                              float* exp_avg_sq, float lr_f_dc, float lr_f_rest, float beta1, float beta2, float eps,
+                              int step, int flags, void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || nranks < 1 || views_per_rank < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || step < 1)
+        return e3_fail(hipErrorInvalidValue, "bad sizes");
+    if (M % 4 != 0 || M > 64) return e3_fail(hipErrorInvalidValue, "M must be a multiple of 4 (the optimizer kernel works on four coefficients per slice)");
+    if (P > 0 && (!means3D || !packed || !sh || !exp_avg || !exp_avg_sq)) return e3_fail(hipErrorInvalidValue, "null pointer");
+    if (rank_stride < (size_t)views_per_rank * ((size_t)P * 3 + 3))
+        return e3_fail(hipErrorInvalidValue, "rank_stride smaller than one rank block");
+    int rc = e3_sh_adam_views_impl(P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, sh, exp_avg,
+                                   exp_avg_sq, lr_f_dc, lr_f_rest, beta1, beta2, eps, step, flags, (hipStream_t)stream);
+    return rc ? e3_fail((hipError_t)rc, "sh_grad_views_kernel<adam>") : 0;
 }
 
 size_t e3dgs_state_offset_emit_gid(int num_rendered) {

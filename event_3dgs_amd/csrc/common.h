@@ -336,6 +336,10 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
 int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* dL_dsh, int flags, hipStream_t s);
 
+int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
+                          size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                          float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s);
+
 // launchers implemented in scan_sort.hip
 void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
                                hipStream_t s);

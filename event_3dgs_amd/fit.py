@@ -66,7 +66,7 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
             now, nxt = event_cameras[index], event_cameras[index + 1]
             blur = blurry_cameras[index].original_image if blurry_cameras else None         # train.py:197-203
             scalars = tr.compute_gradients(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image,
-                                           bg, gt_blur=blur)
+                                           bg, gt_blur=blur, sh_via_colour=tr.sh_via_colour and not tr.overlap_features)
         else:
             scalars = tr.compute_gradients_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim)
         scalars = scalars.clone()

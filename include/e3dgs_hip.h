@@ -280,6 +280,20 @@ int e3dgs_sh_grad_from_colour(int P, int nranks, int views_per_rank, int D, int 
                               void* stream);
 
 /*
+ * The same rebuild fused with the optimizer step of the SH coefficients (train.py:330-332 for the f_dc / f_rest groups of
+ * scene/gaussian_model.py:156-157): the rebuilt gradient is consumed in registers by torch.optim.Adam's update, `sh`
+ * (layout per flags, (P,M,3) or coefficient-major) is updated IN PLACE together with its exp_avg / exp_avg_sq (same
+ * layout).  One streaming pass that reads 3 colour-gradient floats per (Gaussian, view) instead of writing and
+ * re-reading 48 gradient floats per Gaussian -- used on ONE rank too (nranks = 1): at 1 M Gaussians the iteration
+ * sheds 0.3 GB of HBM traffic.  Bit-identical to e3dgs_sh_grad_from_colour + e3dgs_adam_step_groups.  `means3D`: the
+ * positions the colour gradients were computed with (call it BEFORE the optimizer moves them).
+ */
+int e3dgs_sh_adam_from_colour(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
+                              const float* packed, size_t rank_stride, float scale, float* sh, float* exp_avg,
+                              float* exp_avg_sq, float lr_f_dc, float lr_f_rest, float beta1, float beta2, float eps,
+                              int step, int flags, void* stream);
+
+/*
  * Exact tile culling (default ON; environment E3DGS_TILE_CULL=0 turns it off at load time).
  * The reference op bins every Gaussian into all tiles of its 3-sigma bounding rectangle.  With
  * culling ON, (tile, Gaussian) instances that provably reach no pixel of the tile with

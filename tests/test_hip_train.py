@@ -61,7 +61,10 @@ def test_fused_step_equals_autograd_step(deblur):
     gts = _gts(params, cams, bg)
     blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
     a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
-    sa = a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+    # (compute_gradients + apply_update: the form that leaves the whole gradient in memory; step() keeps the SH gradient
+    # in registers on one rank, checked bit for bit against this form in test_sh_optimizer_from_colour_gradients...)
+    sa = a.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur).clone()
+    a.apply_update()
     lb = b.step_autograd(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
     torch.cuda.synchronize()
     assert abs(float(sa[0]) - float(lb)) <= 1e-5 * abs(float(lb))
@@ -821,3 +824,37 @@ def test_triplet_with_mixed_resolutions_falls_back_to_per_view_calls():
         assert float(tr.viewspace_grad.abs().max()) > 0
         tr.apply_update()
         assert torch.isfinite(tr.flat).all()
+
+
+@pytest.mark.parametrize("deblur", [False, True])
+def test_sh_optimizer_from_colour_gradients_is_bit_identical(deblur):
+    """step() on one rank: backward hands out per-view colour gradients, e3dgs_sh_adam_from_colour rebuilds the SH gradient
+    in registers and applies Adam -- against compute_gradients() + apply_update() with the SH gradient in memory:
+    parameters, both moments and c bit for bit over several iterations, also with the opacity group's step count lagging
+    and the SH degree below 3 (inactive coefficients still decay)."""
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene(N=3000)
+    bg = torch.zeros(3, device=DEV)
+    gts = [(torch.round(t.clamp(0, 1) * 255) / 255).contiguous() for t in _gts(params, cams, bg)]
+    blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
+    a = EventTrainer(params, DEV, track_densification_stats=True, active_sh_degree=2)
+    b = EventTrainer(params, DEV, track_densification_stats=True, active_sh_degree=2)
+    assert a.sh_via_colour
+    for it in range(5):
+        sa = a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+        sb = b.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur).clone()
+        assert b._packed_views == 0
+        b.apply_update()
+        assert torch.equal(sa, sb), it
+        assert torch.equal(a.flat, b.flat) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq), it
+        assert torch.equal(a.viewspace_grad, b.viewspace_grad)
+        if it == 1:                      # make the opacity group's step count lag behind the others
+            for t in (a, b):
+                t.reset_opacity()
+                t.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg,
+                                    sh_via_colour=t is a)
+                t.apply_update(skip=("opacity",))
+            assert a.steps == b.steps == {"gauss": 3, "opacity": 2, "c": 3}
+            assert torch.equal(a.flat, b.flat)
+            a.active_sh_degree = b.active_sh_degree = 3
+    assert a.steps == {"gauss": 6, "opacity": 5, "c": 6} and a.iteration == 6

@@ -4,8 +4,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0][:40] for r in rows]
-adam = [i for i, n in enumerate(names) if n.startswith("adam_kernel")]
-ends = adam[5::6]
+adam = [i for i, n in enumerate(names) if n.startswith("adam_segments_kernel")]     # one launch ends an iteration
+ends = adam
 a, b = ends[-3] + 1, ends[-2] + 1
 seg = rows[a:b]
 t0 = int(rows[a - 1]["End_Timestamp"])
