@@ -320,7 +320,38 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
             // own `power` at any pixel of the tile (|terms| <= 2(|terms at the minimiser| + Lambda*15^2*2))
             float thr = 2.0f * logf(255.0f * t.y);
             thr = thr + fabsf(thr) * 1e-4f + 1e-3f + 2e-3f * (fabsf(a.z) + 2.0f * fabsf(a.w) + fabsf(t.x));
-            b = make_float4(t.x, thr, __uint_as_float(r.x), __uint_as_float(w));
+            uint32_t xy0 = r.x;
+#ifndef E3_NO_TIGHT_RECT
+            // Candidate rectangle: the reference walks every tile of the 3-sigma square; tile_touched() then keeps those the
+            // ellipse q <= thr can reach.  Nearly half of the candidates fail that test, and every one costs both binning
+            // passes a search + test.  The axis-aligned box of the (inflated) ellipse is known in closed form --
+            // |dx| <= sqrt(thr' C / det), |dy| <= sqrt(thr' A / det) -- so only its tiles are walked.  thr' carries the
+            // relative slack tile_touched() subtracts (1e-4 of the summed |terms|, bounded over the square) and the box a
+            // pixel of margin: every tile outside it fails tile_touched(), i.e. the kept set is unchanged.
+            if (cull) {
+                const float A = a.z, B = a.w, C = t.x, det = A * C - B * B;
+                if (A > 0.0f && C > 0.0f && det > 0.0f) {
+                    const float ex = 16.0f * (float)w, ey = 16.0f * (float)h;                   // |dx|, |dy| inside the square
+                    const float thr2 = thr + 2e-4f * (A * ex * ex + C * ey * ey) * 1.01f + 1e-3f;
+                    if (thr2 > 0.0f) {
+                        const float hx = __builtin_sqrtf(thr2 * C / det) * 1.001f + 1.0f;
+                        const float hy = __builtin_sqrtf(thr2 * A / det) * 1.001f + 1.0f;
+                        const int x0r = (int)(r.x & 0xFFFFu), y0r = (int)(r.x >> 16), x1r = (int)(r.y & 0xFFFFu), y1r = (int)(r.y >> 16);
+                        // pixels of tile t span [16 t, 16 t + 15]
+                        const int tx0 = max(x0r, (int)__builtin_floorf((a.x - hx - 15.0f) * (1.0f / 16.0f))),
+                                  tx1 = min(x1r, (int)__builtin_floorf((a.x + hx) * (1.0f / 16.0f)) + 1),
+                                  ty0 = max(y0r, (int)__builtin_floorf((a.y - hy - 15.0f) * (1.0f / 16.0f))),
+                                  ty1 = min(y1r, (int)__builtin_floorf((a.y + hy) * (1.0f / 16.0f)) + 1);
+                        if (tx1 > tx0 && ty1 > ty0) {
+                            w = (uint32_t)(tx1 - tx0); h = (uint32_t)(ty1 - ty0);
+                            xy0 = (uint32_t)tx0 | ((uint32_t)ty0 << 16);
+                        } else { w = 0u; h = 0u; }
+                        n = w * h;
+                    } else n = 0u;                      // 255 o < 1 everywhere (with slack): nothing can be kept
+                }
+            }
+#endif
+            b = make_float4(t.x, thr, __uint_as_float(xy0), __uint_as_float(w));
         }
     }
     uint32_t incl = n;
