@@ -181,11 +181,22 @@ def main():
     loss_val = float(loss[0].item())
     # per-stage table: the same steps again, outside the timed region, with every slot bracketed
     L.e3dgs_profile_enable(0xFF)
+    # ... and the optimizer (EventTrainer.apply_update: SH-gradient rebuild + Adam kernels) with events on torch's stream
+    opt_events = []
+    real_apply = trainer.apply_update
+
+    def timed_apply(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); real_apply(*a, **k); e1.record()
+        opt_events.append((e0, e1))
+    trainer.apply_update = timed_apply
     for _ in range(max(3, args.steps // 4)):
         one_step()
     torch.cuda.synchronize()
+    trainer.apply_update = real_apply
     kern = read_slots()
     L.e3dgs_profile_enable(0)
+    opt_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1)
     dom_name = L.e3dgs_profile_slot_name(DOMINANT_SLOT).decode()
     if timed[dom_name][1]:
         kern[dom_name] = timed[dom_name]          # the roofline figure uses the timed-region measurement
@@ -205,25 +216,44 @@ def main():
             b = algorithmic_bytes(name, N * V, I, T * V, npx * V)
             stages[name] = {"avg_ms": round(avg, 4), "launches": n, "alg_GB": round(b / 1e9, 4),
                             "alg_GBps": round(b / 1e9 / (avg / 1e3), 1)}
+    if opt_events and world == 1:
+        ob = 28 * (FLOATS_PER_GAUSSIAN * N + 1)          # torch.optim.Adam: read g, p, m, v; write p, m, v
+        stages["optimizer"] = {"avg_ms": round(opt_ms, 4), "launches": len(opt_events), "alg_GB": round(ob / 1e9, 4),
+                               "alg_GBps": round(ob / 1e9 / (opt_ms / 1e3), 1)}
     # the roofline object describes the kernel timed inside the timed region (the largest one: DESIGN.md section 5)
     dominant = dom_name if dom_name in stages else None
     roofline = None
     if dominant:
         s = stages[dominant]
-        traffic = None
+        traffic, insts = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant + "_kernel", {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(dominant + "_kernel", {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                insts = rec.get("wave_instructions_per_launch")
             except Exception:
-                traffic = None
+                traffic = insts = None
+        # what actually bounds compositing: instruction issue.  Nominal rate = one wave64 VALU instruction per 2 cycles
+        # per SIMD (MI355X_MICROARCH.md, register-file table) x 1024 SIMDs x 2.4 GHz; the instruction counts are the
+        # SQ_INSTS_* counters of the committed profile of this kernel (profiles/traffic.json), the time is this run's.
+        issue = None
+        if insts:
+            rate = 1024 * 2.4e9 / 2.0
+            t = s["avg_ms"] / 1e3
+            allinst = sum(insts.get(k, 0) for k in ("valu", "salu", "lds", "branch", "vmem"))
+            issue = {"valu_issue_frac": round(insts["valu"] / (rate * t), 3), "all_instructions_issue_frac": round(allinst / (rate * t), 3),
+                     "valu_wave_instructions": insts["valu"], "salu_wave_instructions": insts.get("salu"),
+                     "nominal_rate": "1 wave64 instruction / 2 cycles / SIMD, 1024 SIMDs, 2.4 GHz"}
         roofline = {"kernel": dominant + "_kernel", "bound": "hbm", "achieved": s["alg_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(s["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": s["avg_ms"], "alg_bytes_per_launch": int(s["alg_GB"] * 1e9),
-                    "views_per_launch": V,
+                    "views_per_launch": V, "issue": issue,
                     "note": "one launch composites the 3 views of the iteration (HIP events on the launch stream, timed "
-                            "region). Compositing is VALU-bound, not HBM-bound (SURVEY 8d, DESIGN.md): alpha evaluations/s = "
-                            + f"{256.0 * I / (s['avg_ms'] / 1e3) / 1e9:.1f} G/s"}
+                            "region). Compositing is instruction-issue-bound, not HBM-bound (SURVEY 8d, DESIGN.md section 5): "
+                            + (f"VALU issue at {issue['valu_issue_frac']:.0%} of nominal, all instruction types "
+                               f"{issue['all_instructions_issue_frac']:.0%}; " if issue else "")
+                            + f"alpha evaluations/s = {256.0 * I / (s['avg_ms'] / 1e3) / 1e9:.1f} G/s"}
 
     # ---- the contrast-only sub-step north_star words the metric by: renders #2 and #3 forward,
     # differentialable_event_simu + L1 on the pair, backward through both renders; no intensity render, no optimizer.

@@ -48,6 +48,19 @@ for k, v in out.items():
                  "only, kernel dispatches serialised by the profiler; hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE "
                  "(gfx950 correction of MI355X_MICROARCH.md, re-calibrated for 48-B record gathers/scatters with "
                  "tools/ubench/pmc_calib.hip: fetches are 128-B lines counted at 64 B)")
+# instruction counts of the 3-view launches (profiles/run_pmc_mix.sh <regex> <mixtag>  ->  gpurun_out/pmcm_<mixtag>/a/...)
+mixtag = sys.argv[2] if len(sys.argv) > 2 else None
+mixcsv = f"gpurun_out/pmcm_{mixtag}/a/a_counter_collection.csv" if mixtag else None
+if mixcsv and os.path.exists(mixcsv):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(mixcsv)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] = max(agg[k][r["Counter_Name"]], float(r["Counter_Value"]))
+    for k, c in agg.items():
+        out.setdefault(k, {})["wave_instructions_per_launch"] = {
+            "valu": int(c.get("SQ_INSTS_VALU", 0)), "salu": int(c.get("SQ_INSTS_SALU", 0)), "lds": int(c.get("SQ_INSTS_LDS", 0)),
+            "branch": int(c.get("SQ_INSTS_BRANCH", 0)), "vmem": int(c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)),
+            "note": "rocprofv3 --pmc SQ_INSTS_* (max over the launches of a profiled bench run = the 3-view launches)"}
 json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1)
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(open(f"{dst}/kernel_stats_top.txt").read())
