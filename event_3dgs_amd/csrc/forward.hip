@@ -658,17 +658,24 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
     const float pfx = (float)px;
-    // T[k] > 0: pixel live.  A finished (or out-of-image) pixel keeps -T, so "done" costs no flag register.
+    // Which pixels are still live is wave-level state: alive[k] holds, as a lane mask in an SGPR pair, the pixels of
+    // strip k that are inside the image and have not reached T < 1e-4.  The strip test ANDs it with one compare
+    // (no per-pixel "T > 0" compare per entry and strip), and a finished pixel simply leaves the mask.
     float pfy[4], T[4], C0[4], C1[4], C2[4];
     uint32_t last[4];
     bool inside[4];
+    unsigned long long alive[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int py = py0 + 4 * k;
         pfy[k] = (float)py;
         inside[k] = (px < W) && (py < H);
-        T[k] = inside[k] ? 1.0f : -1.0f;
+        T[k] = 1.0f;
+        alive[k] = __builtin_amdgcn_ballot_w64(inside[k]);
         C0[k] = C1[k] = C2[k] = 0.0f; last[k] = 0;
+        // (opaque to the compiler: it would otherwise re-materialise the int -> float conversion in every strip test of
+        // every entry to save four registers -- 4 of the ~50 VALU instructions per entry)
+        asm volatile("" : "+v"(pfy[k]));
     }
     uint2 range = ranges[tile];
     range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     if (WAVE + lane < n) id_next = emit_gid[perm[range.x + WAVE + lane]];
     if (2 * WAVE + lane < n) e_next2 = perm[range.x + 2 * WAVE + lane];
     for (int base = 0; base < n; base += WAVE) {
-        if (__builtin_amdgcn_ballot_w64(T[0] > 0.0f || T[1] > 0.0f || T[2] > 0.0f || T[3] > 0.0f) == 0) break;
+        if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0ull) break;
         const int cnt = min(WAVE, n - base);
         processed += cnt;
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
@@ -720,31 +727,34 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                 // wave-wide "any pixel of the strip live": compare intrinsics deliver the lane masks in SGPR pairs, so
                 // the test is 2 v_cmp + s_and + s_cbranch_scc (ballot(bool) costs two more VALU slots per strip);
                 // power > 0 (degenerate conic) is rejected by `valid` below
-                const unsigned long long live_mask = __builtin_amdgcn_fcmpf(T[k], 0.0f, 2 /* OGT */) &
-                                                     __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
+                const unsigned long long live_mask = alive[k] & __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
                 if (live_mask != 0ull) {
 #ifndef E3_NO_STRIP_MASK
                     sm[k] |= 1ull << j;
 #endif
-                    live_strips += 2;                    // cost model of tile_work below: an evaluated strip ~ 2 entries
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
-                    const bool valid = (T[k] > 0.0f) && !(power > 0.0f) && !(alpha < E3_ALPHA_SKIP);
+                    // lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255)
+                    const unsigned long long valid = alive[k] & __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE */) &
+                                                     __builtin_amdgcn_fcmpf(alpha, E3_ALPHA_SKIP, 11 /* UGE */);
                     const float w = alpha * T[k];
                     const float test_T = T[k] - w;
-                    const bool stop = valid && (test_T < E3_T_STOP);
-                    const bool apply = valid && !stop;
+                    const unsigned long long stop = valid & __builtin_amdgcn_fcmpf(test_T, E3_T_STOP, 4 /* OLT */);
+                    const bool apply = __builtin_amdgcn_inverse_ballot_w64(valid & ~stop);
                     // one select instead of five: a zero weight leaves C and T bit-unchanged (x + 0*c == x, x - 0 == x)
                     const float we = apply ? w : 0.0f;
                     C0[k] = FMA(b.z, we, C0[k]);
                     C1[k] = FMA(b.w, we, C1[k]);
                     C2[k] = FMA(c.x, we, C2[k]);
                     last[k] = apply ? contributor : last[k];
-                    const float Tn = T[k] - we;
-                    T[k] = stop ? -Tn : Tn;
+                    T[k] = T[k] - we;                     // a pixel that stops here keeps its T and leaves the mask
+                    alive[k] &= ~stop;
                 }
             }
         }
+        // (cost model of tile_work below: an evaluated strip ~ 2 entries)
+        live_strips += 2 * (__builtin_popcountll(sm[0]) + __builtin_popcountll(sm[1]) + __builtin_popcountll(sm[2]) +
+                            __builtin_popcountll(sm[3]));
 #ifndef E3_NO_STRIP_MASK
         if (lane < cnt) {
             const uint32_t mine = (__builtin_amdgcn_inverse_ballot_w64(sm[0]) ? 1u : 0u) |
@@ -756,8 +766,6 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
 #endif
         wave_sync();
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) T[k] = fabsf(T[k]);
     {
         // cost model of the backward walk over this tile: a fixed part per visited entry plus a part per
         // evaluated strip (measured: dense tiles cost ~2.4x more per entry than sparse ones)
