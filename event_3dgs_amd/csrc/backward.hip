@@ -23,9 +23,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
     float* __restrict__ part /* (I,12) per-instance records at their SLOTS: mx my A B C o c0 c1 c2 - - - */) {
-    __shared__ float4 sA[BWD_WAVES][WAVE];
-    __shared__ float4 sB[BWD_WAVES][WAVE];
-    __shared__ float4 sC[BWD_WAVES][WAVE];
+    // the 64 staged records of a round, 48 B each: one LDS address per entry, the three 16-B broadcasts are immediate
+    // offsets of it (three separate arrays cost two more address adds per entry); 48-B stride keeps the staging stores
+    // conflict-free (8 lanes x 16 B per LDS cycle land on 32 distinct banks)
+    struct StagedRec { float4 a, b, c; };
+    __shared__ StagedRec sRec[BWD_WAVES][WAVE];
     __shared__ uint32_t sId[BWD_WAVES][WAVE];       // emission index of the staged entries (where their record goes)
     // Gradient reduction through LDS.  DPP adds cost ~9 cycles per wave-instruction on this chip (plain adds 2.7),
     // so instead of a 54-op (or 26-op transposed) DPP butterfly the nine per-lane sums of an entry are transposed
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     if (2 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (2 * WAVE + lane))];
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
-        sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = re;
+        sRec[wave][lane].a = ra; sRec[wave][lane].b = rb; sRec[wave][lane].c = rc; sId[wave][lane] = re;
         const uint32_t mvec = lane < cnt ? rm : 0u;
         wave_sync();
         if (base + WAVE + lane < n) {
@@ -126,9 +128,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 const int j = jb + __builtin_ctz(ng);
                 ng &= ng - 1u;
                 const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)mvec, j);
-                const float4 a = sA[wave][j];
-                const float4 b = sB[wave][j];
-                const float4 c = sC[wave][j];
+                const float4 a = sRec[wave][j].a;
+                const float4 b = sRec[wave][j].b;
+                const float4 c = sRec[wave][j].c;
                 const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
                 const float dx = a.x - pfx;
                 // power(dy) = -(A dx^2 + C dy^2)/2 - B dx dy as a quadratic in dy (Horner: 2 FMAs per strip instead of the
@@ -166,8 +168,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                         asm volatile("" : "+v"(G));          // keep it here: the compiler would sink it into the branch
                         const unsigned long long hi = __builtin_amdgcn_fcmpf(power, c.z, 3 /* OGE */);
                         const unsigned long long nzp = __builtin_amdgcn_fcmpf(power, -1e-5f, 2 /* OGT */);
-                        unsigned long long keep = live & hi & ~nzp;
-                        const unsigned long long near = live & (~hi | nzp);
+                        const unsigned long long safe = hi & ~nzp;          // power in [pmin + 4e-4, -1e-5]: no recheck needed
+                        unsigned long long keep = live & safe;
+                        const unsigned long long near = live & ~safe;
                         if (near != 0ull) {                  // rare (<1 % of the live strips)
                             const float qf = FMA(b.x * dy, dy, (a.z * dx) * dx);
                             const float pf = FMA(-0.5f, qf, -((a.w * dx) * dy));
@@ -233,233 +236,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                     float4 p0 = hit ? sPart[wave][lane][0] : z4, p1 = hit ? sPart[wave][lane][1] : z4;
                     const float p2 = hit ? sPart[wave][lane][2].x : 0.0f;
                     // p0 = (Sx, Sy, Sxx, Sxy) / o   p1 = (Syy / o, So, Sc0, Sc1)   p2 = Sc2
-                    const float4 ea = sA[wave][e];
-                    const float4 eb = sB[wave][e];
+                    const float4 ea = sRec[wave][e].a;
+                    const float4 eb = sRec[wave][e].b;
                     p0.x *= eb.y; p0.y *= eb.y; p0.z *= eb.y; p0.w *= eb.y; p1.x *= eb.y;
-                    float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)sId[wave][e]);
-                    // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
-                    g[0] = make_float4(-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy,
-                                       -0.5f * p0.z, -p0.w);
-                    g[1] = make_float4(-0.5f * p1.x, p1.y, p1.z, p1.w);
-                    g[2] = make_float4(p2, 0.0f, 0.0f, 0.0f);
-                }
-                wave_sync();
-            }
-        }
-        wave_sync();
-    }
-    // list entries behind the last contributor of every pixel are never walked: zero records
-    for (uint32_t e = range.x + (uint32_t)n + (uint32_t)lane; e < range.y; e += WAVE) {
-        float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)perm[e]);
-        const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        g[0] = z4; g[1] = z4; g[2] = z4;
-    }
-    if (trace && lane == 0) {
-        trace[4 * (size_t)tile + 0] = t_start;
-        trace[4 * (size_t)tile + 1] = wall_clock64();
-        trace[4 * (size_t)tile + 2] = ((unsigned long long)(range.y - range.x) << 32) | (unsigned)n;
-        trace[4 * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
-                                      (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-        (void)t_loop;
-    }
-}
-
-__global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel_v1(
-    unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
-    int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
-    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const uint32_t* __restrict__ perm, const float* __restrict__ dL_dpix,
-    float* __restrict__ part /* (I,12) per-instance records at their SLOTS: mx my A B C o c0 c1 c2 - - - */) {
-    __shared__ float4 sA[BWD_WAVES][WAVE];
-    __shared__ float4 sB[BWD_WAVES][WAVE];
-    __shared__ float4 sC[BWD_WAVES][WAVE];
-    __shared__ uint32_t sId[BWD_WAVES][WAVE];       // emission index of the staged entries (where their record goes)
-    // Gradient reduction through LDS.  DPP adds cost ~9 cycles per wave-instruction on this chip (plain adds 2.7),
-    // so instead of a 54-op (or 26-op transposed) DPP butterfly the nine per-lane sums of an entry are transposed
-    // through the wave's LDS slice: 9 conflict-free ds_write_b32, then lane (v,p) = (lane>>3, lane&7) reads the 8
-    // floats [8p,8p+8) of value v as two ds_read_b128 and adds them, and three DPP steps finish the 8-lane groups.
-    // The LDS pipe is otherwise idle in this kernel.  Reduced sums are parked in sPart and committed every 16
-    // entries by lanes 0..15 as three 16-byte stores into the instance's own record (no atomics: the per-Gaussian
-    // sum over its instances happens in geom_bwd_kernel, in a fixed order -> deterministic gradients).
-    __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][9][68];        // per-entry transpose buffer: [value][lane], rows padded to 68
-    __shared__ float4 sPart[BWD_WAVES][16][3];      // [entry & 15][12 floats]: reduced sums parked until the commit
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * BWD_WAVES + wave;
-    if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
-    const int tile = (int)order[unit];          // global tile id: view * tiles_per_view + local tile
-    if (tile < 0) return;
-    const unsigned long long t_start = trace ? wall_clock64() : 0ull;
-    const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
-    const int tx = ltile % gx, ty = ltile / gx;
-    const int px = tx * E3_TILE + (lane & 15);
-    const int py0 = ty * E3_TILE + (lane >> 4);
-    const float pfx = (float)px;
-    const size_t HW = (size_t)H * W;
-    final_T += (size_t)view * HW;               // per-view planes of the batch
-    n_contrib += (size_t)view * HW;
-    dL_dpix += (size_t)view * 3 * HW;           // (nviews, 3, H, W)
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-
-    // Per-pixel state of the back-to-front walk.  With C = sum_j c_j a_j T_j + T_final bg and
-    // T_j = prod_{i<j}(1 - a_i):   dC/da_g = c_g T_g - (sum_{j>g} c_j a_j T_j + T_final bg) / (1 - a_g).
-    // Contracting with dL/dC first leaves ONE scalar running sum per pixel,
-    //   Q_g = T_final (bg . dL/dC) + sum_{j>g} a_j T_j (c_j . dL/dC),
-    // instead of the reference's accumulated colour / last colour / last alpha (7 registers -> 1).
-    float pfy[4], T[4], Q[4], dp0[4], dp1[4], dp2[4];
-    uint32_t last[4];
-    uint32_t maxc = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int py = py0 + 4 * k;
-        pfy[k] = (float)py;
-        bool inside = (px < W) && (py < H);
-        size_t pix = (size_t)py * W + px;
-        T[k] = inside ? final_T[pix] : 0.0f;
-        last[k] = inside ? n_contrib[pix] : 0u;
-        dp0[k] = inside ? dL_dpix[pix] : 0.0f;
-        dp1[k] = inside ? dL_dpix[HW + pix] : 0.0f;
-        dp2[k] = inside ? dL_dpix[2 * HW + pix] : 0.0f;
-        Q[k] = T[k] * FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
-        maxc = last[k] > maxc ? last[k] : maxc;
-    }
-    maxc = wave_max_u32(maxc);
-    const uint2 range = ranges[tile];
-    const int n = (int)maxc;   // entries [0, n) of the tile list can contribute
-    const unsigned long long t_loop = trace ? wall_clock64() : 0ull;
-
-    // walk entries n-1 ... 0; round r covers list positions n-1-r*64-lane
-    // staging pipeline as in the forward kernel (three deep: emission index -> Gaussian id -> record)
-    float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0), rc = make_float4(0, 0, 0, 0);
-    uint32_t re = 0, e_next = 0, id_next = 0, e_next2 = 0;
-    if (lane < n) {
-        re = perm[range.x + (uint32_t)(n - 1 - lane)];
-        const uint32_t rid = emit_gid[re];
-        ra = rec[3 * (size_t)rid]; rb = rec[3 * (size_t)rid + 1]; rc = rec[3 * (size_t)rid + 2];
-    }
-    if (WAVE + lane < n) {
-        e_next = perm[range.x + (uint32_t)(n - 1 - (WAVE + lane))];
-        id_next = emit_gid[e_next];
-    }
-    if (2 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (2 * WAVE + lane))];
-    for (int base = 0; base < n; base += WAVE) {
-        const int cnt = min(WAVE, n - base);
-        sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc; sId[wave][lane] = re;
-        wave_sync();
-        if (base + WAVE + lane < n) {
-            re = e_next;
-            ra = rec[3 * (size_t)id_next]; rb = rec[3 * (size_t)id_next + 1]; rc = rec[3 * (size_t)id_next + 2];
-        }
-        if (base + 2 * WAVE + lane < n) { e_next = e_next2; id_next = emit_gid[e_next2]; }
-        if (base + 3 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (base + 3 * WAVE + lane))];
-        unsigned long long touched = 0ull;
-        for (int j = 0; j < cnt; ++j) {
-            const float4 a = sA[wave][j];
-            const float4 b = sB[wave][j];
-            const float4 c = sC[wave][j];
-            const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
-            const float dx = a.x - pfx;
-            // power(dy) = -(A dx^2 + C dy^2)/2 - B dx dy as a quadratic in dy (Horner: 2 FMAs per strip instead of the
-            // forward's 4-op expression, whose rounding order only the bit-exact forward has to keep)
-            const float h0 = -0.5f * (a.z * dx) * dx;     // -A dx^2 / 2
-            const float h1 = -(a.w * dx);                 // -B dx
-            const float h2 = -0.5f * b.x;                 // -C / 2
-            // per-lane partial sums over its (up to) 4 pixels; h = dL/dG * G
-            //   Sx = sum h dx, Sy = sum h dy, Sxx = sum h dx^2, Sxy = sum h dx dy, Syy = sum h dy^2,
-            //   So = sum G dL/dalpha, Sc* = sum alpha T dL/dC*
-            float Sx = 0.0f, Sy = 0.0f, Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, So = 0.0f, Sc0 = 0.0f, Sc1 = 0.0f, Sc2 = 0.0f;
-            unsigned long long any = 0ull;              // lanes that composited this entry at one of their pixels
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dy = a.y - pfy[k];
-                const float power = FMA(FMA(h2, dy, h1), dy, h0);
-                // All decisions are lane masks in SGPR pairs (compare intrinsics) combined with scalar ops; the one
-                // divergent branch takes its mask through inverse_ballot (an s_and_saveexec, no VALU).
-                // c.y = pmin: below it alpha < 1/255 whatever the rounding (preprocess_kernel)
-                const unsigned long long live = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
-                                                __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
-                if (live != 0ull) {
-                    // The two skip decisions (alpha < 1/255, power > 0) are discontinuities, and the forward took them
-                    // with ITS arithmetic (its rounding order of `power`, the polynomial exp).  Away from the
-                    // thresholds the outcome cannot depend on that: power >= c.z = pmin + 4e-4 keeps, power <= -1e-5
-                    // is not positive.  Inside the bands the forward's own computation is redone, so that backward
-                    // differentiates exactly the set of (pixel, Gaussian) pairs the forward composited.
-                    // hardware exp2 (1 ulp) instead of the forward's bit-reproducible polynomial: the VALUES of
-                    // backward are tolerance-checked, and 2 issue slots replace 10 on the most executed path.
-                    // Issued before the mask algebra so that its latency overlaps the compares.
-                    float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-                    asm volatile("" : "+v"(G));          // keep it here: the compiler would sink it into the branch
-                    const unsigned long long hi = __builtin_amdgcn_fcmpf(power, c.z, 3 /* OGE */);
-                    const unsigned long long nz = __builtin_amdgcn_fcmpf(power, -1e-5f, 2 /* OGT */);
-                    unsigned long long keep = live & hi & ~nz;
-                    const unsigned long long near = live & (~hi | nz);
-                    if (near != 0ull) {                  // rare (<1 % of the live strips)
-                        const float qf = FMA(b.x * dy, dy, (a.z * dx) * dx);
-                        const float pf = FMA(-0.5f, qf, -((a.w * dx) * dy));
-                        const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(pf));
-                        keep |= near & __builtin_amdgcn_fcmpf(pf, 0.0f, 13 /* ULE: !(pf > 0) */) &
-                                __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
-                    }
-                    any |= keep;
-                    if (__builtin_amdgcn_inverse_ballot_w64(keep)) {
-                        const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
-                        // 1-ulp v_rcp_f32
-                        const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
-                        T[k] = T[k] * inv_one_m;                        // transmittance in front of this entry
-                        const float cd = FMA(b.z, dp0[k], FMA(b.w, dp1[k], c.x * dp2[k]));
-                        const float w = alpha * T[k];
-                        const float dL_dalpha = FMA(T[k], cd, -(Q[k] * inv_one_m));
-                        Q[k] = FMA(w, cd, Q[k]);
-                        Sc0 = FMA(w, dp0[k], Sc0);
-                        Sc1 = FMA(w, dp1[k], Sc1);
-                        Sc2 = FMA(w, dp2[k], Sc2);
-                        So = FMA(G, dL_dalpha, So);
-                        const float h = (b.y * dL_dalpha) * G;          // straight-through min(0.99, .)
-                        const float hx = h * dx, hy = h * dy;
-                        Sx += hx; Sy += hy;
-                        Sxx = FMA(hx, dx, Sxx); Sxy = FMA(hx, dy, Sxy); Syy = FMA(hy, dy, Syy);
-                    }
-                }
-            }
-            if (any != 0ull) {
-                touched |= 1ull << j;
-                float* r = &sRed[wave][0][0];
-                r[0 * 68 + lane] = Sx;  r[1 * 68 + lane] = Sy;  r[2 * 68 + lane] = Sxx;
-                r[3 * 68 + lane] = Sxy; r[4 * 68 + lane] = Syy; r[5 * 68 + lane] = So;
-                r[6 * 68 + lane] = Sc0; r[7 * 68 + lane] = Sc1; r[8 * 68 + lane] = Sc2;
-                wave_sync();
-                const int rv = lane >> 3, rp = lane & 7;
-                const float4 q0 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp);
-                const float4 q1 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp + 4);
-                float s = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
-                float s8 = 0.0f;
-                if (lane < 8) {
-                    const float4 a0 = *reinterpret_cast<const float4*>(r + 8 * 68 + 8 * lane);
-                    const float4 a1 = *reinterpret_cast<const float4*>(r + 8 * 68 + 8 * lane + 4);
-                    s8 = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
-                }
-                s += dpp_f<DPP_QUAD_XOR1>(s);  s8 += dpp_f<DPP_QUAD_XOR1>(s8);
-                s += dpp_f<DPP_QUAD_XOR2>(s);  s8 += dpp_f<DPP_QUAD_XOR2>(s8);
-                s += dpp_f<0x141>(s);          s8 += dpp_f<0x141>(s8);            // row_half_mirror: the other quad
-                float* pe = reinterpret_cast<float*>(&sPart[wave][j & 15][0]);
-                if (rp == 0) pe[rv] = s;                 // slots 0..7 = Sx Sy Sxx Sxy Syy So Sc0 Sc1
-                if (lane == 0) pe[8] = s8;               // slot 8 = Sc2
-                wave_sync();
-            }
-            if ((j & 15) == 15 || j == cnt - 1) {
-                // commit the (up to) 16 entries parked since the last commit
-                const int jb = j & ~15;
-                wave_sync();
-                if (lane < 16 && jb + lane < cnt) {
-                    const int e = jb + lane;
-                    // entries no pixel of the tile used still get a (zero) record: grad_acc needs no pre-zeroing
-                    const bool hit = ((touched >> e) & 1ull) != 0ull;
-                    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    const float4 p0 = hit ? sPart[wave][lane][0] : z4, p1 = hit ? sPart[wave][lane][1] : z4;
-                    const float p2 = hit ? sPart[wave][lane][2].x : 0.0f;
-                    // p0 = (Sx, Sy, Sxx, Sxy)   p1 = (Syy, So, Sc0, Sc1)   p2 = Sc2
-                    const float4 ea = sA[wave][e];
-                    const float4 eb = sB[wave][e];
                     float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)sId[wave][e]);
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
                     g[0] = make_float4(-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy,
@@ -1214,16 +993,6 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
         const int nslots = launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, img.work, img.order_bwd, s);
-#ifdef E3_NO_STRIP_MASK
-        static const int use_v1 = 1;
-#else
-        static const int use_v1 = [] { const char* e = getenv("E3DGS_BWD_V1"); return e ? atoi(e) : 0; }();
-#endif
-        if (use_v1 == 1)
-            render_bwd_kernel_v1<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-                g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-                background, img.final_T, img.n_contrib, bin.perm, dL_dpix, grad_acc);
-        else
         render_bwd_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
             g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
             background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc);

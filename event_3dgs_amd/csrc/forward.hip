@@ -729,9 +729,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                 // power > 0 (degenerate conic) is rejected by `valid` below
                 const unsigned long long live_mask = alive[k] & __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
                 if (live_mask != 0ull) {
-#ifndef E3_NO_STRIP_MASK
                     sm[k] |= 1ull << j;
-#endif
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     // lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255)
@@ -755,7 +753,6 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
         // (cost model of tile_work below: an evaluated strip ~ 2 entries)
         live_strips += 2 * (__builtin_popcountll(sm[0]) + __builtin_popcountll(sm[1]) + __builtin_popcountll(sm[2]) +
                             __builtin_popcountll(sm[3]));
-#ifndef E3_NO_STRIP_MASK
         if (lane < cnt) {
             const uint32_t mine = (__builtin_amdgcn_inverse_ballot_w64(sm[0]) ? 1u : 0u) |
                                   (__builtin_amdgcn_inverse_ballot_w64(sm[1]) ? 2u : 0u) |
@@ -763,7 +760,6 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                                   (__builtin_amdgcn_inverse_ballot_w64(sm[3]) ? 8u : 0u);
             strip_mask[range.x + base + lane] = (uint8_t)mine;
         }
-#endif
         wave_sync();
     }
     {
