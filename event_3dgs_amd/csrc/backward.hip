@@ -39,6 +39,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][9][68];        // per-entry transpose buffer: [value][lane], rows padded to 68
     __shared__ float4 sPart[BWD_WAVES][16][3];      // [entry & 15][12 floats]: reduced sums parked until the commit
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) f4_t LdsF4;
+    // LDS byte address of this wave's staged records, as a scalar (the per-entry address is then scalar arithmetic)
+    const uint32_t recs_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)&sRec[wave][0].a.x);
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
     const int tile = __builtin_amdgcn_readfirstlane((int)order[unit]);   // global tile id (made scalar: see render_fwd_kernel)
@@ -128,9 +133,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 const int j = jb + __builtin_ctz(ng);
                 ng &= ng - 1u;
                 const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)mvec, j);
-                const float4 a = sRec[wave][j].a;
-                const float4 b = sRec[wave][j].b;
-                const float4 c = sRec[wave][j].c;
+                // (32-bit LDS pointer arithmetic: through the generic pointer the compiler forms the address with a 64-bit mad)
+                LdsF4* vp = (LdsF4*)(uintptr_t)(recs_base + 48u * (uint32_t)j);
+                const f4_t va = vp[0], vb = vp[1], vc = vp[2];
+                const float4 a = make_float4(va.x, va.y, va.z, va.w);
+                const float4 b = make_float4(vb.x, vb.y, vb.z, vb.w);
+                const float4 c = make_float4(vc.x, vc.y, vc.z, vc.w);
                 const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
                 const float dx = a.x - pfx;
                 // power(dy) = -(A dx^2 + C dy^2)/2 - B dx dy as a quadratic in dy (Horner: 2 FMAs per strip instead of the
