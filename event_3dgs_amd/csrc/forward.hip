@@ -257,19 +257,22 @@ __device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float 
     const float pxl = (float)(tx * E3_TILE), pyl = (float)(ty * E3_TILE);
     const float dxlo = x0 - (pxl + (float)(E3_TILE - 1)), dxhi = x0 - pxl;
     const float dylo = y0 - (pyl + (float)(E3_TILE - 1)), dyhi = y0 - pyl;
-    float qmin = 0.0f;
-    if (!(dxlo <= 0.0f && dxhi >= 0.0f && dylo <= 0.0f && dyhi >= 0.0f)) {
-        const float B2 = 2.0f * B;
-        auto qadj = [&](float dx, float dy) {
-            float t0 = A * dx * dx, t1 = B2 * dx * dy, t2 = C * dy * dy;
-            return (t0 + t1 + t2) - 1e-4f * (fabsf(t0) + fabsf(t1) + fabsf(t2));
-        };
-        float q0 = qadj(dxlo, fminf(dyhi, fmaxf(dylo, iC * dxlo)));
-        float q1 = qadj(dxhi, fminf(dyhi, fmaxf(dylo, iC * dxhi)));
-        float q2 = qadj(fminf(dxhi, fmaxf(dxlo, iA * dylo)), dylo);
-        float q3 = qadj(fminf(dxhi, fmaxf(dxlo, iA * dyhi)), dyhi);
-        qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-    }
+    // q is convex with its minimum (0) at d = 0.  With the centre outside the box the minimum over the box lies on an edge
+    // that FACES the centre -- walking from any point of a far edge towards the centre lowers q and crosses a near edge
+    // first -- so at most two of the four edges need their 1-D clamped minimiser evaluated (half the instructions of
+    // the four-edge form; this test is ~45 % of the binning passes' VALU work).
+    const bool out_x = dxlo > 0.0f || dxhi < 0.0f, out_y = dylo > 0.0f || dyhi < 0.0f;
+    const float ex = dxlo > 0.0f ? dxlo : dxhi;          // the x-edge nearest to the centre (meaningful if out_x)
+    const float ey = dylo > 0.0f ? dylo : dyhi;
+    const float B2 = 2.0f * B;
+    auto qadj = [&](float dx, float dy) {
+        float t0 = A * dx * dx, t1 = B2 * dx * dy, t2 = C * dy * dy;
+        return (t0 + t1 + t2) - 1e-4f * (fabsf(t0) + fabsf(t1) + fabsf(t2));
+    };
+    const float qx = qadj(ex, fminf(dyhi, fmaxf(dylo, iC * ex)));
+    const float qy = qadj(fminf(dxhi, fmaxf(dxlo, iA * ey)), ey);
+    // centre inside the box in both axes -> 0; an axis whose range contains the centre has no facing edge
+    const float qmin = fminf(out_x ? qx : (out_y ? INFINITY : 0.0f), out_y ? qy : (out_x ? INFINITY : 0.0f));
     return !(qmin > thr);
 }
 
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
         uint32_t t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    const uint32_t total = __shfl(incl, 63, 64);
+    // (made scalar explicitly: a trip count that sits in a VGPR makes the candidate loop a divergent loop)
+    const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
     sA[wave][lane] = a; sB[wave][lane] = b; sIncl[wave][lane] = incl; sId[wave][lane] = g;
     {
         const uint32_t tbase = nviews > 1 ? (g % (uint32_t)nviews) * (uint32_t)ntiles : 0u;
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     wave_sync();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t count = 0;
-    const uint32_t out_base = EMIT ? wave_offsets[gw] : 0u;
+    const uint32_t out_base = EMIT ? __builtin_amdgcn_readfirstlane(wave_offsets[gw]) : 0u;
     for (uint32_t m0 = 0; m0 < total; m0 += WAVE) {
         const uint32_t m = m0 + lane;
         const bool active = m < total;

@@ -1,0 +1,11 @@
+REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_threads; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-include-regex "render_(fwd|bwd)_kernel" -d $OUT/a -o a --output-format csv -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-substep > $OUT/a.log 2>&1
+python - <<PY
+import csv,collections,glob
+for f in sorted(glob.glob("$OUT/*/*_counter_collection.csv")):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[(r['Kernel_Name'][:17],r['Counter_Name'])].append(float(r['Counter_Value']))
+    for k,v in sorted(agg.items()): print(k[0], k[1], len(v), "max", round(max(v)))
+PY
+tail -3 $OUT/a.log
