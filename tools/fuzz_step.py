@@ -45,10 +45,17 @@ def check(seed):
     gts = [q8(t.render_raw(c, bg)["color"]) for c in cams]
     blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
     a, b = EventTrainer(params, DEV, active_sh_degree=deg), EventTrainer(params, DEV, active_sh_degree=deg)
-    sa = a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+    a2 = EventTrainer(params, DEV, active_sh_degree=deg)
+    # a: gradients in memory, then the optimizer; a2: step() as training runs it (SH gradient rebuilt inside the SH
+    # optimizer kernel, never stored) -- must land on the same parameters bit for bit
+    sa = a.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur).clone()
+    a.apply_update()
+    a2.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
     lb = b.step_autograd(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
     torch.cuda.synchronize()
     problems = []
+    if not (torch.equal(a.flat, a2.flat) and torch.equal(a.exp_avg, a2.exp_avg) and torch.equal(a.exp_avg_sq, a2.exp_avg_sq)):
+        problems.append("step() differs from compute_gradients() + apply_update()")
     # The two trainers differ by <= 1 ulp in the activations (kernel vs torch); the rasteriser is discontinuous at its
     # alpha >= 1/255 threshold, so a few pixels on a splat's outline may flip -- with a handful of Gaussians that is
     # visible at the 1e-3 level, with hundreds it is not.
