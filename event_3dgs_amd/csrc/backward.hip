@@ -37,7 +37,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     // entries by lanes 0..15 as three 16-byte stores into the instance's own record (no atomics: the per-Gaussian
     // sum over its instances happens in geom_bwd_kernel, in a fixed order -> deterministic gradients).
     __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][9][68];        // per-entry transpose buffer: [value][lane], rows padded to 68
-    __shared__ float4 sPart[BWD_WAVES][16][3];      // [entry & 15][12 floats]: reduced sums parked until the commit
+    __shared__ __attribute__((aligned(16))) float sPart[BWD_WAVES][16][16];     // [entry & 15][16 floats]: reduced sums parked until the commit
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4_t LdsF4;
@@ -209,27 +209,30 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 if (any != 0ull) {
                     touched |= 1ull << j;
                     float* r = &sRed[wave][0][0];
+                    float* part_base_ptr = &sPart[wave][0][0];
                     const float Sx = dx * So;                  // all of these still lack the factor o (commit)
                     r[0 * 68 + lane] = Sx;  r[1 * 68 + lane] = Uy;  r[2 * 68 + lane] = dx * Sx;
                     r[3 * 68 + lane] = dx * Uy; r[4 * 68 + lane] = Uyy; r[5 * 68 + lane] = So;
                     r[6 * 68 + lane] = Sc0; r[7 * 68 + lane] = Sc1; r[8 * 68 + lane] = Sc2;
                     wave_sync();
+                    // lane (v, p) = (lane >> 3, lane & 7) adds the 8 floats [8p, 8p + 8) of value v (two ds_read_b128) and ONE
+                    // float of the ninth value (Sc2): its 64 floats are spread over all lanes instead of a masked second
+                    // pass by eight of them.  Three fused DPP adds finish the 8-lane groups (the last one is a row
+                    // shift: only the group's first lane, which does the write, needs the right partner); the
+                    // eight per-group partials of Sc2 are added by the commit lanes.
                     const int rv = lane >> 3, rp = lane & 7;
                     const float4 q0 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp);
                     const float4 q1 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp + 4);
+                    float s8 = r[8 * 68 + lane];
                     float s = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
-                    float s8 = 0.0f;
-                    if (lane < 8) {
-                        const float4 a0 = *reinterpret_cast<const float4*>(r + 8 * 68 + 8 * lane);
-                        const float4 a1 = *reinterpret_cast<const float4*>(r + 8 * 68 + 8 * lane + 4);
-                        s8 = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
-                    }
                     s += dpp_f<DPP_QUAD_XOR1>(s);  s8 += dpp_f<DPP_QUAD_XOR1>(s8);
                     s += dpp_f<DPP_QUAD_XOR2>(s);  s8 += dpp_f<DPP_QUAD_XOR2>(s8);
-                    s += dpp_f<0x141>(s);          s8 += dpp_f<0x141>(s8);            // row_half_mirror: the other quad
-                    float* pe = reinterpret_cast<float*>(&sPart[wave][j & 15][0]);
-                    if (rp == 0) pe[rv] = s;                 // slots 0..7 = Sx Sy Sxx Sxy Syy So Sc0 Sc1
-                    if (lane == 0) pe[8] = s8;               // slot 8 = Sc2
+                    s += dpp_bc_f<DPP_ROW_SHL4>(s); s8 += dpp_bc_f<DPP_ROW_SHL4>(s8);  // lanes 0-3 / 8-11 of a row: + the next quad
+                    asm volatile("" : "+v"(s), "+v"(s8));     // keep the adds here (fused v_add_f32_dpp) instead of sunk behind the branch
+                    if (rp == 0) {                           // slots 0..7 = Sx Sy Sxx Sxy Syy So Sc0 Sc1, 8..15 = partials of Sc2
+                        float* pe = reinterpret_cast<float*>(part_base_ptr + (size_t)(j & 15) * 16);
+                        pe[rv] = s; pe[8 + rv] = s8;
+                    }
                     wave_sync();
                 }
             }
@@ -241,8 +244,10 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                     // entries no pixel of the tile used still get a (zero) record: grad_acc needs no pre-zeroing
                     const bool hit = ((touched >> e) & 1ull) != 0ull;
                     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    float4 p0 = hit ? sPart[wave][lane][0] : z4, p1 = hit ? sPart[wave][lane][1] : z4;
-                    const float p2 = hit ? sPart[wave][lane][2].x : 0.0f;
+                    const float4* pp = reinterpret_cast<const float4*>(&sPart[wave][lane][0]);
+                    float4 p0 = hit ? pp[0] : z4, p1 = hit ? pp[1] : z4;
+                    const float4 c0 = pp[2], c1 = pp[3];
+                    const float p2 = hit ? ((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w)) : 0.0f;
                     // p0 = (Sx, Sy, Sxx, Sxy) / o   p1 = (Syy / o, So, Sc0, Sc1)   p2 = Sc2
                     const float4 ea = sRec[wave][e].a;
                     const float4 eb = sRec[wave][e].b;

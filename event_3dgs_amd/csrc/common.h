@@ -94,11 +94,17 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // ---- DPP helpers (wave64 = 4 rows of 16 lanes; quad = 4 lanes)
 #define DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
 #define DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
-#define DPP_ROW_ROR4 0x124   // row_ror:4
+#define DPP_ROW_SHL4 0x104   // row_shl:4: lane i reads lane i + 4 of its row of 16 (0 past the row end with bound_ctrl)
 #define DPP_ROW_ROR8 0x128   // row_ror:8
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// bound_ctrl:1 form: for controls that read a valid lane everywhere (rotations) the result is the same, and the compiler
+// may fold the move into the consuming add (v_add_f32_dpp: one instruction instead of v_mov + v_mov_dpp + v_add)
+template <int CTRL>
+__device__ __forceinline__ float dpp_bc_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
