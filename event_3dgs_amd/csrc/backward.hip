@@ -22,7 +22,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
-    float* __restrict__ part /* (I,12) per-instance records at their SLOTS: mx my A B C o c0 c1 c2 - - - */) {
+    float* __restrict__ part /* (I,9) per-instance records at their SLOTS, packed: mx my A B C o c0 c1 c2 */) {
     // the 64 staged records of a round, 48 B each: one LDS address per entry, the three 16-B broadcasts are immediate
     // offsets of it (three separate arrays cost two more address adds per entry); 48-B stride keeps the staging stores
     // conflict-free (8 lanes x 16 B per LDS cycle land on 32 distinct banks)
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4_t LdsF4;
+    struct F3 { float x, y, z; };               // 12-byte store unit of the packed 36-byte records (4-byte aligned)
     // LDS byte address of this wave's staged records, as a scalar (the per-entry address is then scalar arithmetic)
     const uint32_t recs_base = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)&sRec[wave][0].a.x);
@@ -252,12 +253,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                     const float4 ea = sRec[wave][e].a;
                     const float4 eb = sRec[wave][e].b;
                     p0.x *= eb.y; p0.y *= eb.y; p0.z *= eb.y; p0.w *= eb.y; p1.x *= eb.y;
-                    float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)sId[wave][e]);
+                    F3* g = reinterpret_cast<F3*>(part + E3_REC_FLOATS * (size_t)sId[wave][e]);
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
-                    g[0] = make_float4(-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy,
-                                       -0.5f * p0.z, -p0.w);
-                    g[1] = make_float4(-0.5f * p1.x, p1.y, p1.z, p1.w);
-                    g[2] = make_float4(p2, 0.0f, 0.0f, 0.0f);
+                    g[0] = F3{-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy, -0.5f * p0.z};
+                    g[1] = F3{-p0.w, -0.5f * p1.x, p1.y};
+                    g[2] = F3{p1.z, p1.w, p2};
                 }
                 wave_sync();
             }
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     }
     // list entries behind the last contributor of every pixel are never walked: zero records
     for (uint32_t e = range.x + (uint32_t)n + (uint32_t)lane; e < range.y; e += WAVE) {
-        float4* g = reinterpret_cast<float4*>(part + E3_ACC_STRIDE * (size_t)perm[e]);
-        const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        g[0] = z4; g[1] = z4; g[2] = z4;
+        F3* g = reinterpret_cast<F3*>(part + E3_REC_FLOATS * (size_t)perm[e]);
+        const F3 z3 = F3{0.0f, 0.0f, 0.0f};
+        g[0] = z3; g[1] = z3; g[2] = z3;
     }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;
@@ -390,45 +390,61 @@ __device__ __forceinline__ void build_cov3(const float sact[3], float scale_modi
 }
 
 // Per-splat sums of the per-instance gradient records.  A splat's records sit contiguously at its emission
-// positions, so the 256 depth-consecutive splats of a workgroup own ONE contiguous slot range: it is streamed
-// through LDS with fully coalesced 16-byte loads (256 records per chunk) and every thread adds the records of
-// its own run from LDS, in slot order (fixed order -> deterministic).  Output: 3 float4 per splat at its INDEX
-// q, (mx my A B | C o c0 c1 | c2 - - -), which the per-Gaussian kernels then read coalesced.
-constexpr int RR_CHUNK = 256;
+// positions, so the 64 depth-consecutive splats of a WAVE own one contiguous slot range: the wave streams it through
+// its private LDS slice with coalesced 16-byte loads (128 packed 36-byte records per chunk; no workgroup barrier, the
+// four waves of a workgroup run independently) and every lane adds the records of its own run from LDS, in slot
+// order (fixed order -> deterministic).  Output: 3 float4 per splat at its INDEX q,
+// (mx my A B | C o c0 c1 | c2 - - -), which the per-Gaussian kernels then read coalesced.
+constexpr int RR_CHUNK = 128;
+constexpr int RR_SLICE = (RR_CHUNK * E3_REC_FLOATS + 3 + 3) / 4 + 1;     // float4s: chunk + misalignment of its first float
 __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint32_t* __restrict__ order,
                                                          const uint2* __restrict__ run_sorted,
                                                          const float* __restrict__ part, float4* __restrict__ gsum) {
-    __shared__ float4 sbuf[3 * RR_CHUNK];
-    __shared__ uint32_t sRange[2];
-    const uint32_t t = threadIdx.x, j0 = blockIdx.x * 256u, j = j0 + t;
-    const uint32_t jlast = (Q < j0 + 256u ? Q : j0 + 256u) - 1u;
+    __shared__ float4 sbuf[4][(RR_SLICE + 63) / 64 * 64];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t j0 = blockIdx.x * 256u + wave * 64u, j = j0 + lane;
+    if (j0 >= Q) return;
+    const uint32_t nl = (Q - j0 < 64u ? Q - j0 : 64u) - 1u;          // last lane with a splat
     const uint2 rn = j < Q ? run_sorted[j] : make_uint2(0u, 0u);
-    if (t == 0) sRange[0] = rn.x;
-    if (j == jlast) sRange[1] = rn.x + rn.y;
-    __syncthreads();
-    const uint32_t S0 = sRange[0], S1 = sRange[1];
-    float4 a0 = make_float4(0, 0, 0, 0), a1 = make_float4(0, 0, 0, 0);
-    float a2 = 0.0f;
+    const uint32_t S0 = __builtin_amdgcn_readfirstlane(rn.x);
+    const uint32_t S1 = __builtin_amdgcn_readlane(rn.x + rn.y, nl);
+    float a[E3_REC_FLOATS];
+#pragma unroll
+    for (int k = 0; k < E3_REC_FLOATS; ++k) a[k] = 0.0f;
     const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part);
+    float4* sb4 = sbuf[wave];
+    const float* sb = reinterpret_cast<const float*>(sb4);
+    const uint32_t end = rn.x + rn.y;
     for (uint32_t c0 = S0; c0 < S1; c0 += RR_CHUNK) {
         const uint32_t nrec = (S1 - c0 < (uint32_t)RR_CHUNK) ? S1 - c0 : (uint32_t)RR_CHUNK;
-        for (uint32_t i = t; i < 3u * nrec; i += 256u) sbuf[i] = p4[3 * (size_t)c0 + i];
-        __syncthreads();
+        const uint32_t f0 = E3_REC_FLOATS * c0, a0 = f0 & ~3u;                     // first float, aligned down to 16 B
+        const uint32_t n4 = (E3_REC_FLOATS * (c0 + nrec) - a0 + 3u) >> 2;          // float4s to stage (reads < 16 B past the last record: slack)
+        const float4* __restrict__ src = p4 + (size_t)(a0 >> 2);
+        constexpr int NLD = (RR_SLICE + 63) / 64;
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {                     // all loads of the chunk in flight before the first LDS store
+            const uint32_t i = lane + 64u * k;              // (unconditional, index clamped: a predicated load serialises)
+            v[k] = src[i < n4 ? i : n4 - 1u];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) sb4[lane + 64u * k] = v[k];     // unconditional too (the slice holds NLD * 64 float4)
+        wave_sync();
         const uint32_t lo = rn.x > c0 ? rn.x : c0;
-        const uint32_t end = rn.x + rn.y, cend = c0 + nrec;
+        const uint32_t cend = c0 + nrec;
         const uint32_t hi = end < cend ? end : cend;
         for (uint32_t r = lo; r < hi; ++r) {
-            const float4 s0 = sbuf[3 * (r - c0)], s1 = sbuf[3 * (r - c0) + 1];
-            const float s2 = sbuf[3 * (r - c0) + 2].x;
-            a0.x += s0.x; a0.y += s0.y; a0.z += s0.z; a0.w += s0.w;
-            a1.x += s1.x; a1.y += s1.y; a1.z += s1.z; a1.w += s1.w;
-            a2 += s2;
+            const float* q = sb + (E3_REC_FLOATS * r - a0);
+#pragma unroll
+            for (int k = 0; k < E3_REC_FLOATS; ++k) a[k] += q[k];
         }
-        __syncthreads();
+        wave_sync();
     }
     if (j < Q) {              // zeros for splats whose every tile was culled (their radius can still be > 0)
         const size_t q = order[j];
-        gsum[3 * q] = a0; gsum[3 * q + 1] = a1; gsum[3 * q + 2] = make_float4(a2, 0.0f, 0.0f, 0.0f);
+        gsum[3 * q] = make_float4(a[0], a[1], a[2], a[3]);
+        gsum[3 * q + 1] = make_float4(a[4], a[5], a[6], a[7]);
+        gsum[3 * q + 2] = make_float4(a[8], 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -442,13 +458,11 @@ __global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const 
     const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (j >= Q) return;
     const uint2 rn = run_sorted[j];
-    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part) + 3 * (size_t)rn.x;
+    const float* __restrict__ p = part + E3_REC_FLOATS * (size_t)rn.x;
     float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t r = lane; r < rn.y; r += 64u) {
-        const float4 s0 = p4[3 * (size_t)r], s1 = p4[3 * (size_t)r + 1];
-        const float s2 = p4[3 * (size_t)r + 2].x;
-        a[0] += s0.x; a[1] += s0.y; a[2] += s0.z; a[3] += s0.w;
-        a[4] += s1.x; a[5] += s1.y; a[6] += s1.z; a[7] += s1.w; a[8] += s2;
+#pragma unroll
+        for (int k = 0; k < E3_REC_FLOATS; ++k) a[k] += p[E3_REC_FLOATS * (size_t)r + k];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -28,7 +28,8 @@
 #define E3_FLAG_COUNT_MAPPED 64     // begin: num_rendered_host is pinned + device-mapped; the GPU stores the count there
 #define E3_FLAG_DEFER_COLOR 128     // multi begin: no SH evaluation in preprocess; finish runs colour_kernel
 #define E3_MAX_VIEWS 4       // views per e3dgs_rasterize_backward_geom_multi call
-#define E3_ACC_STRIDE 12      // floats per (tile, Gaussian) instance in the backward gradient records
+#define E3_ACC_STRIDE 12      // floats the CALLER provides per (tile, Gaussian) instance and per splat sum in grad_acc
+#define E3_REC_FLOATS 9       // floats of a per-instance gradient record as stored (packed, 36 B; the rest is slack)
 
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define WAVE 64
