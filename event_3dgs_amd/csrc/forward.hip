@@ -713,11 +713,16 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
         // composited nothing there.  Bit j of sm[k] (an SGPR pair per strip) = entry j of this round evaluated strip k:
         // one scalar bit-set per evaluated strip, and one byte per entry stored per round.
         unsigned long long sm[4] = {0ull, 0ull, 0ull, 0ull};
-        for (int j = 0; j < cnt; ++j) {
+        // 1-based list position of the entry, kept in a VECTOR register on purpose: the select that records a pixel's
+        // last contributor needs it there, and a scalar copy is re-materialised with a v_mov in every live strip
+        uint32_t contributor = (uint32_t)base;
+        unsigned long long jbit = 1ull;             // 1 << j, shifted along (a 64-bit shift amount drags a 64-bit counter)
+        auto entry = [&](const int j) __attribute__((always_inline)) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
             const float4 c = sC[wave][j];
-            const uint32_t contributor = (uint32_t)(base + j + 1);
+            contributor += 1u;
+            asm volatile("" : "+v"(contributor));
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
             const float qx = cxdx * dx;
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                 // power > 0 (degenerate conic) is rejected by `valid` below
                 const unsigned long long live_mask = alive[k] & __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
                 if (live_mask != 0ull) {
-                    sm[k] |= 1ull << j;
+                    sm[k] |= jbit;
                     const float G = exp_det_noclamp(power);
                     const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                     // lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255)
@@ -753,7 +758,12 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                     alive[k] &= ~stop;
                 }
             }
-        }
+            jbit <<= 1;
+        };
+        // two entries per trip: halves the loop bookkeeping (counter, LDS address, branch) of an issue-bound loop
+        int j = 0;
+        for (; j + 1 < cnt; j += 2) { entry(j); entry(j + 1); }
+        if (j < cnt) entry(j);
         // (cost model of tile_work below: an evaluated strip ~ 2 entries)
         live_strips += 2 * (__builtin_popcountll(sm[0]) + __builtin_popcountll(sm[1]) + __builtin_popcountll(sm[2]) +
                             __builtin_popcountll(sm[3]));
