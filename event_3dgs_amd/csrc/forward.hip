@@ -19,53 +19,66 @@
 // ------------------------------------------------------------------------------------ SH colour
 // element (k, ch) of one Gaussian's SH block lives at sh[(k*3 + ch) * st]: st = 1 for the reference's
 // (P,M,3) layout, st = P for the coefficient-major layout (E3_FLAG_SH_PLANAR, coalesced across lanes)
-__device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, size_t st, float mx, float my, float mz,
-                                          const float* __restrict__ campos, float rgb[3], uint32_t& clamped) {
+// The degree is a template argument so that ALL coefficient loads of a splat are issued back to back before the first
+// use: with a run-time degree every `if (D > n)` block ends in its own wait on its own loads -- four dependent
+// memory round trips per thread, which made the projection kernel latency-bound (80 % of its wave cycles waiting).
+template <int D, bool REGS = false>
+__device__ __forceinline__ void sh_to_rgb_t(const float* sh, size_t st, float mx, float my, float mz,
+                                            const float* __restrict__ campos, float rgb[3], uint32_t& clamped) {
     const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
     const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
                 C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
     const float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f,
                 C33 = 0.3731763325901154f, C34 = -0.4570457994644658f, C35 = 1.445305721320277f,
                 C36 = -0.5900435899266435f;
+    // (degree 4, 75 coefficients, is not batched: it would cost every launch half its occupancy for a rarely used degree)
+    constexpr int NC = 3 * (D + 1) * (D + 1);
+    constexpr bool BATCH = D <= 3 && !REGS;     // REGS: `sh` already is a register array (sh_load_regs)
+    float cf[BATCH ? NC : 1];
+    if (BATCH) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cf[k] = sh[(size_t)k * st];
+    }
+#define SHC(k) (BATCH ? cf[BATCH ? (k) : 0] : sh[(size_t)(k) * st])
     float dx = mx - campos[0], dy = my - campos[1], dz = mz - campos[2];
     float len = __builtin_sqrtf(FMA(dx, dx, FMA(dy, dy, dz * dz)));
     float x = dx / len, y = dy / len, z = dz / len;
     clamped = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float r = SH_C0 * sh[(size_t)(0 * 3 + ch) * st];
+        float r = SH_C0 * SHC(0 * 3 + ch);
         if (D > 0) {
-            r = FMA(-(SH_C1 * y), sh[(size_t)(1 * 3 + ch) * st], r);
-            r = FMA(SH_C1 * z, sh[(size_t)(2 * 3 + ch) * st], r);
-            r = FMA(-(SH_C1 * x), sh[(size_t)(3 * 3 + ch) * st], r);
+            r = FMA(-(SH_C1 * y), SHC(1 * 3 + ch), r);
+            r = FMA(SH_C1 * z, SHC(2 * 3 + ch), r);
+            r = FMA(-(SH_C1 * x), SHC(3 * 3 + ch), r);
             if (D > 1) {
                 float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                r = FMA(C20 * xy, sh[(size_t)(4 * 3 + ch) * st], r);
-                r = FMA(C21 * yz, sh[(size_t)(5 * 3 + ch) * st], r);
-                r = FMA(C22 * (FMA(2.0f, zz, -xx) - yy), sh[(size_t)(6 * 3 + ch) * st], r);
-                r = FMA(C23 * xz, sh[(size_t)(7 * 3 + ch) * st], r);
-                r = FMA(C24 * (xx - yy), sh[(size_t)(8 * 3 + ch) * st], r);
+                r = FMA(C20 * xy, SHC(4 * 3 + ch), r);
+                r = FMA(C21 * yz, SHC(5 * 3 + ch), r);
+                r = FMA(C22 * (FMA(2.0f, zz, -xx) - yy), SHC(6 * 3 + ch), r);
+                r = FMA(C23 * xz, SHC(7 * 3 + ch), r);
+                r = FMA(C24 * (xx - yy), SHC(8 * 3 + ch), r);
                 if (D > 2) {
-                    r = FMA(C30 * y * FMA(3.0f, xx, -yy), sh[(size_t)(9 * 3 + ch) * st], r);
-                    r = FMA(C31 * xy * z, sh[(size_t)(10 * 3 + ch) * st], r);
-                    r = FMA(C32 * y * (FMA(4.0f, zz, -xx) - yy), sh[(size_t)(11 * 3 + ch) * st], r);
-                    r = FMA(C33 * z * (FMA(2.0f, zz, -(3.0f * xx)) - 3.0f * yy), sh[(size_t)(12 * 3 + ch) * st], r);
-                    r = FMA(C34 * x * (FMA(4.0f, zz, -xx) - yy), sh[(size_t)(13 * 3 + ch) * st], r);
-                    r = FMA(C35 * z * (xx - yy), sh[(size_t)(14 * 3 + ch) * st], r);
-                    r = FMA(C36 * x * FMA(-3.0f, yy, xx), sh[(size_t)(15 * 3 + ch) * st], r);
+                    r = FMA(C30 * y * FMA(3.0f, xx, -yy), SHC(9 * 3 + ch), r);
+                    r = FMA(C31 * xy * z, SHC(10 * 3 + ch), r);
+                    r = FMA(C32 * y * (FMA(4.0f, zz, -xx) - yy), SHC(11 * 3 + ch), r);
+                    r = FMA(C33 * z * (FMA(2.0f, zz, -(3.0f * xx)) - 3.0f * yy), SHC(12 * 3 + ch), r);
+                    r = FMA(C34 * x * (FMA(4.0f, zz, -xx) - yy), SHC(13 * 3 + ch), r);
+                    r = FMA(C35 * z * (xx - yy), SHC(14 * 3 + ch), r);
+                    r = FMA(C36 * x * FMA(-3.0f, yy, xx), SHC(15 * 3 + ch), r);
                     if (D > 3) {     // utils/sh_utils.py:97-110 (25 coefficients)
                         const float C40 = 2.5033429417967046f, C41 = -1.7701307697799304f, C42 = 0.9461746957575601f,
                                     C43 = -0.6690465435572892f, C44 = 0.10578554691520431f, C45 = -0.6690465435572892f,
                                     C46 = 0.47308734787878004f, C47 = -1.7701307697799304f, C48 = 0.6258357354491761f;
-                        r = FMA(C40 * xy * (xx - yy), sh[(size_t)(16 * 3 + ch) * st], r);
-                        r = FMA(C41 * yz * FMA(3.0f, xx, -yy), sh[(size_t)(17 * 3 + ch) * st], r);
-                        r = FMA(C42 * xy * FMA(7.0f, zz, -1.0f), sh[(size_t)(18 * 3 + ch) * st], r);
-                        r = FMA(C43 * yz * FMA(7.0f, zz, -3.0f), sh[(size_t)(19 * 3 + ch) * st], r);
-                        r = FMA(C44 * FMA(zz, FMA(35.0f, zz, -30.0f), 3.0f), sh[(size_t)(20 * 3 + ch) * st], r);
-                        r = FMA(C45 * xz * FMA(7.0f, zz, -3.0f), sh[(size_t)(21 * 3 + ch) * st], r);
-                        r = FMA(C46 * (xx - yy) * FMA(7.0f, zz, -1.0f), sh[(size_t)(22 * 3 + ch) * st], r);
-                        r = FMA(C47 * xz * FMA(-3.0f, yy, xx), sh[(size_t)(23 * 3 + ch) * st], r);
-                        r = FMA(C48 * (xx * FMA(-3.0f, yy, xx) - yy * FMA(3.0f, xx, -yy)), sh[(size_t)(24 * 3 + ch) * st], r);
+                        r = FMA(C40 * xy * (xx - yy), SHC(16 * 3 + ch), r);
+                        r = FMA(C41 * yz * FMA(3.0f, xx, -yy), SHC(17 * 3 + ch), r);
+                        r = FMA(C42 * xy * FMA(7.0f, zz, -1.0f), SHC(18 * 3 + ch), r);
+                        r = FMA(C43 * yz * FMA(7.0f, zz, -3.0f), SHC(19 * 3 + ch), r);
+                        r = FMA(C44 * FMA(zz, FMA(35.0f, zz, -30.0f), 3.0f), SHC(20 * 3 + ch), r);
+                        r = FMA(C45 * xz * FMA(7.0f, zz, -3.0f), SHC(21 * 3 + ch), r);
+                        r = FMA(C46 * (xx - yy) * FMA(7.0f, zz, -1.0f), SHC(22 * 3 + ch), r);
+                        r = FMA(C47 * xz * FMA(-3.0f, yy, xx), SHC(23 * 3 + ch), r);
+                        r = FMA(C48 * (xx * FMA(-3.0f, yy, xx) - yy * FMA(3.0f, xx, -yy)), SHC(24 * 3 + ch), r);
                     }
                 }
             }
@@ -73,6 +86,18 @@ __device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, s
         r = r + 0.5f;
         if (r < 0.0f) clamped |= (1u << ch);
         rgb[ch] = fmaxf(r, 0.0f);
+    }
+#undef SHC
+}
+
+__device__ __forceinline__ void sh_to_rgb(int D, const float* __restrict__ sh, size_t st, float mx, float my, float mz,
+                                          const float* __restrict__ campos, float rgb[3], uint32_t& clamped) {
+    switch (D) {
+    case 0: sh_to_rgb_t<0>(sh, st, mx, my, mz, campos, rgb, clamped); break;
+    case 1: sh_to_rgb_t<1>(sh, st, mx, my, mz, campos, rgb, clamped); break;
+    case 2: sh_to_rgb_t<2>(sh, st, mx, my, mz, campos, rgb, clamped); break;
+    case 3: sh_to_rgb_t<3>(sh, st, mx, my, mz, campos, rgb, clamped); break;
+    default: sh_to_rgb_t<4>(sh, st, mx, my, mz, campos, rgb, clamped); break;
     }
 }
 
@@ -96,25 +121,59 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod,
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------ preprocess
-// One thread per splat q = i * n + v (Gaussian i, view v).  The n threads of one Gaussian sit in adjacent lanes
-// and read the same parameter addresses, so HBM sees the parameters once per call while the grid is n times
-// larger than a per-Gaussian loop (which was latency-bound at 3 waves/SIMD) and every store is contiguous.
-__global__ __launch_bounds__(256) void preprocess_kernel(
-    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
+// One thread per GAUSSIAN; its views are a loop.  Everything the views share -- mean, covariance, opacity and the SH
+// coefficients (81 % of the parameter bytes) -- is loaded once, in ONE batch of independent loads at the top of the
+// thread, and the per-view work (projection, EWA, rectangle, colour) then runs from registers.  (Round 1 ran one
+// thread per splat with the SH loads inside the nested degree tests behind the culling tests: five dependent memory
+// round trips per thread, 80 % of the wave cycles waiting, 0.15 ms for 0.43 GB.)  The coefficients of Gaussians that
+// turn out to be culled in every view are read for nothing (contiguous rows, ~1/4 of them on the benchmark scene):
+// cheaper than a second round trip.  The SH degree is a template argument (the host picks the instantiation): the
+// coefficient array then lives in registers with static indices.
+#ifndef E3_PRE_WAVES
+#define E3_PRE_WAVES 5
+#endif
+template <int DEG>
+__global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
+    int P, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
     const float* __restrict__ rots, const float* __restrict__ cov_pre, ViewSet vs, int flags,
     int* __restrict__ radii,
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key,
     uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // housekeeping that would otherwise be two memset commands (each costs a barrier packet on the queue)
-    for (int t = tid; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
-    if (tid == 0) *offsets0 = 0u;
-    const int nv = vs.n;
-    const int i = nv == 1 ? tid : tid / nv;
+    for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
+    if (i == 0) *offsets0 = 0u;
     if (i >= P) return;
+    const int nv = vs.n;
+    constexpr int NCF = 3 * (DEG + 1) * (DEG + 1);
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    // colours of all views first, branch-free (independent chains the scheduler can interleave), so that the coefficient
+    // registers are free again before the per-view geometry: views that turn out culled cost ~100 wasted VALU slots
+    // each, the kernel gets 6 instead of 4 waves per SIMD for its long dependent division / sqrt chains
+    float rgbv[E3_MAX_VIEWS][3];
+    uint32_t clv[E3_MAX_VIEWS];
+    if (shs && !(flags & E3_FLAG_DEFER_COLOR)) {
+        const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
+        const float* __restrict__ sh = planar ? shs + i : shs + (size_t)i * M * 3;
+        const size_t st = planar ? (size_t)P : (size_t)1;
+        float cf[NCF];
+#pragma unroll
+        for (int k = 0; k < NCF; ++k) cf[k] = sh[(size_t)k * st];
+#pragma unroll
+        for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+            if (v >= nv) break;
+            sh_to_rgb_t<DEG, true>(cf, 1, mx, my, mz, vs.v[v].campos, rgbv[v], clv[v]);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+            clv[v] = 0u;
+            if (shs) { rgbv[v][0] = rgbv[v][1] = rgbv[v][2] = 0.0f; }      // E3_FLAG_DEFER_COLOR: colour_kernel fills colour + clamp mask later
+            else { rgbv[v][0] = colors[3 * (size_t)i]; rgbv[v][1] = colors[3 * (size_t)i + 1]; rgbv[v][2] = colors[3 * (size_t)i + 2]; }
+        }
+    }
     float S[6];
     if (cov_pre) {
 #pragma unroll
@@ -129,10 +188,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     // (in the forward the same fp32 `power` feeds both tests, so the margin only has to cover exp/log rounding, ~1e-6;
     // backward evaluates `power` in another order, which moves it by ~1e-7 of its largest term: 2e-4 covers that too)
     const float pmin = -(logf(255.0f * o_) + 2e-4f);
-    {
-        const int v = tid - i * nv;
+    // (unrolled with a uniform guard: a run-time index into the by-value ViewSet would move it to scratch memory)
+#pragma unroll
+    for (int v = 0; v < E3_MAX_VIEWS; ++v) {
+        if (v >= nv) break;
         const ViewParams& vp = vs.v[v];
-        const size_t q = (size_t)tid;
+        const size_t q = (size_t)i * nv + v;
         const float* V = vp.view;
         const float* Pm = vp.proj;
         int radius_out = 0;
@@ -181,17 +242,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 int xmax = clampi((int)((((px + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gx);
                 int ymax = clampi((int)((((py + fr) + (float)E3_TILE) - 1.0f) / (float)E3_TILE), 0, vp.gy);
                 if ((xmax - xmin) * (ymax - ymin) != 0) {
-                    float rgb[3];
-                    uint32_t cl = 0;
-                    if (shs && (flags & E3_FLAG_DEFER_COLOR)) {
-                        rgb[0] = rgb[1] = rgb[2] = 0.0f;          // colour_kernel fills colour + clamp mask later
-                    } else if (shs) {
-                        const bool planar = (flags & E3_FLAG_SH_PLANAR) != 0;
-                        sh_to_rgb(D, planar ? shs + i : shs + (size_t)i * M * 3, planar ? (size_t)P : (size_t)1, mx, my,
-                                  mz, vp.campos, rgb, cl);
-                    } else {
-                        rgb[0] = colors[3 * (size_t)i]; rgb[1] = colors[3 * (size_t)i + 1]; rgb[2] = colors[3 * (size_t)i + 2];
-                    }
+                    const float* rgb = rgbv[v];
+                    const uint32_t cl = clv[v];
                     rec[3 * q] = make_float4(px, py, conx, cony);
                     rec[3 * q + 1] = make_float4(conz, o_, rgb[0], rgb[1]);
                     // .z: above pmin + 4e-4 alpha >= 1/255 holds whatever the rounding of power / exp (backward's band)
@@ -876,13 +928,14 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     if (P <= 0) HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
     if (!(flags & E3_FLAG_COUNT_MAPPED) || P <= 0) *count_host = 0;      // (mapped: the caller armed a sentinel)
     if (P > 0) {
-        const unsigned pb = (unsigned)((Q + 255) / 256);
+        const unsigned pb = (unsigned)(((size_t)P + 255) / 256);      // one thread per Gaussian (its views are a loop)
         {
         ProfScope ps(PS_PREPROCESS, s);
-        preprocess_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, D, M, means3D, shs, colors, opac, scales, rots, cov_pre,
-                                                         vs, flags, radii, geom.rec, geom.clamped,
-                                                         geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                                         geom.offsets);
+        auto kern = D <= 0 ? preprocess_kernel<0> : D == 1 ? preprocess_kernel<1> : D == 2 ? preprocess_kernel<2>
+                  : D == 3 ? preprocess_kernel<3> : preprocess_kernel<4>;
+        kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
+                                            geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
+                                            geom.offsets);
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
