@@ -128,17 +128,20 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
 // workgroup's first key with digit d.  Keys are first placed at their workgroup-local sorted position in LDS
 // and then streamed out by consecutive threads, so the lanes of a store instruction write consecutive
 // addresses inside each digit's segment (avg 16 keys = 64 B) instead of 4-key fragments per (wave, digit).
+template <int ITEMS>
 struct StageLds {
-    uint32_t key[SORT_TILE];
-    uint32_t val[SORT_TILE];
+    uint32_t key[SORT_THREADS * ITEMS];
+    uint32_t val[SORT_THREADS * ITEMS];
     uint32_t glob[256];     // global position minus local position, per digit
     uint32_t wtot[SORT_THREADS / WAVE];
 };
-__device__ __forceinline__ void staged_scatter(const uint32_t (&key)[SORT_ITEMS], const uint32_t (&val)[SORT_ITEMS],
-                                               const uint32_t (&pos)[SORT_ITEMS],
+template <int ITEMS>
+__device__ __forceinline__ void staged_scatter(const uint32_t (&key)[ITEMS], const uint32_t (&val)[ITEMS],
+                                               const uint32_t (&pos)[ITEMS],
                                                uint32_t (*wcnt)[256], uint32_t gfirst, size_t block_first, size_t wbase,
                                                size_t n, int shift, uint32_t* __restrict__ keys_out,
-                                               uint32_t* __restrict__ vals_out, StageLds& L) {
+                                               uint32_t* __restrict__ vals_out, StageLds<ITEMS>& L) {
+    constexpr int TILE = SORT_THREADS * ITEMS;
     constexpr int NW = SORT_THREADS / WAVE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = threadIdx.x;
     uint32_t c[NW], total = 0;
@@ -158,7 +161,7 @@ __device__ __forceinline__ void staged_scatter(const uint32_t (&key)[SORT_ITEMS]
     for (int w = 0; w < NW; ++w) { wcnt[w][d] = l; l += c[w]; }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         size_t idx = wbase + (size_t)r * WAVE + lane;
         if (idx < n) {
             uint32_t dg = (key[r] >> shift) & 255u;
@@ -168,9 +171,9 @@ __device__ __forceinline__ void staged_scatter(const uint32_t (&key)[SORT_ITEMS]
         }
     }
     __syncthreads();
-    const uint32_t nvalid = (uint32_t)((n - block_first) < (size_t)SORT_TILE ? (n - block_first) : (size_t)SORT_TILE);
+    const uint32_t nvalid = (uint32_t)((n - block_first) < (size_t)TILE ? (n - block_first) : (size_t)TILE);
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         uint32_t lp = (uint32_t)j * SORT_THREADS + threadIdx.x;
         if (lp < nvalid) {
             uint32_t k = L.key[lp];
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     constexpr int NW = SORT_THREADS / WAVE;          // 4 waves
     constexpr int WAVE_KEYS = SORT_TILE / NW;        // 1024 consecutive keys per wave
     __shared__ uint32_t wcnt[NW][256];
-    __shared__ StageLds stage;
+    __shared__ StageLds<SORT_ITEMS> stage;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < NW; ++w) wcnt[w][threadIdx.x] = 0;
@@ -242,14 +245,21 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 // (no dependence on dispatch order or placement).  All descriptor words are zeroed by a memset before the pass.
 constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_MASK = (1u << 30) - 1u;
 
+// Keys per thread of the onesweep passes: the look-back chain is as long as the number of workgroups, so the depth
+// sort (one launch per digit over a few million keys) runs with bigger tiles than the three-kernel passes (measured:
+// 16 / 24 / 32 keys per thread -> 0.174 / 0.157 / 0.165 ms for the 3 M-key depth sort).
+constexpr int OS_ITEMS = 24;
+constexpr int OS_TILE = SORT_THREADS * OS_ITEMS;
+static inline size_t onesweep_blocks(size_t n) { return (n + OS_TILE - 1) / OS_TILE; }
+
 __global__ __launch_bounds__(SORT_THREADS) void radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                          int passes, uint32_t* __restrict__ ghist) {
     __shared__ uint32_t h[4][256];
     for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * SORT_TILE;
+    size_t base = (size_t)blockIdx.x * OS_TILE;
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < OS_ITEMS; ++i) {
         size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
         if (idx < n) {
             uint32_t k = keys[idx];
@@ -268,29 +278,29 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
     uint32_t* __restrict__ vals_out, size_t n, int shift, const uint32_t* __restrict__ ghist /*256, this pass*/,
     uint32_t* desc /* nblocks x 256, zeroed */, uint32_t* ticket /* zeroed */) {
     constexpr int NW = SORT_THREADS / WAVE;
-    constexpr int WAVE_KEYS = SORT_TILE / NW;
+    constexpr int WAVE_KEYS = OS_TILE / NW;
     __shared__ uint32_t wcnt[NW][256];
     __shared__ uint32_t wtot[NW];
     __shared__ uint32_t s_bid;
-    __shared__ StageLds stage;
+    __shared__ StageLds<OS_ITEMS> stage;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
 #pragma unroll
     for (int w = 0; w < NW; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
     const uint32_t bid = s_bid;
-    const size_t wbase = (size_t)bid * SORT_TILE + (size_t)wave * WAVE_KEYS;
+    const size_t wbase = (size_t)bid * OS_TILE + (size_t)wave * WAVE_KEYS;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
+    uint32_t key[OS_ITEMS], val[OS_ITEMS], pos[OS_ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < OS_ITEMS; ++r) {
         size_t idx = wbase + (size_t)r * WAVE + lane;
         bool ok = idx < n;
         key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
         val[r] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
     }
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < OS_ITEMS; ++r) {
         size_t idx = wbase + (size_t)r * WAVE + lane;
         bool ok = idx < n;
         uint32_t d = (key[r] >> shift) & 255u;
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
         gfirst = dbase + excl;
     }
     __syncthreads();
-    staged_scatter(key, val, pos, wcnt, gfirst, (size_t)bid * SORT_TILE, wbase, n, shift, keys_out, vals_out, stage);
+    staged_scatter(key, val, pos, wcnt, gfirst, (size_t)bid * OS_TILE, wbase, n, shift, keys_out, vals_out, stage);
 }
 
 static bool use_onesweep() {
@@ -385,8 +395,8 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
     const int passes = radix_passes(nbits);
     // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
     // for the multi-million instance sort the plain three-kernel pass is faster on this chip
-    if (n > 0 && use_onesweep() && passes <= 4 && (nbits == 32 ? sort_blocks(n) <= onesweep_max_blocks() : onesweep_small_keys())) {
-        unsigned nb = (unsigned)sort_blocks(n);
+    if (n > 0 && use_onesweep() && passes <= 4 && (nbits == 32 ? onesweep_blocks(n) <= onesweep_max_blocks() : onesweep_small_keys())) {
+        unsigned nb = (unsigned)onesweep_blocks(n);
         // scratch: [ghist 4*256][ticket 64 per pass ...][desc passes * nb * 256]
         uint32_t* ghist = scratch;
         uint32_t* tickets = scratch + 1024;
