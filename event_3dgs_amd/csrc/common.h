@@ -348,6 +348,8 @@ int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
                           float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s);
 
 // launchers implemented in scan_sort.hip
+void launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
+                             hipStream_t s);   // one launch; desc_zeroed: scan_blocks(n) + 1 words, zero on entry
 void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
                                hipStream_t s);
 // Stable LSD radix sort of (key,val) u32 pairs on bits [0,nbits).  Result is returned in

@@ -140,10 +140,13 @@ __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
     int* __restrict__ radii,
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key,
-    uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0) {
+    uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0,
+    uint32_t* __restrict__ scan_desc, int ndesc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // housekeeping that would otherwise be two memset commands (each costs a barrier packet on the queue)
+    // housekeeping that would otherwise be memset commands (each costs a barrier packet on the queue): the tile ranges,
+    // offsets[0], and the descriptors of the single-launch scan behind the binning count pass
     for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
+    for (int t = i; t < ndesc; t += gridDim.x * blockDim.x) scan_desc[t] = 0u;
     if (i == 0) *offsets0 = 0u;
     if (i >= P) return;
     const int nv = vs.n;
@@ -929,13 +932,15 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     if (!(flags & E3_FLAG_COUNT_MAPPED) || P <= 0) *count_host = 0;      // (mapped: the caller armed a sentinel)
     if (P > 0) {
         const unsigned pb = (unsigned)(((size_t)P + 255) / 256);      // one thread per Gaussian (its views are a loop)
+        // descriptors of the scan behind the count pass: the tail of the scratch, which the depth sort does not use
+        uint32_t* bin_scan_desc = geom.scratch + sort_scratch_words(Q);
         {
         ProfScope ps(PS_PREPROCESS, s);
         auto kern = D <= 0 ? preprocess_kernel<0> : D == 1 ? preprocess_kernel<1> : D == 2 ? preprocess_kernel<2>
                   : D == 3 ? preprocess_kernel<3> : preprocess_kernel<4>;
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                            geom.offsets);
+                                            geom.offsets, bin_scan_desc, (int)scan_blocks(Q) + 1);
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
@@ -955,7 +960,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                                                      vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
                                                                      nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
-        launch_exclusive_scan_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, geom.scratch, true, s);
+        launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s);
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back

@@ -106,11 +106,99 @@ void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint
         scan_final_kernel<false><<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, scratch);
 }
 
+// ------------------------------------------------------------------------------------ single-launch scan
+// The same scan in ONE launch (chained scan with decoupled look-back): for the scans that sit between two kernels of
+// the list-building chain, where three launches of ~5 us each cost more than the scan itself.  Protocol as in
+// radix_onesweep_kernel (cdna_hip_programming.md G16, form R2): one 32-bit descriptor {2-bit status, 30-bit sum} per
+// workgroup, relaxed agent-scope atomics, logical workgroup ids from an atomic ticket.  Wave 0 of a workgroup looks
+// back 64 predecessors at a time.  `desc` = nb + 1 words (descriptors, then the ticket) that MUST be zero on entry:
+// the kernel in front of the scan in the stream zeroes them (radix_hist_kernel / preprocess_kernel), which costs
+// no extra command.  Sums must stay below 2^30.
+constexpr uint32_t SC_AGG = 1u << 30, SC_PREFIX = 2u << 30, SC_MASK = (1u << 30) - 1u;
+template <bool INCLUSIVE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32_t* in, uint32_t* out, size_t n,
+                                                                    uint32_t* desc, unsigned nb) {
+    __shared__ uint32_t wtot[SCAN_THREADS / WAVE];
+    __shared__ uint32_t s_bid, s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_bid = atomicAdd(desc + nb, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const size_t base = (size_t)bid * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        tsum += v[i];
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        if (lane == 0)
+            __hip_atomic_store(desc + bid, (bid == 0 ? SC_PREFIX : SC_AGG) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        int p = (int)bid - 1;                       // lane l looks at workgroup p - l
+        while (p >= 0) {
+            const int idx = p - lane;
+            const uint32_t d = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : SC_PREFIX;             // virtual workgroup -1: prefix 0
+            const uint32_t st = d >> 30;
+            const unsigned long long ready = __ballot(st != 0u), pre = __ballot(st == 2u);
+            const int lead = (~ready) ? __builtin_ctzll(~ready) : 64;       // published entries in a row from lane 0
+            const int firstpre = pre ? __builtin_ctzll(pre) : 64;
+            const int use = firstpre < lead ? firstpre + 1 : lead;          // consumed this round
+            uint32_t c = lane < use ? (d & SC_MASK) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            excl += c;
+            if (firstpre < lead) break;                                     // reached an inclusive prefix
+            p -= use;
+            if (use == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) {
+            if (bid != 0)
+                __hip_atomic_store(desc + bid, SC_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    uint32_t run = s_excl + inc - tsum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        uint32_t ex = run;
+        run += v[i];
+        if (base + i < n) out[base + i] = INCLUSIVE ? run : ex;
+    }
+}
+
+void launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
+                             hipStream_t s) {
+    if (n == 0) return;
+    const unsigned nb = (unsigned)scan_blocks(n);
+    if (inclusive)
+        scan_chained_kernel<true><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb);
+    else
+        scan_chained_kernel<false><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb);
+}
+
 // ------------------------------------------------------------------------------------ radix sort
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                   int shift, uint32_t* __restrict__ hist,
-                                                                  unsigned nblocks) {
+                                                                  unsigned nblocks, uint32_t* __restrict__ scan_desc,
+                                                                  unsigned ndesc) {
     __shared__ uint32_t h[256];
+    // (descriptors + ticket of the chained scan that follows in the stream: zeroed here instead of by a memset command)
+    if (blockIdx.x == 0) for (unsigned t = threadIdx.x; t < ndesc; t += SORT_THREADS) scan_desc[t] = 0u;
     h[threadIdx.x] = 0;
     __syncthreads();
     size_t base = (size_t)blockIdx.x * SORT_TILE;
@@ -417,8 +505,9 @@ void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t*
         uint32_t* hist = scratch;
         uint32_t* scan_scratch = scratch + hn;
         for (int shift = 0; shift < nbits; shift += 8) {
-            radix_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, shift, hist, nb);
-            launch_exclusive_scan_u32(hist, hist, hn, scan_scratch, false, s);
+            radix_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, shift, hist, nb, scan_scratch,
+                                                                      (unsigned)scan_blocks(hn) + 1u);
+            launch_scan_chained_u32(hist, hist, hn, scan_scratch, false, s);
             radix_scatter_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(
                 ki, (identity_payload && shift == 0) ? nullptr : vi, ko, vo, n, shift, hist, nb);
             uint32_t* t = ki; ki = ko; ko = t;
