@@ -349,7 +349,8 @@ int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
 
 // launchers implemented in scan_sort.hip
 void launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
-                             hipStream_t s);   // one launch; desc_zeroed: scan_blocks(n) + 1 words, zero on entry
+                             hipStream_t s, int* total_host = nullptr);   // one launch; desc_zeroed: scan_blocks(n) + 1
+                             // words, zero on entry; total_host: mapped host word that receives the grand total
 void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
                                hipStream_t s);
 // Stable LSD radix sort of (key,val) u32 pairs on bits [0,nbits).  Result is returned in
@@ -357,7 +358,10 @@ void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint
 // identity_payload: v0 is NOT read; the payload of element i is i (saves writing and reading the index array).
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                              uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
-                             bool identity_payload = false);
+                             bool identity_payload = false, bool scratch_zeroed = false);
+// words at the start of the sort scratch that must be zero when launch_radix_sort_pairs(n, nbits) is called with
+// scratch_zeroed = true (0: that sort needs none); lets the kernel in front of the sort do the zeroing
+size_t radix_sort_zero_words(size_t n, int nbits);
 static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---------------------------------------------------------------- optional event profiler (capi.hip)

@@ -141,12 +141,13 @@ __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key,
     uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0,
-    uint32_t* __restrict__ scan_desc, int ndesc) {
+    uint32_t* __restrict__ scan_desc, int ndesc, uint32_t* __restrict__ sort_zero, int nsort) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // housekeeping that would otherwise be memset commands (each costs a barrier packet on the queue): the tile ranges,
     // offsets[0], and the descriptors of the single-launch scan behind the binning count pass
     for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
     for (int t = i; t < ndesc; t += gridDim.x * blockDim.x) scan_desc[t] = 0u;
+    for (int t = i; t < nsort; t += gridDim.x * blockDim.x) sort_zero[t] = 0u;        // look-back state of the depth sort
     if (i == 0) *offsets0 = 0u;
     if (i >= P) return;
     const int nv = vs.n;
@@ -876,13 +877,6 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
     present[i] = vz > E3_NEAR_CULL_Z ? 1 : 0;
 }
 
-// E3_FLAG_COUNT_MAPPED: the instance count is stored straight into host-visible (pinned, mapped) memory by the
-// GPU; the host polls that word instead of waiting for a copy command + stream synchronisation.
-__global__ void publish_count_kernel(const uint32_t* __restrict__ src, volatile int* __restrict__ dst_host) {
-    *dst_host = (int)*src;
-    __threadfence_system();
-}
-
 // ------------------------------------------------------------------------------------ host driver
 extern thread_local char g_err[512];
 extern int g_tile_cull;
@@ -940,14 +934,15 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                   : D == 3 ? preprocess_kernel<3> : preprocess_kernel<4>;
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                            geom.offsets, bin_scan_desc, (int)scan_blocks(Q) + 1);
+                                            geom.offsets, bin_scan_desc, (int)scan_blocks(Q) + 1, geom.scratch,
+                                            (int)radix_sort_zero_words(Q, 32));
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
         {
         ProfScope ps(PS_SORT_DEPTH, s);
         launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, 32, geom.scratch, &keys_sorted,
-                                &order, s, true);
+                                &order, s, true, true);
         }
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
@@ -960,13 +955,12 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                                                      vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
                                                                      nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
-        launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s);
+        launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
+                                (flags & E3_FLAG_COUNT_MAPPED) ? count_host : nullptr);
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back
-        if (flags & E3_FLAG_COUNT_MAPPED)
-            publish_count_kernel<<<dim3(1), dim3(1), 0, s>>>(geom.offsets + nwaves, count_host);
-        else
+        if (!(flags & E3_FLAG_COUNT_MAPPED))      // (mapped: the scan's last thread stored the total into count_host)
             HIP_OK(hipMemcpyAsync(count_host, geom.offsets + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     return 0;

@@ -117,7 +117,8 @@ void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint
 constexpr uint32_t SC_AGG = 1u << 30, SC_PREFIX = 2u << 30, SC_MASK = (1u << 30) - 1u;
 template <bool INCLUSIVE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32_t* in, uint32_t* out, size_t n,
-                                                                    uint32_t* desc, unsigned nb) {
+                                                                    uint32_t* desc, unsigned nb,
+                                                                    volatile int* total_host) {
     __shared__ uint32_t wtot[SCAN_THREADS / WAVE];
     __shared__ uint32_t s_bid, s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,16 +180,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
         run += v[i];
         if (base + i < n) out[base + i] = INCLUSIVE ? run : ex;
     }
+    // the grand total straight into host-visible (pinned, mapped) memory, by the thread that owns the last element:
+    // the host polls that word (E3_FLAG_COUNT_MAPPED) -- no separate publishing kernel, no copy command
+    if (total_host && base < n && n <= base + SCAN_ITEMS) {
+        *total_host = (int)run;
+        __threadfence_system();
+    }
 }
 
 void launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
-                             hipStream_t s) {
+                             hipStream_t s, int* total_host) {
     if (n == 0) return;
     const unsigned nb = (unsigned)scan_blocks(n);
     if (inclusive)
-        scan_chained_kernel<true><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb);
+        scan_chained_kernel<true><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb, total_host);
     else
-        scan_chained_kernel<false><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb);
+        scan_chained_kernel<false><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb, total_host);
 }
 
 // ------------------------------------------------------------------------------------ radix sort
@@ -475,22 +482,30 @@ static size_t onesweep_max_blocks() {
     return (size_t)v;
 }
 
+static bool onesweep_chosen(size_t n, int nbits) {
+    const int passes = radix_passes(nbits);
+    return n > 0 && use_onesweep() && passes <= 4 &&
+           (nbits == 32 ? onesweep_blocks(n) <= onesweep_max_blocks() : onesweep_small_keys());
+}
+size_t radix_sort_zero_words(size_t n, int nbits) {
+    return onesweep_chosen(n, nbits) ? 1024 + 64 + (size_t)radix_passes(nbits) * onesweep_blocks(n) * 256 : 0;
+}
+
 void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                              uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
-                             bool identity_payload) {
+                             bool identity_payload, bool scratch_zeroed) {
     uint32_t *ki = k0, *ko = k1, *vi = v0, *vo = v1;
     if (identity_payload && nbits < 1) nbits = 1;        // the payload (0, 1, 2, ...) only exists after a pass
     const int passes = radix_passes(nbits);
     // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
     // for the multi-million instance sort the plain three-kernel pass is faster on this chip
-    if (n > 0 && use_onesweep() && passes <= 4 && (nbits == 32 ? onesweep_blocks(n) <= onesweep_max_blocks() : onesweep_small_keys())) {
+    if (onesweep_chosen(n, nbits)) {
         unsigned nb = (unsigned)onesweep_blocks(n);
         // scratch: [ghist 4*256][ticket 64 per pass ...][desc passes * nb * 256]
         uint32_t* ghist = scratch;
         uint32_t* tickets = scratch + 1024;
         uint32_t* desc = scratch + 1024 + 64;
-        size_t words = 1024 + 64 + (size_t)passes * nb * 256;
-        (void)hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), s);
+        if (!scratch_zeroed) (void)hipMemsetAsync(scratch, 0, radix_sort_zero_words(n, nbits) * sizeof(uint32_t), s);
         radix_global_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, passes, ghist);
         for (int p = 0; p < passes; ++p) {
             radix_onesweep_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, (identity_payload && p == 0) ? nullptr : vi,
