@@ -246,17 +246,27 @@ __global__ __launch_bounds__(EV_THREADS) void event_reduce_kernel(
 }
 
 // scalars (float[8]): 0 loss, 1 dL/dc, 2 rho, 3 L1 event, 4 L1 intensity, 5 L1 blur, 6 kE, 7 kI
-__global__ __launch_bounds__(WAVE) void event_finalize_kernel(int nblocks, size_t HW, const double* __restrict__ partials,
-                                                              const float* __restrict__ c_ptr, int has_blur,
-                                                              float* __restrict__ scalars) {
+__global__ __launch_bounds__(EV_THREADS) void event_finalize_kernel(int nblocks, size_t HW, const double* __restrict__ partials,
+                                                                    const float* __restrict__ c_ptr, int has_blur,
+                                                                    float* __restrict__ scalars) {
+    // one workgroup (a single wave walked the ~2 000 partial rows in 12 us of dependent loads); fixed order: deterministic
+    __shared__ double sfin[EV_NSUM][EV_THREADS / WAVE];
     double acc[EV_NSUM] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += WAVE)
+    for (int b = threadIdx.x; b < nblocks; b += EV_THREADS)
 #pragma unroll
         for (int k = 0; k < EV_NSUM; ++k) acc[k] += partials[(size_t)b * EV_NSUM + k];
 #pragma unroll
-    for (int k = 0; k < EV_NSUM; ++k)
+    for (int k = 0; k < EV_NSUM; ++k) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        if ((threadIdx.x & 63) == 0) sfin[k][threadIdx.x >> 6] = acc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EV_NSUM; ++k) {
+        acc[k] = 0;
+        for (int w = 0; w < EV_THREADS / WAVE; ++w) acc[k] += sfin[k][w];
+    }
     if (threadIdx.x == 0) {
         const double n = (double)HW, c = (double)c_ptr[0];
         double L1E = acc[0] / n, rho = acc[1] / n, L1I = acc[3] / (3.0 * n), L1B = acc[4] / (3.0 * n);
@@ -318,7 +328,7 @@ int e3_event_loss_impl(int W, int H, const float* image, const float* now, const
     double* partials = reinterpret_cast<double*>(scratch);
     event_reduce_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
                                                               gt_c, partials);
-    event_finalize_kernel<<<dim3(1), dim3(WAVE), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars);
+    event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars);
     event_grad_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
                                                             gt_c, scalars, d_image, d_now, d_next);
     hipError_t e = hipGetLastError();

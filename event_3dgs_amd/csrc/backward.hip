@@ -45,6 +45,8 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     // LDS byte address of this wave's staged records, as a scalar (the per-entry address is then scalar arithmetic)
     const uint32_t recs_base = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)&sRec[wave][0].a.x);
+    uint32_t recs_base_v = recs_base;
+    asm volatile("" : "+v"(recs_base_v));       // the same address kept in a VGPR for the per-entry v_mad
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
     const int tile = __builtin_amdgcn_readfirstlane((int)order[unit]);   // global tile id (made scalar: see render_fwd_kernel)
@@ -127,6 +129,8 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
         }
         if (base + 3 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (base + 3 * WAVE + lane))];
         const unsigned long long nz = __builtin_amdgcn_ballot_w64(mvec != 0u);
+        int nrem = n - base;
+        asm volatile("" : "+s"(nrem));           // (opaque: otherwise re-associated into two scalar ops per entry)
         unsigned long long touched = 0ull;
         for (int jb = 0; jb < cnt; jb += 16) {          // 16 entries share one commit
             uint32_t ng = (uint32_t)(nz >> jb) & 0xFFFFu;
@@ -135,12 +139,15 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                 ng &= ng - 1u;
                 const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)mvec, j);
                 // (32-bit LDS pointer arithmetic: through the generic pointer the compiler forms the address with a 64-bit mad)
-                LdsF4* vp = (LdsF4*)(uintptr_t)(recs_base + 48u * (uint32_t)j);
+                // one VALU op (24-bit multiply-add with the base in a vector register) instead of s_mul + s_add + v_mov
+                uint32_t rec_addr;
+                asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(rec_addr) : "s"(j), "v"(recs_base_v));
+                LdsF4* vp = (LdsF4*)(uintptr_t)rec_addr;
                 const f4_t va = vp[0], vb = vp[1], vc = vp[2];
                 const float4 a = make_float4(va.x, va.y, va.z, va.w);
                 const float4 b = make_float4(vb.x, vb.y, vb.z, vb.w);
                 const float4 c = make_float4(vc.x, vc.y, vc.z, vc.w);
-                const uint32_t contributor = (uint32_t)(n - (base + j));   // 1-based position in the list
+                const uint32_t contributor = (uint32_t)(nrem - j);         // 1-based position in the list
                 const float dx = a.x - pfx;
                 // power(dy) = -(A dx^2 + C dy^2)/2 - B dx dy as a quadratic in dy (Horner: 2 FMAs per strip instead of the
                 // forward's 4-op expression, whose rounding order only the bit-exact forward has to keep)
@@ -181,7 +188,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                         unsigned long long keep = live & safe;
                         const unsigned long long near = live & ~safe;
                         if (near != 0ull) {                  // rare (<1 % of the live strips)
-                            const float qf = FMA(b.x * dy, dy, (a.z * dx) * dx);
+                            float adx = a.z * dx;
+                            asm volatile("" : "+v"(adx));      // (keeps the product below in this rare branch: as a common
+                            const float qf = FMA(b.x * dy, dy, adx * dx);   //  subexpression it is hoisted to every entry)
                             const float pf = FMA(-0.5f, qf, -((a.w * dx) * dy));
                             const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(pf));
                             keep |= near & __builtin_amdgcn_fcmpf(pf, 0.0f, 13 /* ULE: !(pf > 0) */) &
