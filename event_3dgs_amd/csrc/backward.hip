@@ -293,10 +293,30 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
 template <bool ACCUM>
 __device__ __forceinline__ void put(float* p, float v) { if (ACCUM) *p += v; else *p = v; }
 
-template <bool ACCUM>
-__device__ __forceinline__ void sh_backward(int D, int M, const float* __restrict__ sh, float* __restrict__ dsh, size_t st,
+// D (degree) is a template argument: the coefficients then live in a statically indexed register array that is loaded in
+// one batch and -- coefficient by coefficient -- overwritten with the gradient it produces, which is stored in one batch
+// at the end.  VEC4: the reference's (P, M, 3) layout with 16-byte aligned rows, moved as float4 (a quarter of the
+// memory instructions and cache-line requests of dword accesses at a 192-byte lane stride); otherwise element (k, ch)
+// lives at [(k * 3 + ch) * st] (st = P: coefficient-major).  ACCUM adds into dsh (VEC4 is not used with it).
+template <bool ACCUM, int D, bool VEC4>
+__device__ __forceinline__ void sh_backward(int M, const float* __restrict__ sh, float* __restrict__ dsh, size_t st,
                                             float mx, float my, float mz, const float* __restrict__ campos,
                                             uint32_t clamped, const float gin[3], float gmean[3]) {
+    constexpr int NC = 3 * (D + 1) * (D + 1);
+    float cf[NC];
+    if (VEC4) {
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+        for (int k = 0; k < NC / 4; ++k) {
+            const float4 q = s4[k];
+            cf[4 * k] = q.x; cf[4 * k + 1] = q.y; cf[4 * k + 2] = q.z; cf[4 * k + 3] = q.w;
+        }
+#pragma unroll
+        for (int k = NC / 4 * 4; k < NC; ++k) cf[k] = sh[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cf[k] = sh[(size_t)k * st];
+    }
     const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
     const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
                          0.5462742152960396f};
@@ -312,8 +332,8 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
     auto term = [&](int k, float Y, float Yx, float Yy, float Yz) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            put<ACCUM>(&dsh[(size_t)(k * 3 + ch) * st], Y * g[ch]);
-            float s = sh[(size_t)(k * 3 + ch) * st] * g[ch];
+            float s = cf[k * 3 + ch] * g[ch];
+            cf[k * 3 + ch] = Y * g[ch];                // the coefficient is consumed: its slot now holds dL/dsh[k][ch]
             ddx = FMA(Yx, s, ddx); ddy = FMA(Yy, s, ddy); ddz = FMA(Yz, s, ddz);
         }
     };
@@ -362,8 +382,18 @@ __device__ __forceinline__ void sh_backward(int D, int M, const float* __restric
             }
         }
     }
+    if (VEC4 && !ACCUM) {
+        float4* __restrict__ d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+        for (int k = 0; k < NC / 4; ++k) d4[k] = make_float4(cf[4 * k], cf[4 * k + 1], cf[4 * k + 2], cf[4 * k + 3]);
+#pragma unroll
+        for (int k = NC / 4 * 4; k < NC; ++k) dsh[k] = cf[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) put<ACCUM>(&dsh[(size_t)k * st], cf[k]);
+    }
     if (!ACCUM)
-        for (int k = 3 * (D + 1) * (D + 1); k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
+        for (int k = NC; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
     float dot = x * ddx + y * ddy + z * ddz;
     gmean[0] += (ddx - x * dot) / len;
     gmean[1] += (ddy - y * dot) / len;
@@ -599,9 +629,9 @@ __device__ __forceinline__ void cov3_backward(const Cov3& c, const float gcov[6]
 // One thread per Gaussian.  ACCUM=false writes every output element (zeros for culled Gaussians, so the
 // caller never has to pre-zero); ACCUM=true adds into the outputs for visible Gaussians only, which lets the
 // renders of a training iteration accumulate straight into one gradient buffer.
-template <bool ACCUM>
+template <bool ACCUM, int DEG, bool VEC4>
 __global__ __launch_bounds__(256) void geom_bwd_kernel(
-    int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
+    int P, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
     const float* __restrict__ cov_pre, ViewParams vp, int flags, const int* __restrict__ radii,
     const uint32_t* __restrict__ clamped, const float4* __restrict__ gsum,
@@ -664,8 +694,9 @@ __global__ __launch_bounds__(256) void geom_bwd_kernel(
     if (shs) {
         float gcol[3] = {g12[6], g12[7], g12[8]};
         const bool pl = (flags & E3_FLAG_SH_PLANAR) != 0;
-        sh_backward<ACCUM>(D, M, pl ? shs + i : shs + (size_t)i * M * 3, pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3,
-                           pl ? (size_t)P : (size_t)1, mx, my, mz, vp.campos, clamped[i], gcol, gmean);
+        sh_backward<ACCUM, DEG, VEC4>(M, pl ? shs + i : shs + (size_t)i * M * 3,
+                                      pl ? dL_dsh + i : dL_dsh + (size_t)i * M * 3, pl ? (size_t)P : (size_t)1, mx, my, mz,
+                                      vp.campos, clamped[i], gcol, gmean);
     }
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i], gmean[0]);
     put<ACCUM>(&dL_dmean3D[3 * (size_t)i + 1], gmean[1]);
@@ -1050,14 +1081,28 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);
         if (me != hipSuccess) return e3_fail(me, "hipMemsetAsync(gsum)");
     }
-    if (nv == 1 && (flags & E3_FLAG_ACCUMULATE))
-        geom_bwd_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,
+    if (nv == 1) {
+        // instantiation: accumulate or overwrite x SH degree x (P, M, 3) rows movable as float4 (16-byte aligned rows of the
+        // reference layout, overwrite mode)
+        const bool acc = (flags & E3_FLAG_ACCUMULATE) != 0;
+        const bool vec4 = shs && dL_dsh && !acc && !(flags & E3_FLAG_SH_PLANAR) &&
+                          ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh) |
+                            (uintptr_t)((size_t)M * 12)) & 15) == 0;
+        using Kern = void (*)(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
+                              ViewParams, int, const int*, const uint32_t*, const float4*, float*, float*, float*, float*,
+                              float*, float*, float*, float*);
+        static const Kern table[3][5] = {
+            {geom_bwd_kernel<false, 0, false>, geom_bwd_kernel<false, 1, false>, geom_bwd_kernel<false, 2, false>,
+             geom_bwd_kernel<false, 3, false>, geom_bwd_kernel<false, 4, false>},
+            {geom_bwd_kernel<false, 0, true>, geom_bwd_kernel<false, 1, true>, geom_bwd_kernel<false, 2, true>,
+             geom_bwd_kernel<false, 3, true>, geom_bwd_kernel<false, 4, true>},
+            {geom_bwd_kernel<true, 0, false>, geom_bwd_kernel<true, 1, false>, geom_bwd_kernel<true, 2, false>,
+             geom_bwd_kernel<true, 3, false>, geom_bwd_kernel<true, 4, false>}};
+        const int dsel = !shs ? 0 : (D < 0 ? 0 : (D > 4 ? 4 : D));
+        table[acc ? 2 : (vec4 ? 1 : 0)][dsel]<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,
             dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
-    else if (nv == 1)
-        geom_bwd_kernel<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-            P, D, M, means3D, shs, scales, rots, opacities, cov_pre, vs.v[0], flags, radii, geom.clamped, gsum,
-            dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    }
     else {
         // several views: one pass, every gradient element written once (capi.hip checked the argument subset)
         MultiViews mv;

@@ -132,7 +132,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 #ifndef E3_PRE_WAVES
 #define E3_PRE_WAVES 5
 #endif
-template <int DEG>
+template <int DEG, bool VEC4 /* (P, M, 3) coefficient rows, 16-byte aligned: loaded as float4 */>
 __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
     int P, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
@@ -163,8 +163,21 @@ __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
         const float* __restrict__ sh = planar ? shs + i : shs + (size_t)i * M * 3;
         const size_t st = planar ? (size_t)P : (size_t)1;
         float cf[NCF];
+        if (VEC4) {
+            // the reference's (P, M, 3) layout: a lane's coefficients are one 192-byte row -> 16-byte loads (a quarter of
+            // the load instructions and cache-line requests of dword loads at a 192-byte lane stride)
+            const float4* __restrict__ s4 = reinterpret_cast<const float4*>(sh);
 #pragma unroll
-        for (int k = 0; k < NCF; ++k) cf[k] = sh[(size_t)k * st];
+            for (int k = 0; k < NCF / 4; ++k) {
+                const float4 q = s4[k];
+                cf[4 * k] = q.x; cf[4 * k + 1] = q.y; cf[4 * k + 2] = q.z; cf[4 * k + 3] = q.w;
+            }
+#pragma unroll
+            for (int k = NCF / 4 * 4; k < NCF; ++k) cf[k] = sh[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCF; ++k) cf[k] = sh[(size_t)k * st];
+        }
 #pragma unroll
         for (int v = 0; v < E3_MAX_VIEWS; ++v) {
             if (v >= nv) break;
@@ -930,8 +943,16 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         uint32_t* bin_scan_desc = geom.scratch + sort_scratch_words(Q);
         {
         ProfScope ps(PS_PREPROCESS, s);
-        auto kern = D <= 0 ? preprocess_kernel<0> : D == 1 ? preprocess_kernel<1> : D == 2 ? preprocess_kernel<2>
-                  : D == 3 ? preprocess_kernel<3> : preprocess_kernel<4>;
+        // (P, M, 3) coefficient rows that start on 16-byte boundaries are loaded as float4 (the planar layout is coalesced
+        // across lanes as it is)
+        const bool vec4 = shs && !(flags & (E3_FLAG_SH_PLANAR | E3_FLAG_DEFER_COLOR)) &&
+                          ((reinterpret_cast<uintptr_t>(shs) | (uintptr_t)((size_t)M * 12)) & 15) == 0;
+        auto kern = vec4 ? (D <= 0 ? preprocess_kernel<0, true> : D == 1 ? preprocess_kernel<1, true>
+                            : D == 2 ? preprocess_kernel<2, true> : D == 3 ? preprocess_kernel<3, true>
+                                                                            : preprocess_kernel<4, true>)
+                         : (D <= 0 ? preprocess_kernel<0, false> : D == 1 ? preprocess_kernel<1, false>
+                            : D == 2 ? preprocess_kernel<2, false> : D == 3 ? preprocess_kernel<3, false>
+                                                                            : preprocess_kernel<4, false>);
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
                                             geom.offsets, bin_scan_desc, (int)scan_blocks(Q) + 1, geom.scratch,

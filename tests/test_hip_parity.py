@@ -283,6 +283,42 @@ def test_small_scene_work_decomposition_is_invisible():
         assert rel_l2(off[2][k], ref) <= GRAD_TOL and rel_l2(on[2][k], ref) <= GRAD_TOL, k
 
 
+def test_sh_rows_moved_as_float4_or_dwords_give_identical_results():
+    """The (P, M, 3) coefficient rows of the reference layout are read (projection) and their gradient written
+    (per-Gaussian backward) as float4 when the rows start on 16-byte boundaries, else as dwords; a tensor that is a
+    contiguous view 4 bytes into its storage takes the dword path.  Same arithmetic: bit-identical image and gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    N, W, H = 3000, 176, 128
+    act, cam = scene(N, W, H, seed=33)
+    rs = _settings(cam, (0.2, 0.2, 0.2), dev)
+    gw = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(misalign):
+        leaf = lambda t: t.detach().clone().to(dev).requires_grad_(True)
+        L = dict(means3D=leaf(act["means3D"]), opacities=leaf(act["opacities"]), scales=leaf(act["scales"]),
+                 rotations=leaf(act["rotations"]))
+        if misalign:
+            store = torch.zeros(N * 48 + 1, device=dev)
+            store[1:] = act["shs"].to(dev).reshape(-1)
+            store.requires_grad_(True)
+            shs = store[1:].view(N, 16, 3)                      # contiguous, data_ptr % 16 == 4
+            assert shs.data_ptr() % 16 == 4 and shs.is_contiguous()
+        else:
+            store = leaf(act["shs"]); shs = store
+            assert shs.data_ptr() % 16 == 0
+        means2D = torch.zeros(N, 3, device=dev, requires_grad=True)
+        img, radii = GaussianRasterizer(rs)(means3D=L["means3D"], means2D=means2D, shs=shs, opacities=L["opacities"],
+                                            scales=L["scales"], rotations=L["rotations"])
+        (img * gw).sum().backward()
+        gsh = store.grad[1:].view(N, 16, 3) if misalign else store.grad
+        return img.detach(), radii, gsh, L["means3D"].grad, L["scales"].grad
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float(a[2].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("first", [0, 16, 32])
 def test_randomised_configurations_against_oracle(first):
     """tools/fuzz_parity.py: random frame sizes (not tile multiples), 1..4000 Gaussians, sub-pixel to screen-filling
