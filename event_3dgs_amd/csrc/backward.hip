@@ -17,7 +17,10 @@ constexpr int BWD_WAVES = 4;
 extern unsigned long long* g_trace;
 int launch_tile_order(int ntiles, int tiles_per_view, int gx, const uint2* ranges, const uint32_t* work, uint32_t* order,
                       hipStream_t s);
-__global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
+#ifndef E3_BWD_WAVES
+#define E3_BWD_WAVES 6
+#endif
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -28,7 +31,6 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     // conflict-free (8 lanes x 16 B per LDS cycle land on 32 distinct banks)
     struct StagedRec { float4 a, b, c; };
     __shared__ StagedRec sRec[BWD_WAVES][WAVE];
-    __shared__ uint32_t sId[BWD_WAVES][WAVE];       // emission index of the staged entries (where their record goes)
     // Gradient reduction through LDS.  DPP adds cost ~9 cycles per wave-instruction on this chip (plain adds 2.7),
     // so instead of a 54-op (or 26-op transposed) DPP butterfly the nine per-lane sums of an entry are transposed
     // through the wave's LDS slice: 9 conflict-free ds_write_b32, then lane (v,p) = (lane>>3, lane&7) reads the 8
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
     if (2 * WAVE + lane < n) e_next2 = perm[range.x + (uint32_t)(n - 1 - (2 * WAVE + lane))];
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
-        sRec[wave][lane].a = ra; sRec[wave][lane].b = rb; sRec[wave][lane].c = rc; sId[wave][lane] = re;
+        rc.w = __uint_as_float(re);                 // the record's spare word carries the emission index (where its gradient record goes)
+        sRec[wave][lane].a = ra; sRec[wave][lane].b = rb; sRec[wave][lane].c = rc;
         const uint32_t mvec = lane < cnt ? rm : 0u;
         wave_sync();
         if (base + WAVE + lane < n) {
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, 5) void render_bwd_kernel(
                     const float4 ea = sRec[wave][e].a;
                     const float4 eb = sRec[wave][e].b;
                     p0.x *= eb.y; p0.y *= eb.y; p0.z *= eb.y; p0.w *= eb.y; p1.x *= eb.y;
-                    F3* g = reinterpret_cast<F3*>(part + E3_REC_FLOATS * (size_t)sId[wave][e]);
+                    F3* g = reinterpret_cast<F3*>(part + E3_REC_FLOATS * (size_t)__float_as_uint(sRec[wave][e].c.w));
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
                     g[0] = F3{-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy, -0.5f * p0.z};
                     g[1] = F3{-p0.w, -0.5f * p1.x, p1.y};
