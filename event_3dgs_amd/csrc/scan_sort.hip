@@ -353,14 +353,22 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_global_hist_kernel(const u
     for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
     size_t base = (size_t)blockIdx.x * OS_TILE;
+    uint32_t ones = 0;
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; ++i) {
         size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
         if (idx < n) {
             uint32_t k = keys[idx];
-            for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+            // (the all-ones key -- culled splats, a third of the depth keys -- would serialise 64 lanes on one LDS
+            // counter in every pass: counted in a register instead)
+            if (k == 0xFFFFFFFFu) ++ones;
+            else for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ones += __shfl_xor(ones, o, 64);
+    if ((threadIdx.x & 63) == 0 && ones)
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][255], ones);
     __syncthreads();
     for (int p = 0; p < passes; ++p) {
         uint32_t c = h[p][threadIdx.x];
