@@ -221,6 +221,19 @@ def main():
         stages["optimizer"] = {"avg_ms": round(opt_ms, 4), "launches": len(opt_events), "alg_GB": round(ob / 1e9, 4),
                                "alg_GBps": round(ob / 1e9 / (opt_ms / 1e3), 1)}
     # the roofline object describes the kernel timed inside the timed region (the largest one: DESIGN.md section 5)
+    # measured HBM traffic of every stage (committed PMC profile of this workload, profiles/traffic_stages.json) next to
+    # the algorithmic bytes: the list-building stages move 2-3x their algorithmic bytes (gathers in depth order,
+    # sector granularity), which is what their launch durations have to be read against
+    spath = os.path.join(ROOT, "profiles", "traffic_stages.json")
+    if os.path.exists(spath) and cfg_name == "cfg3_1M_1080p_event":
+        try:
+            per_stage = json.load(open(spath)).get("bytes_per_stage_launch", {})
+            for name, b in per_stage.items():
+                if name in stages and b:
+                    stages[name]["pmc_GB"] = round(b / 1e9, 4)
+                    stages[name]["pmc_GBps"] = round(b / 1e9 / (stages[name]["avg_ms"] / 1e3), 1)
+        except Exception:
+            pass
     dominant = dom_name if dom_name in stages else None
     roofline = None
     if dominant:

@@ -65,3 +65,37 @@ json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1)
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(open(f"{dst}/kernel_stats_top.txt").read())
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "note"} for k, v in out.items()}, indent=1))
+
+
+# ---- measured traffic per bench stage (tools/pmc_all_traffic.sh -> gpurun_out/traffic_all_<mixtag>.txt): the bench line
+# reports it next to the algorithmic bytes of every stage (stages[*].pmc_GB / pmc_GBps)
+tall = f"gpurun_out/traffic_all_{mixtag}.txt" if mixtag else None
+if tall and os.path.exists(tall):
+    shutil.copy(tall, f"{dst}/pmc_traffic_all_kernels.txt")
+    per = {}
+    for line in open(tall).read().splitlines()[1:]:
+        parts = line.rsplit(None, 2)
+        if len(parts) == 3:
+            try:
+                per[parts[0].strip()] = (float(parts[1]) + float(parts[2])) * 1e6        # fetch (corrected) + write, bytes
+            except ValueError:
+                pass
+    def k(prefix):
+        return sum(v for name, v in per.items() if name.startswith(prefix))
+    # one entry = bytes per LAUNCH of the stage as bench.py times it (a stage that is launched twice per iteration is
+    # averaged over its two launches, like its avg_ms)
+    stage = {
+        "preprocess": k("void preprocess_kernel"),
+        "sort_depth": k("radix_global_hist_kernel") + 4 * k("radix_onesweep_kernel"),
+        "scan_emit": (k("void bin_kernel<false>") + k("void scan_chained_kernel<true>") + k("void bin_kernel<true>")) / 2,
+        "sort_tile": 2 * (k("radix_hist_kernel") + k("void scan_chained_kernel<false>") + k("radix_scatter_kernel")),
+        "tile_ranges": (k("tile_ranges_kernel") + 2 * k("tile_order_reg_kernel")) / 2,
+        "render_fwd": k("render_fwd_kernel"),
+        "render_bwd": k("render_bwd_kernel"),
+        "geom_bwd": k("run_reduce_kernel") + k("geom_bwd_multi_kernel"),
+        "optimizer": k("sh_adam_views_kernel") + 2 * k("adam_segments_kernel"),
+    }
+    json.dump({"bytes_per_stage_launch": {a: int(b) for a, b in stage.items()},
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of every kernel (tools/pmc_all_traffic.sh; 2 x FETCH_SIZE + "
+                       "WRITE_SIZE, max over launches), summed per bench.py stage"}, open("profiles/traffic_stages.json", "w"), indent=1)
+    print(json.dumps(stage, indent=1))
