@@ -264,7 +264,10 @@ __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
                     rec[3 * q] = make_float4(px, py, conx, cony);
                     rec[3 * q + 1] = make_float4(conz, o_, rgb[0], rgb[1]);
                     // .z: above pmin + 4e-4 alpha >= 1/255 holds whatever the rounding of power / exp (backward's band)
-                    rec[3 * q + 2] = make_float4(rgb[2], pmin, pmin + 4e-4f, 0.0f);
+                    // .w: the tile rectangle once more, 8 bits per bound (grids up to 255 x 255 tiles): the binning passes
+                    // then need ONE gather per splat (this record) instead of two (bin_kernel)
+                    const uint32_t prect = (uint32_t)xmin | ((uint32_t)ymin << 8) | ((uint32_t)xmax << 16) | ((uint32_t)ymax << 24);
+                    rec[3 * q + 2] = make_float4(rgb[2], pmin, pmin + 4e-4f, __uint_as_float(prect));
                     clamped[q] = cl;
                     radius_out = radius;
                     rect_out = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)xmax | ((uint32_t)ymax << 16));
@@ -359,7 +362,8 @@ constexpr int BIN_WAVES = 4;
 template <bool EMIT>
 __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift, int nviews, int ntiles,
                                                               const uint32_t* __restrict__ order,
-                                                              const uint2* __restrict__ rect,
+                                                              const uint32_t* __restrict__ depth_keys /* sorted */,
+                                                              const uint2* __restrict__ rect, int packed_rect,
                                                               const float4* __restrict__ rec, int gx, int cull,
                                                               const uint32_t* __restrict__ wave_offsets,
                                                               uint32_t* __restrict__ wave_counts,
@@ -381,12 +385,25 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
     if (mine) {
         g = order[s];
-        uint2 r = rect[g];
+        // Culled splats carry the all-ones depth key and sit at the end of the order: known from the (coalesced) sorted
+        // key, without touching their records.  For the others ONE gather of the 48-byte record delivers the rectangle too
+        // (8 bits per bound in its spare word, grids up to 255 x 255 tiles; the 16-bit array otherwise): the rectangle
+        // array used to cost a second 128-byte line per splat and pass.
+        uint2 r = make_uint2(0u, 0u);
+        float4 t = make_float4(0, 0, 0, 0);
+        if (depth_keys[s] != 0xFFFFFFFFu) {
+            a = rec[3 * (size_t)g];
+            t = rec[3 * (size_t)g + 1];
+            if (packed_rect) {
+                const uint32_t p = __float_as_uint(rec[3 * (size_t)g + 2].w);
+                r = make_uint2((p & 255u) | (((p >> 8) & 255u) << 16), ((p >> 16) & 255u) | ((p >> 24) << 16));
+            } else {
+                r = rect[g];
+            }
+        }
         uint32_t w = (r.y & 0xFFFFu) - (r.x & 0xFFFFu), h = (r.y >> 16) - (r.x >> 16);
         n = w * h;
         if (n) {
-            a = rec[3 * (size_t)g];
-            float4 t = rec[3 * (size_t)g + 1];
             // 2 ln(255 o) with the safety margin folded in; o <= 0 -> -inf -> nothing kept
             // margins: see tile_touched(); the Lambda term bounds the rounding of the compositing kernels'
             // own `power` at any pixel of the tile (|terms| <= 2(|terms at the minimiser| + Lambda*15^2*2))
@@ -966,14 +983,16 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                 &order, s, true, true);
         }
         KERNEL_OK("radix sort (depth)");
-        if (order != geom.ord0) return e3_fail(hipErrorUnknown, "internal: depth order not in ord0");
+        if (order != geom.ord0 || keys_sorted != geom.key0)
+            return e3_fail(hipErrorUnknown, "internal: depth order not in ord0 / key0");
         const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
         const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, geom.rect, geom.rec,
-                                                                     vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
+        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, keys_sorted,
+                                                                     geom.rect, vs.v[0].gx <= 255 && vs.v[0].gy <= 255,
+                                                                     geom.rec, vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
                                                                      nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
@@ -1015,8 +1034,10 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         {
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
-                                                                    geom.rect, geom.rec, gx, g_tile_cull, geom.offsets,
-                                                                    nullptr, k0, bin.emit_gid, geom.run);
+                                                                    geom.key0 /* sorted keys: four passes end here */,
+                                                                    geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
+                                                                    g_tile_cull, geom.offsets, nullptr, k0, bin.emit_gid,
+                                                                    geom.run);
         }
         KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
