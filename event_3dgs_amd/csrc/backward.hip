@@ -441,7 +441,8 @@ constexpr int RR_CHUNK = 128;
 constexpr int RR_SLICE = (RR_CHUNK * E3_REC_FLOATS + 3 + 3) / 4 + 1;     // float4s: chunk + misalignment of its first float
 __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint32_t* __restrict__ order,
                                                          const uint2* __restrict__ run_sorted,
-                                                         const float* __restrict__ part, float4* __restrict__ gsum) {
+                                                         const float* __restrict__ part, float4* __restrict__ gsum,
+                                                         const uint32_t* __restrict__ depth_keys /* sorted */) {
     __shared__ float4 sbuf[4][(RR_SLICE + 63) / 64 * 64];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t j0 = blockIdx.x * 256u + wave * 64u, j = j0 + lane;
@@ -482,7 +483,10 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
         }
         wave_sync();
     }
-    if (j < Q) {              // zeros for splats whose every tile was culled (their radius can still be > 0)
+    // zeros for splats whose every tile was culled (their radius can still be > 0); nothing for the splats the projection
+    // culled (radius 0, all-ones depth key, the tail of the order): the per-Gaussian kernels never read their sums, and a
+    // third of the scattered 48-byte stores goes away
+    if (j < Q && depth_keys[j] != 0xFFFFFFFFu) {
         const size_t q = order[j];
         gsum[3 * q] = make_float4(a[0], a[1], a[2], a[3]);
         gsum[3 * q + 1] = make_float4(a[4], a[5], a[6], a[7]);
@@ -1078,7 +1082,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                                                                                     grad_acc, gsum);
     else if (num_rendered > 0)
         run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                   grad_acc, gsum);
+                                                                                   grad_acc, gsum, geom.key0);
     else        // no instance at all (a radius can still be > 0 when every tile of the splat was culled): zero sums
     {
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);
