@@ -249,12 +249,13 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
                     wave_sync();
                 }
             }
-            {
-                // commit the (up to) 16 entries of this group
+            if (((nz >> jb) & 0xFFFFull) != 0ull) {
+                // commit the (up to) 16 entries of this group.  Records exist only for entries the forward evaluated on
+                // some strip (non-zero mask = BinningState::touched of their slot): those no pixel used here get a zero
+                // record, the others are neither written nor read (run_reduce_kernel).
                 wave_sync();
-                if (lane < 16 && jb + lane < cnt) {
+                if (lane < 16 && ((nz >> (jb + lane)) & 1ull) != 0ull) {
                     const int e = jb + lane;
-                    // entries no pixel of the tile used still get a (zero) record: grad_acc needs no pre-zeroing
                     const bool hit = ((touched >> e) & 1ull) != 0ull;
                     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     const float4* pp = reinterpret_cast<const float4*>(&sPart[wave][lane][0]);
@@ -276,8 +277,11 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
         }
         wave_sync();
     }
-    // list entries behind the last contributor of every pixel are never walked: zero records
+    // list entries behind the last contributor of every pixel are never walked: zero records for those the forward
+    // evaluated (its mask bytes behind its own early exit are stale: a spurious zero record there is never read, the
+    // slot's `touched` flag is 0)
     for (uint32_t e = range.x + (uint32_t)n + (uint32_t)lane; e < range.y; e += WAVE) {
+        if (strip_mask[e] == 0) continue;
         F3* g = reinterpret_cast<F3*>(part + E3_REC_FLOATS * (size_t)perm[e]);
         const F3 z3 = F3{0.0f, 0.0f, 0.0f};
         g[0] = z3; g[1] = z3; g[2] = z3;
@@ -438,12 +442,12 @@ __device__ __forceinline__ void build_cov3(const float sact[3], float scale_modi
 // order (fixed order -> deterministic).  Output: 3 float4 per splat at its INDEX q,
 // (mx my A B | C o c0 c1 | c2 - - -), which the per-Gaussian kernels then read coalesced.
 constexpr int RR_CHUNK = 128;
-constexpr int RR_SLICE = (RR_CHUNK * E3_REC_FLOATS + 3 + 3) / 4 + 1;     // float4s: chunk + misalignment of its first float
 __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint32_t* __restrict__ order,
                                                          const uint2* __restrict__ run_sorted,
                                                          const float* __restrict__ part, float4* __restrict__ gsum,
-                                                         const uint32_t* __restrict__ depth_keys /* sorted */) {
-    __shared__ float4 sbuf[4][(RR_SLICE + 63) / 64 * 64];
+                                                         const uint32_t* __restrict__ depth_keys /* sorted */,
+                                                         const uint8_t* __restrict__ touched /* per slot */) {
+    __shared__ float sbuf[4][RR_CHUNK * E3_REC_FLOATS];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t j0 = blockIdx.x * 256u + wave * 64u, j = j0 + lane;
     if (j0 >= Q) return;
@@ -454,30 +458,35 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
     float a[E3_REC_FLOATS];
 #pragma unroll
     for (int k = 0; k < E3_REC_FLOATS; ++k) a[k] = 0.0f;
-    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part);
-    float4* sb4 = sbuf[wave];
-    const float* sb = reinterpret_cast<const float*>(sb4);
+    float* sb = sbuf[wave];
     const uint32_t end = rn.x + rn.y;
     for (uint32_t c0 = S0; c0 < S1; c0 += RR_CHUNK) {
         const uint32_t nrec = (S1 - c0 < (uint32_t)RR_CHUNK) ? S1 - c0 : (uint32_t)RR_CHUNK;
-        const uint32_t f0 = E3_REC_FLOATS * c0, a0 = f0 & ~3u;                     // first float, aligned down to 16 B
-        const uint32_t n4 = (E3_REC_FLOATS * (c0 + nrec) - a0 + 3u) >> 2;          // float4s to stage (reads < 16 B past the last record: slack)
-        const float4* __restrict__ src = p4 + (size_t)(a0 >> 2);
-        constexpr int NLD = (RR_SLICE + 63) / 64;
-        float4 v[NLD];
+        // Stage the chunk: lane l brings records l and l + 64.  Only records whose slot is flagged `touched` exist (the
+        // compositing backward writes nothing for the ~55 % of the instances the forward never evaluated); the others
+        // are staged as zeros without touching memory -- the loads of unflagged lanes are redirected to the chunk's
+        // first record (one cache line, unconditional loads: predicated ones serialise) and discarded.
+        float v[2][E3_REC_FLOATS];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {                     // all loads of the chunk in flight before the first LDS store
-            const uint32_t i = lane + 64u * k;              // (unconditional, index clamped: a predicated load serialises)
-            v[k] = src[i < n4 ? i : n4 - 1u];
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t r = lane + 64u * t;
+            const bool f = r < nrec && touched[c0 + r] != 0;
+            const float* __restrict__ src = part + E3_REC_FLOATS * (size_t)(c0 + (f ? r : 0u));
+#pragma unroll
+            for (int k = 0; k < E3_REC_FLOATS; ++k) v[t][k] = src[k];
+#pragma unroll
+            for (int k = 0; k < E3_REC_FLOATS; ++k) v[t][k] = f ? v[t][k] : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) sb4[lane + 64u * k] = v[k];     // unconditional too (the slice holds NLD * 64 float4)
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < E3_REC_FLOATS; ++k) sb[E3_REC_FLOATS * (lane + 64u * t) + k] = v[t][k];
         wave_sync();
         const uint32_t lo = rn.x > c0 ? rn.x : c0;
         const uint32_t cend = c0 + nrec;
         const uint32_t hi = end < cend ? end : cend;
         for (uint32_t r = lo; r < hi; ++r) {
-            const float* q = sb + (E3_REC_FLOATS * r - a0);
+            const float* q = sb + E3_REC_FLOATS * (r - c0);
 #pragma unroll
             for (int k = 0; k < E3_REC_FLOATS; ++k) a[k] += q[k];
         }
@@ -500,13 +509,15 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
 __global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const uint32_t* __restrict__ order,
                                                               const uint2* __restrict__ run_sorted,
                                                               const float* __restrict__ part,
-                                                              float4* __restrict__ gsum) {
+                                                              float4* __restrict__ gsum,
+                                                              const uint8_t* __restrict__ touched) {
     const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (j >= Q) return;
     const uint2 rn = run_sorted[j];
     const float* __restrict__ p = part + E3_REC_FLOATS * (size_t)rn.x;
     float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t r = lane; r < rn.y; r += 64u) {
+        if (touched[rn.x + r] == 0) continue;            // no record was written for this slot
 #pragma unroll
         for (int k = 0; k < E3_REC_FLOATS; ++k) a[k] += p[E3_REC_FLOATS * (size_t)r + k];
     }
@@ -1079,10 +1090,10 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     float4* gsum = reinterpret_cast<float4*>(grad_acc + E3_ACC_STRIDE * (size_t)num_rendered);
     if (num_rendered > 0 && Q <= E3_RUN_REDUCE_WAVE_MAX && g_small_scene_paths)
         run_reduce_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                    grad_acc, gsum);
+                                                                                    grad_acc, gsum, bin.touched);
     else if (num_rendered > 0)
         run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                   grad_acc, gsum, geom.key0);
+                                                                                   grad_acc, gsum, geom.key0, bin.touched);
     else        // no instance at all (a radius can still be > 0 when every tile of the splat was culled): zero sums
     {
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);

@@ -215,6 +215,9 @@ struct BinningState {
     uint32_t* emit_gid;   // splat id of each slot (= emission position)                       [read by fwd + bwd]
     uint8_t* strip_mask;  // per LIST POSITION: bit k = the forward evaluated this entry on the tile's 16x4 pixel strip k
                           // (written by render_fwd_kernel for the entries it visited, read by render_bwd_kernel)
+    uint8_t* touched;     // per SLOT: 1 = the forward evaluated the instance on some strip, i.e. the compositing backward writes
+                          // its gradient record (zeroed at emission, set by render_fwd_kernel, read by run_reduce_kernel: the
+                          // other ~55 % of the records are neither written nor read)
     uint32_t* scratch;
     static size_t required(size_t I) {
         char* p = nullptr;
@@ -231,6 +234,7 @@ struct BinningState {
         b.emit_gid = carve<uint32_t>(p, n);
         b.strip_mask = carve<uint8_t>(p, n + 64);
         b.scratch = carve<uint32_t>(p, sort_scratch_words(n));
+        b.touched = carve<uint8_t>(p, n + 64);
         return b;
     }
 };

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
                                                               uint32_t* __restrict__ wave_counts,
                                                               uint32_t* __restrict__ keys,
                                                               uint32_t* __restrict__ emit_gid,
-                                                              uint2* __restrict__ run_sorted) {
+                                                              uint2* __restrict__ run_sorted,
+                                                              uint8_t* __restrict__ touched) {
     __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
     __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per splat of the wave (EMIT only)
     __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
             const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
             keys[pos] = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
             emit_gid[pos] = sId[wave][j];
+            touched[pos] = 0;                       // (render_fwd_kernel sets it for the instances it evaluates)
             atomicAdd(&sCnt[wave][j], 1u);
         }
         count += (uint32_t)__popcll(mask);
@@ -729,7 +731,8 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ perm,
     const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work, uint8_t* __restrict__ strip_mask) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work, uint8_t* __restrict__ strip_mask,
+    uint8_t* __restrict__ touched /* per slot, see BinningState */) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
     __shared__ float4 sB[RENDER_WAVES][WAVE];
     __shared__ float4 sC[RENDER_WAVES][WAVE];
@@ -859,6 +862,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                                   (__builtin_amdgcn_inverse_ballot_w64(sm[2]) ? 4u : 0u) |
                                   (__builtin_amdgcn_inverse_ballot_w64(sm[3]) ? 8u : 0u);
             strip_mask[range.x + base + lane] = (uint8_t)mine;
+            if (mine) touched[perm[range.x + base + lane]] = 1;     // (slot of the entry; zero from the emission pass otherwise)
         }
         wave_sync();
     }
@@ -993,7 +997,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, keys_sorted,
                                                                      geom.rect, vs.v[0].gx <= 255 && vs.v[0].gy <= 255,
                                                                      geom.rec, vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
-                                                                     nullptr, nullptr, nullptr);
+                                                                     nullptr, nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
                                 (flags & E3_FLAG_COUNT_MAPPED) ? count_host : nullptr);
@@ -1037,7 +1041,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
                                                                     geom.key0 /* sorted keys: four passes end here */,
                                                                     geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
                                                                     g_tile_cull, geom.offsets, nullptr, k0, bin.emit_gid,
-                                                                    geom.run);
+                                                                    geom.run, bin.touched);
         }
         KERNEL_OK("bin emit");
         uint32_t *ks, *vs;
@@ -1073,7 +1077,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((nslots + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
         g_trace, nslots, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
-        out_color, img.final_T, img.n_contrib, img.work, bin.strip_mask);
+        out_color, img.final_T, img.n_contrib, img.work, bin.strip_mask, bin.touched);
     KERNEL_OK("render_fwd_kernel");
     return 0;
 }
