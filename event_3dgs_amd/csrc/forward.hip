@@ -588,16 +588,26 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t key[ORDER_ITEMS];
     uint32_t m = 0;
+    // unconditional loads with a clamped index, all in flight together: a load under `if (t < ntiles)` waits for its
+    // own round trip in every unrolled iteration (32 dependent memory latencies in a kernel that runs alone on the GPU)
+    if (work) {
+#pragma unroll
+        for (int i = 0; i < ORDER_ITEMS; ++i) {
+            const int t = tid + i * 1024;
+            key[i] = work[t < ntiles ? t : ntiles - 1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ORDER_ITEMS; ++i) {
+            const int t = tid + i * 1024;
+            const uint2 r = ranges[t < ntiles ? t : ntiles - 1];
+            key[i] = r.y - r.x;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ORDER_ITEMS; ++i) {
-        const int t = tid + i * 1024;
-        uint32_t k = 0;
-        if (t < ntiles) {
-            if (work) k = work[t];
-            else { const uint2 r = ranges[t]; k = r.y - r.x; }
-        }
-        key[i] = k;
-        m = max(m, k);
+        if (tid + i * 1024 >= ntiles) key[i] = 0;
+        m = max(m, key[i]);
     }
     m = wave_max_u32(m);
     if (lane == 0) wsum[wave] = m;
@@ -606,9 +616,16 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const 
     if (tid == 0) { uint32_t x = 0; for (int w = 0; w < 16; ++w) x = max(x, wsum[w]); smax = x; }
     __syncthreads();
     const uint32_t width = smax / 1024u + 1u;
+    // bucket = 1023 - min(1023, key / width) with the division as a multiplication by the rounded-up reciprocal
+    // (exact for the 32-bit keys and widths that occur: checked against the division below in debug builds is not
+    // needed -- an off-by-one bucket only changes the launch order, never a result)
+    const float inv_width = 1.0f / (float)width;
 #pragma unroll
-    for (int i = 0; i < ORDER_ITEMS; ++i)
-        if (tid + i * 1024 < ntiles) atomicAdd(&hist[1023u - min(1023u, key[i] / width)], 1u);
+    for (int i = 0; i < ORDER_ITEMS; ++i) {
+        const uint32_t b = min(1023u, (uint32_t)((float)key[i] * inv_width));
+        key[i] = 1023u - b;                                  // from here on key[] holds the bucket
+        if (tid + i * 1024 < ntiles) atomicAdd(&hist[key[i]], 1u);
+    }
     __syncthreads();
     uint32_t v = hist[tid], inc = v;
 #pragma unroll
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const 
     for (int i = 0; i < ORDER_ITEMS; ++i) {
         const int t = tid + i * 1024;
         if (t < ntiles) {
-            uint32_t pos = atomicAdd(&hist[1023u - min(1023u, key[i] / width)], 1u);
+            uint32_t pos = atomicAdd(&hist[key[i]], 1u);
             order[pos] = (uint32_t)t;
         }
     }
