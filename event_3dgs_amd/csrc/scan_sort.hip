@@ -209,10 +209,18 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     h[threadIdx.x] = 0;
     __syncthreads();
     size_t base = (size_t)blockIdx.x * SORT_TILE;
+    // (all loads first, unconditional with a clamped index: a load inside `if (idx < n)` next to its use waits for its own
+    // round trip in every unrolled iteration)
+    uint32_t k[SORT_ITEMS];
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+        k[i] = keys[idx < n ? idx : n - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -354,11 +362,17 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_global_hist_kernel(const u
     __syncthreads();
     size_t base = (size_t)blockIdx.x * OS_TILE;
     uint32_t ones = 0;
+    uint32_t kk[OS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; ++i) {                       // loads first (see radix_hist_kernel)
+        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+        kk[i] = keys[idx < n ? idx : n - 1];
+    }
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; ++i) {
         size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
         if (idx < n) {
-            uint32_t k = keys[idx];
+            uint32_t k = kk[i];
             // (the all-ones key -- culled splats, a third of the depth keys -- would serialise 64 lanes on one LDS
             // counter in every pass: counted in a register instead)
             if (k == 0xFFFFFFFFu) ++ones;
