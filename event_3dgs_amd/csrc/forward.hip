@@ -520,11 +520,23 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
 // compositing backward on this chip).
 __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint32_t* __restrict__ keys,
                                                           uint2* __restrict__ ranges) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= I) return;
-    uint32_t t = keys[i];
-    if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
-    if (i == I - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
+    // four consecutive sorted keys per thread (one 16-byte load + the two neighbours): a quarter of the threads and load
+    // instructions of the one-key-per-thread form for the same 4 I bytes
+    const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (i0 >= I) return;
+    uint32_t k[6];                                            // keys[i0 - 1 .. i0 + 4]
+    const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);      // (the key buffer is padded: BinningState carves n >= I)
+    k[1] = q.x; k[2] = q.y; k[3] = q.z; k[4] = q.w;
+    k[0] = i0 ? keys[i0 - 1] : 0xFFFFFFFFu;
+    k[5] = i0 + 4u < I ? keys[i0 + 4u] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = i0 + (uint32_t)j;
+        if (i >= I) break;
+        const uint32_t t = k[j + 1];
+        if (i == 0 || k[j] != t) ranges[t].x = i;
+        if (i == I - 1 || k[j + 2] != t) ranges[t].y = i + 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------ compositing
@@ -1070,7 +1082,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         if (vs != bin.perm) return e3_fail(hipErrorUnknown, "internal: sorted list not in perm");
         {
         ProfScope ps(PS_RANGES, s);
-        tile_ranges_kernel<<<dim3((I + 255) / 256), dim3(256), 0, s>>>(I, ks, img.ranges);
+        tile_ranges_kernel<<<dim3((I + 1023) / 1024), dim3(256), 0, s>>>(I, ks, img.ranges);
         }
         KERNEL_OK("tile_ranges_kernel");
     }
