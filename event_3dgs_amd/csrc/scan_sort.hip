@@ -128,11 +128,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
     const size_t base = (size_t)bid * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t tsum = 0;
+    // a thread's 16 consecutive elements as four 16-byte loads when the tile is full and the pointer aligned
+    const bool full = base + SCAN_ITEMS <= n;
+    if (full && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const uint4* __restrict__ in4 = reinterpret_cast<const uint4*>(in + base);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = (base + i < n) ? in[base + i] : 0;
-        tsum += v[i];
+        for (int i = 0; i < SCAN_ITEMS / 4; ++i) {
+            const uint4 q = in4[i];
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = (base + i < n) ? in[base + i] : 0;
     }
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) tsum += v[i];
     uint32_t inc = tsum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -178,7 +188,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         uint32_t ex = run;
         run += v[i];
-        if (base + i < n) out[base + i] = INCLUSIVE ? run : ex;
+        v[i] = INCLUSIVE ? run : ex;
+    }
+    if (full && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        uint4* __restrict__ out4 = reinterpret_cast<uint4*>(out + base);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS / 4; ++i) out4[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i)
+            if (base + i < n) out[base + i] = v[i];
     }
     // the grand total straight into host-visible (pinned, mapped) memory, by the thread that owns the last element:
     // the host polls that word (E3_FLAG_COUNT_MAPPED) -- no separate publishing kernel, no copy command
