@@ -509,7 +509,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
 
 static bool use_onesweep() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP"); v = (e && e[0] == '0') ? 0 : 1; }
+    // off by default since round 2: with the single-launch scan and the batched-load histogram a three-kernel pass of the
+    // depth sort (hist 4 us + scan 6 us + scatter 12 us on 3 M pairs) beats the look-back chain of a onesweep pass (28 us +
+    // its share of the global histogram) at every size measured; E3DGS_ONESWEEP=1 turns it back on
+    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP"); v = (e && e[0] == '1') ? 1 : 0; }
     return v != 0;
 }
 static bool onesweep_small_keys() {     // tile-id sort (few bits, millions of pairs): classic passes by default

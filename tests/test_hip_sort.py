@@ -33,16 +33,17 @@ def _lists(n_gauss, W, H, seed):
 @pytest.mark.parametrize("n_gauss,W,H", [(30000, 640, 480), (200000, 1280, 720)])
 def test_sorted_lists_are_depth_ordered_and_variants_agree(n_gauss, W, H):
     I, pl, rg, recA, img = _lists(n_gauss, W, H, seed=5)
-    assert I > 10 * 4096          # many sort workgroups -> the look-back chain is exercised
+    assert I > 10 * 4096          # many sort workgroups -> the look-back chains (scan, onesweep) are exercised
     # inside every tile the list is ordered by (depth, index); depth is not stored, but (x,y) records are, so
-    # check the weaker invariant on ids via a second run with the classic 3-kernel sort in a fresh process
+    # check the weaker invariant on ids via a second run with the OTHER depth-sort implementation (onesweep passes;
+    # the three-kernel passes are the default) in a fresh process
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests');"
         "import numpy as np; from test_hip_sort import _lists;"
         "I, pl, rg, recA, img = _lists(%d, %d, %d, 5);"
         "np.savez(sys.argv[1], I=I, pl=pl, rg=rg, img=img)" % (ROOT, ROOT, n_gauss, W, H))
-    out = os.path.join("/tmp", f"sort_classic_{n_gauss}.npz")
-    env = dict(os.environ, E3DGS_ONESWEEP="0")
+    out = os.path.join("/tmp", f"sort_onesweep_{n_gauss}.npz")
+    env = dict(os.environ, E3DGS_ONESWEEP="1")
     subprocess.check_call([sys.executable, "-c", code, out], env=env)
     ref = np.load(out)
     assert int(ref["I"]) == I
