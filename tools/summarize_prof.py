@@ -81,12 +81,27 @@ if tall and os.path.exists(tall):
             except ValueError:
                 pass
     def k(prefix):
-        return sum(v for name, v in per.items() if name.startswith(prefix))
+        return sum(v for name, v in per.items() if name.startswith(prefix) and " @" not in name)
+    def depth_sort_bytes():
+        """Four three-kernel passes on the 3-view depth keys.  The same kernels also run the (larger) tile sort and the
+        single-view launches of the ground-truth renders: per kernel the launch sizes seen are, descending, tile sort
+        3 views / 1 view, depth sort 3 views / 1 view -> picked by their workgroup count (onesweep build: the global
+        histogram + four onesweep passes instead)."""
+        if any(n.startswith("radix_onesweep_kernel") for n in per):
+            return k("radix_global_hist_kernel") + 4 * k("radix_onesweep_kernel")
+        # launch sizes of the benchmark workload (cfg3: 3 views x 1 M Gaussians = 3 M depth keys, 4096 keys per workgroup;
+        # its 256 x 733 counters are scanned by 46 workgroups)
+        nb = (3 * 1_000_000 + 4095) // 4096
+        want = {"radix_hist_kernel": nb, "radix_scatter_kernel": nb, "void scan_chained_kernel<false>": (256 * nb + 4095) // 4096}
+        tot = 0.0
+        for kern, g in want.items():
+            tot += 4 * per.get("%s @%d" % (kern, g), 0.0)
+        return tot
     # one entry = bytes per LAUNCH of the stage as bench.py times it (a stage that is launched twice per iteration is
     # averaged over its two launches, like its avg_ms)
     stage = {
         "preprocess": k("void preprocess_kernel"),
-        "sort_depth": k("radix_global_hist_kernel") + 4 * k("radix_onesweep_kernel"),
+        "sort_depth": depth_sort_bytes(),
         "scan_emit": (k("void bin_kernel<false>") + k("void scan_chained_kernel<true>") + k("void bin_kernel<true>")) / 2,
         "sort_tile": 2 * (k("radix_hist_kernel") + k("void scan_chained_kernel<false>") + k("radix_scatter_kernel")),
         "tile_ranges": (k("tile_ranges_kernel") + 2 * k("tile_order_reg_kernel")) / 2,
