@@ -215,20 +215,63 @@ __global__ __launch_bounds__(EV_THREADS) void event_reduce_kernel(
     __shared__ double sred[EV_NSUM][EV_THREADS / WAVE];
     const float c = c_ptr[0];
     double acc[EV_NSUM] = {0, 0, 0, 0, 0};
-    for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
+    // one pixel: the per-pixel terms, accumulated in the order of the pixel index
+    auto pixel = [&](const float nx[3], const float nw[3], const float gx[3], const float gw[3], const float im[3],
+                     const float gi[3], const float gb[3]) {
         // logf, not the fast __logf: the mask rho = count(D* != 0) and sign(D - D*) hinge on exact zeros / ties, and the
         // reference's torch.log is the 1-ulp device logf (equal luminances give exactly D* = 0 with any deterministic log)
-        float D = (logf(lum3(next, HW, p) + 1e-8f) - logf(lum3(now, HW, p) + 1e-8f)) / c;
-        float Dg = (logf(lum3(gt_next, HW, p) + 1e-8f) - logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
+        auto lum = [](const float v[3]) { return FMA(0.1804f, v[2], FMA(0.35758f, v[1], 0.4124f * v[0])); };
+        float D = (logf(lum(nx) + 1e-8f) - logf(lum(nw) + 1e-8f)) / c;
+        float Dg = (logf(lum(gx) + 1e-8f) - logf(lum(gw) + 1e-8f)) / gt_c;
         float e = D - Dg;
         acc[0] += fabsf(e);
         acc[1] += (Dg != 0.0f) ? 1.0 : 0.0;
         acc[2] += (double)((e > 0.0f) - (e < 0.0f)) * (double)D;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float v = image[ch * HW + p];
-            acc[3] += fabsf(v - gt_int[ch * HW + p]);
-            if (gt_blur) acc[4] += fabsf(v - gt_blur[ch * HW + p]);
+            acc[3] += fabsf(im[ch] - gi[ch]);
+            if (gt_blur) acc[4] += fabsf(im[ch] - gb[ch]);
+        }
+    };
+    const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(now) |
+                                        reinterpret_cast<uintptr_t>(next) | reinterpret_cast<uintptr_t>(gt_int) |
+                                        reinterpret_cast<uintptr_t>(gt_now) | reinterpret_cast<uintptr_t>(gt_next) |
+                                        reinterpret_cast<uintptr_t>(gt_blur)) & 15) == 0;
+    if (vec) {
+        // four pixels per thread and trip, every plane read with 16-byte loads (a quarter of the load instructions)
+        const size_t HW4 = HW >> 2;
+        for (size_t q = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; q < HW4; q += (size_t)gridDim.x * EV_THREADS) {
+            float4 vn[3], vw[3], vgx[3], vgw[3], vim[3], vgi[3], vgb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                vn[ch] = reinterpret_cast<const float4*>(next + ch * HW)[q];
+                vw[ch] = reinterpret_cast<const float4*>(now + ch * HW)[q];
+                vgx[ch] = reinterpret_cast<const float4*>(gt_next + ch * HW)[q];
+                vgw[ch] = reinterpret_cast<const float4*>(gt_now + ch * HW)[q];
+                vim[ch] = reinterpret_cast<const float4*>(image + ch * HW)[q];
+                vgi[ch] = reinterpret_cast<const float4*>(gt_int + ch * HW)[q];
+                vgb[ch] = gt_blur ? reinterpret_cast<const float4*>(gt_blur + ch * HW)[q] : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                auto comp = [u](const float4& v) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); };
+                const float nx[3] = {comp(vn[0]), comp(vn[1]), comp(vn[2])}, nw[3] = {comp(vw[0]), comp(vw[1]), comp(vw[2])};
+                const float gx[3] = {comp(vgx[0]), comp(vgx[1]), comp(vgx[2])}, gw[3] = {comp(vgw[0]), comp(vgw[1]), comp(vgw[2])};
+                const float im[3] = {comp(vim[0]), comp(vim[1]), comp(vim[2])}, gi[3] = {comp(vgi[0]), comp(vgi[1]), comp(vgi[2])};
+                const float gb[3] = {comp(vgb[0]), comp(vgb[1]), comp(vgb[2])};
+                pixel(nx, nw, gx, gw, im, gi, gb);
+            }
+        }
+    } else {
+        for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
+            float nx[3], nw[3], gx[3], gw[3], im[3], gi[3], gb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                nx[ch] = next[ch * HW + p]; nw[ch] = now[ch * HW + p]; gx[ch] = gt_next[ch * HW + p];
+                gw[ch] = gt_now[ch * HW + p]; im[ch] = image[ch * HW + p]; gi[ch] = gt_int[ch * HW + p];
+                gb[ch] = gt_blur ? gt_blur[ch * HW + p] : 0.0f;
+            }
+            pixel(nx, nw, gx, gw, im, gi, gb);
         }
     }
 #pragma unroll
@@ -291,24 +334,81 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     const float kE = scalars[6], kI = scalars[7];
     const float kB = 0.5f / (3.0f * (float)HW);
     const float wch[3] = {0.4124f, 0.35758f, 0.1804f};
-    for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
-        float yn = lum3(next, HW, p) + 1e-8f, yo = lum3(now, HW, p) + 1e-8f;
+    // one pixel: inputs per channel -> the three gradient triples
+    auto pixel = [&](const float nx[3], const float nw[3], const float gx[3], const float gw[3], const float im[3],
+                     const float gi[3], const float gb[3], float dn[3], float dw[3], float di[3]) {
+        auto lum = [](const float v[3]) { return FMA(0.1804f, v[2], FMA(0.35758f, v[1], 0.4124f * v[0])); };
+        float yn = lum(nx) + 1e-8f, yo = lum(nw) + 1e-8f;
         float D = (logf(yn) - logf(yo)) / c;
-        float Dg = (logf(lum3(gt_next, HW, p) + 1e-8f) - logf(lum3(gt_now, HW, p) + 1e-8f)) / gt_c;
+        float Dg = (logf(lum(gx) + 1e-8f) - logf(lum(gw) + 1e-8f)) / gt_c;
         float e = D - Dg;
         float k = kE * (float)((e > 0.0f) - (e < 0.0f)) / c;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            d_next[ch * HW + p] = k * wch[ch] / yn;
-            d_now[ch * HW + p] = -(k * wch[ch]) / yo;
-            float v = image[ch * HW + p];
-            float ei = v - gt_int[ch * HW + p];
+            dn[ch] = k * wch[ch] / yn;
+            dw[ch] = -(k * wch[ch]) / yo;
+            float ei = im[ch] - gi[ch];
             float g = kI * (float)((ei > 0.0f) - (ei < 0.0f));
             if (gt_blur) {
-                float eb = v - gt_blur[ch * HW + p];
+                float eb = im[ch] - gb[ch];
                 g += kB * (float)((eb > 0.0f) - (eb < 0.0f));
             }
-            d_image[ch * HW + p] = g;
+            di[ch] = g;
+        }
+    };
+    const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(now) |
+                                        reinterpret_cast<uintptr_t>(next) | reinterpret_cast<uintptr_t>(gt_int) |
+                                        reinterpret_cast<uintptr_t>(gt_now) | reinterpret_cast<uintptr_t>(gt_next) |
+                                        reinterpret_cast<uintptr_t>(gt_blur) | reinterpret_cast<uintptr_t>(d_image) |
+                                        reinterpret_cast<uintptr_t>(d_now) | reinterpret_cast<uintptr_t>(d_next)) & 15) == 0;
+    if (vec) {
+        const size_t HW4 = HW >> 2;                          // four pixels per thread and trip, 16-byte loads and stores
+        for (size_t q = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; q < HW4; q += (size_t)gridDim.x * EV_THREADS) {
+            float4 vn[3], vw[3], vgx[3], vgw[3], vim[3], vgi[3], vgb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                vn[ch] = reinterpret_cast<const float4*>(next + ch * HW)[q];
+                vw[ch] = reinterpret_cast<const float4*>(now + ch * HW)[q];
+                vgx[ch] = reinterpret_cast<const float4*>(gt_next + ch * HW)[q];
+                vgw[ch] = reinterpret_cast<const float4*>(gt_now + ch * HW)[q];
+                vim[ch] = reinterpret_cast<const float4*>(image + ch * HW)[q];
+                vgi[ch] = reinterpret_cast<const float4*>(gt_int + ch * HW)[q];
+                vgb[ch] = gt_blur ? reinterpret_cast<const float4*>(gt_blur + ch * HW)[q] : make_float4(0, 0, 0, 0);
+            }
+            float on[3][4], ow[3][4], oi[3][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                auto comp = [u](const float4& v) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); };
+                const float nx[3] = {comp(vn[0]), comp(vn[1]), comp(vn[2])}, nw[3] = {comp(vw[0]), comp(vw[1]), comp(vw[2])};
+                const float gx[3] = {comp(vgx[0]), comp(vgx[1]), comp(vgx[2])}, gw[3] = {comp(vgw[0]), comp(vgw[1]), comp(vgw[2])};
+                const float im[3] = {comp(vim[0]), comp(vim[1]), comp(vim[2])}, gi[3] = {comp(vgi[0]), comp(vgi[1]), comp(vgi[2])};
+                const float gb[3] = {comp(vgb[0]), comp(vgb[1]), comp(vgb[2])};
+                float dn[3], dw[3], di[3];
+                pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { on[ch][u] = dn[ch]; ow[ch][u] = dw[ch]; oi[ch][u] = di[ch]; }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                reinterpret_cast<float4*>(d_next + ch * HW)[q] = make_float4(on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
+                reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
+                reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
+            }
+        }
+    } else {
+        for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
+            float nx[3], nw[3], gx[3], gw[3], im[3], gi[3], gb[3], dn[3], dw[3], di[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                nx[ch] = next[ch * HW + p]; nw[ch] = now[ch * HW + p]; gx[ch] = gt_next[ch * HW + p];
+                gw[ch] = gt_now[ch * HW + p]; im[ch] = image[ch * HW + p]; gi[ch] = gt_int[ch * HW + p];
+                gb[ch] = gt_blur ? gt_blur[ch * HW + p] : 0.0f;
+            }
+            pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                d_next[ch * HW + p] = dn[ch]; d_now[ch * HW + p] = dw[ch]; d_image[ch * HW + p] = di[ch];
+            }
         }
     }
 }
