@@ -188,7 +188,7 @@ int e3_knn_impl(int P, const float* pts, float* out, char* scratch, hipStream_t 
     knn_bbox_kernel<<<dim3(pb < 1024 ? pb : 1024), dim3(256), 0, s>>>(P, pts, bbox);
     knn_cellid_kernel<<<dim3(pb), dim3(256), 0, s>>>(P, pts, bbox, c0, i0);
     uint32_t *cs, *is;
-    launch_radix_sort_pairs(c0, c1, i0, i1, n, 21, sscr, &cs, &is, s);
+    if (int rc = launch_radix_sort_pairs(c0, c1, i0, i1, n, 21, sscr, &cs, &is, s)) return rc;
     e = hipMemsetAsync(cstart, 0, KNN_MAX_CELLS * 4, s);
     if (e != hipSuccess) return e3_fail(e, "knn memset");
     e = hipMemsetAsync(cend, 0, KNN_MAX_CELLS * 4, s);

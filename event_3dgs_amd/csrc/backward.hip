@@ -15,7 +15,7 @@
 constexpr int BWD_WAVES = 4;
 
 extern unsigned long long* g_trace;
-int launch_tile_order(int ntiles, int tiles_per_view, int gx, const uint2* ranges, const uint32_t* work, uint32_t* order,
+int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, const uint32_t* work, uint32_t* order,
                       hipStream_t s);
 #ifndef E3_BWD_WAVES
 #define E3_BWD_WAVES 6
@@ -445,11 +445,14 @@ constexpr int RR_CHUNK = 128;
 __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint32_t* __restrict__ order,
                                                          const uint2* __restrict__ run_sorted,
                                                          const float* __restrict__ part, float4* __restrict__ gsum,
-                                                         const uint32_t* __restrict__ depth_keys /* sorted */,
+                                                         const uint32_t* __restrict__ nvis /* [1]: length of the order */,
                                                          const uint8_t* __restrict__ touched /* per slot */) {
     __shared__ float sbuf[4][RR_CHUNK * E3_REC_FLOATS];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t j0 = blockIdx.x * 256u + wave * 64u, j = j0 + lane;
+    // the depth-sorted order holds only the splats the projection kept (the depth sort dropped the others): nothing to
+    // sum, and no sum to store, for the rest -- the per-Gaussian kernels never read the sums of culled splats
+    Q = __builtin_amdgcn_readfirstlane(*nvis);
     if (j0 >= Q) return;
     const uint32_t nl = (Q - j0 < 64u ? Q - j0 : 64u) - 1u;          // last lane with a splat
     const uint2 rn = j < Q ? run_sorted[j] : make_uint2(0u, 0u);
@@ -492,10 +495,8 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
         }
         wave_sync();
     }
-    // zeros for splats whose every tile was culled (their radius can still be > 0); nothing for the splats the projection
-    // culled (radius 0, all-ones depth key, the tail of the order): the per-Gaussian kernels never read their sums, and a
-    // third of the scattered 48-byte stores goes away
-    if (j < Q && depth_keys[j] != 0xFFFFFFFFu) {
+    // (zeros for splats whose every tile was culled: their radius can still be > 0)
+    if (j < Q) {
         const size_t q = order[j];
         gsum[3 * q] = make_float4(a[0], a[1], a[2], a[3]);
         gsum[3 * q + 1] = make_float4(a[4], a[5], a[6], a[7]);
@@ -510,9 +511,10 @@ __global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const 
                                                               const uint2* __restrict__ run_sorted,
                                                               const float* __restrict__ part,
                                                               float4* __restrict__ gsum,
-                                                              const uint8_t* __restrict__ touched) {
+                                                              const uint8_t* __restrict__ touched,
+                                                              const uint32_t* __restrict__ nvis) {
     const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (j >= Q) return;
+    if (j >= *nvis) return;                  // (the order holds the kept splats only)
     const uint2 rn = run_sorted[j];
     const float* __restrict__ p = part + E3_REC_FLOATS * (size_t)rn.x;
     float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1090,10 +1092,10 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     float4* gsum = reinterpret_cast<float4*>(grad_acc + E3_ACC_STRIDE * (size_t)num_rendered);
     if (num_rendered > 0 && Q <= E3_RUN_REDUCE_WAVE_MAX && g_small_scene_paths)
         run_reduce_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                    grad_acc, gsum, bin.touched);
+                                                                                    grad_acc, gsum, bin.touched, geom.nvis);
     else if (num_rendered > 0)
         run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                   grad_acc, gsum, geom.key0, bin.touched);
+                                                                                   grad_acc, gsum, geom.nvis, bin.touched);
     else        // no instance at all (a radius can still be > 0 when every tile of the splat was culled): zero sums
     {
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);

@@ -14,7 +14,7 @@ int e3_fail(hipError_t e, const char* what) {
 }
 
 // exact tile culling (forward.hip: tile_touched); E3DGS_TILE_CULL=0 in the environment disables it
-int g_tile_cull = [] { const char* e = getenv("E3DGS_TILE_CULL"); return (e && e[0] == '0') ? 0 : 1; }();
+int g_tile_cull = [] { const char* e = getenv("E3DGS_TILE_CULL"); return (e && e[0] == '0') ? 0 : (e && e[0] == '3') ? 3 : 1; }();
 int g_small_scene_paths = [] { const char* e = getenv("E3DGS_SMALL_SCENE_PATHS"); return (e && e[0] == '0') ? 0 : 1; }();
 
 // ---- event profiler
@@ -70,7 +70,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 10; }
+int e3dgs_abi_version(void) { return 11; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -482,9 +482,38 @@ int e3dgs_densify_apply(int P, int P_new, const int* counts4, const float* param
                                  exp_avg_sq_new, scratch, (hipStream_t)stream);
 }
 
+size_t e3dgs_sort_scratch_bytes(size_t n) { return sort_scratch_words(n ? n : 1) * sizeof(uint32_t) + 256; }
+int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1,
+                     int identity_payload, char* scratch, uint32_t* kept_count_dev, uint32_t* ranges, uint32_t nranges,
+                     int* result_index_host, void* stream) {
+    g_err[0] = 0;
+    if ((key_bytes != 2 && key_bytes != 4) || nbits < 0 || nbits > 8 * key_bytes || !result_index_host)
+        return e3_fail(hipErrorInvalidValue, "key_bytes must be 2 or 4, 0 <= nbits <= 8 * key_bytes");
+    if (n >= 0xFFFFFFFFull) return e3_fail(hipErrorInvalidValue, "n must be below 2^32 - 1");
+    if (n > 0 && (!keys0 || !keys1 || !vals0 || !vals1 || !scratch)) return e3_fail(hipErrorInvalidValue, "null pointer");
+    if (kept_count_dev && key_bytes != 4) return e3_fail(hipErrorInvalidValue, "dropping all-ones keys needs 32-bit keys");
+    if ((reinterpret_cast<uintptr_t>(scratch) & 7) != 0) return e3_fail(hipErrorInvalidValue, "scratch must be 8-byte aligned");
+    uint32_t* vout = nullptr;
+    int rc;
+    if (key_bytes == 4) {
+        uint32_t* kout;
+        rc = launch_radix_sort_pairs((uint32_t*)keys0, (uint32_t*)keys1, vals0, vals1, n, nbits, (uint32_t*)scratch, &kout,
+                                     &vout, (hipStream_t)stream, identity_payload != 0, kept_count_dev, nullptr,
+                                     (uint2*)ranges, nranges);
+    } else {
+        uint16_t* kout;
+        rc = launch_radix_sort_pairs_u16((uint16_t*)keys0, (uint16_t*)keys1, vals0, vals1, n, nbits, (uint32_t*)scratch,
+                                         &kout, &vout, (hipStream_t)stream, identity_payload != 0, nullptr, (uint2*)ranges,
+                                         nranges);
+    }
+    if (rc) return rc;
+    *result_index_host = (vout == vals1) ? 1 : 0;
+    return 0;
+}
+
 extern unsigned long long* g_trace;
 void e3dgs_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }   /* not in the public header */
-void e3dgs_set_tile_cull(int on) { g_tile_cull = on ? 1 : 0; }
+void e3dgs_set_tile_cull(int on) { g_tile_cull = on == 3 ? 3 : (on ? 1 : 0); }
 int e3dgs_get_tile_cull(void) { return g_tile_cull; }
 void e3dgs_set_small_scene_paths(int on) { g_small_scene_paths = on ? 1 : 0; }
 int e3dgs_get_small_scene_paths(void) { return g_small_scene_paths; }

@@ -144,13 +144,14 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 static inline size_t sort_blocks(size_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 static inline size_t scan_blocks(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
-// scratch (in uint32) needed to sort n pairs: per-block digit histograms + scan block sums
+// scratch (in uint32) needed to sort n pairs: per-workgroup digit histograms (with the 256 extra workgroups of a
+// segment-aligned last pass), the 257 segment boundaries, the 64-bit descriptors of the chained scan (+ ticket)
 static inline size_t sort_scratch_words(size_t n) {
-    size_t h = sort_blocks(n) * 256;
-    size_t classic = h + scan_blocks(h) + 64;
-    size_t onesweep = 1024 + 64 + 4 * h;      // global histograms, tickets, per-pass look-back descriptors
-    return classic > onesweep ? classic : onesweep;
+    size_t h = (sort_blocks(n) + 256) * 256;
+    return h + 260 + 2 * (scan_blocks(h) + 1) + 64;
 }
+// words (uint32) of the descriptors of a chained scan over n elements (64-bit descriptors + ticket)
+static inline size_t scan_desc_words(size_t n) { return 2 * (scan_blocks(n) + 1); }
 
 // ---------------------------------------------------------------- scratch layouts
 // Splats per binning wave = 1 << shift: 64 when there are plenty of splats, fewer when the launch would otherwise
@@ -182,6 +183,8 @@ struct GeomState {
     uint32_t* offsets; // inclusive scan of `tiles`
     uint32_t* scratch; // sort/scan scratch
     uint32_t* total;   // [1] instance count (device copy)
+    uint32_t* nvis;    // [1] splats the projection kept = length of the depth-sorted order (key0 / ord0): the depth sort
+                       // drops the culled ones in its first pass, and every kernel behind it reads its count here
     static size_t required(size_t P) {
         char* p = nullptr;
         from(p, P);
@@ -200,8 +203,9 @@ struct GeomState {
         g.ord1 = carve<uint32_t>(p, n);
         g.tiles = carve<uint32_t>(p, n);
         g.offsets = carve<uint32_t>(p, n + 64);      // [0] = 0, then one entry per binning wave (<= n of them)
-        g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_blocks(n) + 64);
+        g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_desc_words(n) + 64);
         g.total = carve<uint32_t>(p, 64);
+        g.nvis = g.total + 16;
         return g;
     }
 };
@@ -351,21 +355,30 @@ int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
                           size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
                           float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s);
 
-// launchers implemented in scan_sort.hip
-void launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
-                             hipStream_t s, int* total_host = nullptr);   // one launch; desc_zeroed: scan_blocks(n) + 1
-                             // words, zero on entry; total_host: mapped host word that receives the grand total
-void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
-                               hipStream_t s);
-// Stable LSD radix sort of (key,val) u32 pairs on bits [0,nbits).  Result is returned in
-// (*keys_out,*vals_out) which are one of the two provided buffer pairs.
+// launchers implemented in scan_sort.hip (0 or a hipError_t code; the text is in e3dgs_last_error())
+int launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
+                            hipStream_t s, int* total_host = nullptr, uint32_t* total_dev = nullptr);
+                            // one launch; desc_zeroed: scan_desc_words(n) words, 8-byte aligned, zero on entry;
+                            // total_host: mapped host word / total_dev: device word that receives the grand total
+int launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
+                              hipStream_t s);
+// Stable LSD radix sort of (key,val) pairs on bits [0,nbits).  The result is returned in (*keys_out,*vals_out), which
+// are one of the two provided buffer pairs.
 // identity_payload: v0 is NOT read; the payload of element i is i (saves writing and reading the index array).
-void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
-                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
-                             bool identity_payload = false, bool scratch_zeroed = false);
-// words at the start of the sort scratch that must be zero when launch_radix_sort_pairs(n, nbits) is called with
-// scratch_zeroed = true (0: that sort needs none); lets the kernel in front of the sort do the zeroing
-size_t radix_sort_zero_words(size_t n, int nbits);
+// drop_count_dev:   (u32 keys) keys equal to 0xFFFFFFFF are dropped by the first pass; the number of kept keys is stored
+//                   there and the later passes sort those only.
+// n_dev:            the element count lives in device memory (n is then the host's upper bound, which sizes the grids).
+// ranges_out:       after the sort, ranges_out[k] = [first, last + 1) positions of key k (k < nranges); keys without an
+//                   element keep what they held (an empty range).  A two-pass sort derives them inside its last pass and
+//                   writes no sorted keys (*keys_out = NULL).
+int launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
+                            uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
+                            bool identity_payload = false, uint32_t* drop_count_dev = nullptr,
+                            const uint32_t* n_dev = nullptr, uint2* ranges_out = nullptr, uint32_t nranges = 0);
+int launch_radix_sort_pairs_u16(uint16_t* k0, uint16_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
+                                uint32_t* scratch, uint16_t** keys_out, uint32_t** vals_out, hipStream_t s,
+                                bool identity_payload = false, const uint32_t* n_dev = nullptr,
+                                uint2* ranges_out = nullptr, uint32_t nranges = 0);
 static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---------------------------------------------------------------- optional event profiler (capi.hip)

@@ -153,7 +153,8 @@ int e3_densify_plan_impl(int N, const float* param, const float* grad_accum, con
     densify_flags_kernel<<<dim3(nb), dim3(256), 0, st>>>(N, param, grad_accum, denom, max_grad, min_opacity,
                                                          (float)((double)percent_dense * (double)extent),
                                                          (float)(0.1 * (double)extent), size_prune, f[0], f[1], f[2], f[3]);
-    for (int k = 0; k < 4; ++k) launch_exclusive_scan_u32(f[k], s[k], (size_t)N, scan_scratch, false, st);
+    for (int k = 0; k < 4; ++k)
+        if (int rc = launch_exclusive_scan_u32(f[k], s[k], (size_t)N, scan_scratch, false, st)) return rc;
     densify_split_rows_kernel<<<dim3(nb), dim3(256), 0, st>>>(N, f[2], s[2], rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e3_fail(e, "densify plan kernels");

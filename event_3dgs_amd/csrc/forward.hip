@@ -141,13 +141,12 @@ __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key,
     uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0,
-    uint32_t* __restrict__ scan_desc, int ndesc, uint32_t* __restrict__ sort_zero, int nsort) {
+    uint32_t* __restrict__ scan_desc, int ndesc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // housekeeping that would otherwise be memset commands (each costs a barrier packet on the queue): the tile ranges,
     // offsets[0], and the descriptors of the single-launch scan behind the binning count pass
     for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
     for (int t = i; t < ndesc; t += gridDim.x * blockDim.x) scan_desc[t] = 0u;
-    for (int t = i; t < nsort; t += gridDim.x * blockDim.x) sort_zero[t] = 0u;        // look-back state of the depth sort
     if (i == 0) *offsets0 = 0u;
     if (i >= P) return;
     const int nv = vs.n;
@@ -362,12 +361,12 @@ constexpr int BIN_WAVES = 4;
 template <bool EMIT>
 __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift, int nviews, int ntiles,
                                                               const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ depth_keys /* sorted */,
+                                                              const uint32_t* __restrict__ nvis /* [1]: length of `order` */,
                                                               const uint2* __restrict__ rect, int packed_rect,
                                                               const float4* __restrict__ rec, int gx, int cull,
                                                               const uint32_t* __restrict__ wave_offsets,
                                                               uint32_t* __restrict__ wave_counts,
-                                                              uint32_t* __restrict__ keys,
+                                                              void* __restrict__ keys, int keys16,
                                                               uint32_t* __restrict__ emit_gid,
                                                               uint2* __restrict__ run_sorted,
                                                               uint8_t* __restrict__ touched) {
@@ -381,26 +380,29 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     const int gw = blockIdx.x * BIN_WAVES + wave;
     const int s = (gw << gshift) + lane;
     if ((gw << gshift) >= P) return;
-    const bool mine = lane < (1 << gshift) && s < P;
+    // `order` holds the splats the projection kept, by depth: the depth sort dropped the culled ones (their count is
+    // only known on the device).  Waves behind the end have nothing to walk.
+    const int nv = (int)__builtin_amdgcn_readfirstlane(*nvis);
+    if ((gw << gshift) >= nv) {
+        if (!EMIT && lane == 0) wave_counts[gw] = 0u;
+        return;
+    }
+    const bool mine = lane < (1 << gshift) && s < nv;
     uint32_t n = 0, g = 0;
     float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
     if (mine) {
         g = order[s];
-        // Culled splats carry the all-ones depth key and sit at the end of the order: known from the (coalesced) sorted
-        // key, without touching their records.  For the others ONE gather of the 48-byte record delivers the rectangle too
-        // (8 bits per bound in its spare word, grids up to 255 x 255 tiles; the 16-bit array otherwise): the rectangle
-        // array used to cost a second 128-byte line per splat and pass.
-        uint2 r = make_uint2(0u, 0u);
-        float4 t = make_float4(0, 0, 0, 0);
-        if (depth_keys[s] != 0xFFFFFFFFu) {
-            a = rec[3 * (size_t)g];
-            t = rec[3 * (size_t)g + 1];
-            if (packed_rect) {
-                const uint32_t p = __float_as_uint(rec[3 * (size_t)g + 2].w);
-                r = make_uint2((p & 255u) | (((p >> 8) & 255u) << 16), ((p >> 16) & 255u) | ((p >> 24) << 16));
-            } else {
-                r = rect[g];
-            }
+        // ONE gather of the 48-byte record delivers the rectangle too (8 bits per bound in its spare word, grids up to
+        // 255 x 255 tiles; the 16-bit array otherwise): the rectangle array used to cost a second 128-byte line per
+        // splat and pass.
+        uint2 r;
+        a = rec[3 * (size_t)g];
+        const float4 t = rec[3 * (size_t)g + 1];
+        if (packed_rect) {
+            const uint32_t p = __float_as_uint(rec[3 * (size_t)g + 2].w);
+            r = make_uint2((p & 255u) | (((p >> 8) & 255u) << 16), ((p >> 16) & 255u) | ((p >> 24) << 16));
+        } else {
+            r = rect[g];
         }
         uint32_t w = (r.y & 0xFFFFu) - (r.x & 0xFFFFu), h = (r.y >> 16) - (r.x >> 16);
         n = w * h;
@@ -416,17 +418,21 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
             // ellipse q <= thr can reach.  Nearly half of the candidates fail that test, and every one costs both binning
             // passes a search + test.  The axis-aligned box of the (inflated) ellipse is known in closed form --
             // |dx| <= sqrt(thr' C / det), |dy| <= sqrt(thr' A / det) -- so only its tiles are walked.  thr' carries the
-            // relative slack tile_touched() subtracts (1e-4 of the summed |terms|, bounded over the square) and the box a
-            // pixel of margin: every tile outside it fails tile_touched(), i.e. the kept set is unchanged.
-            if (cull) {
+            // relative slack tile_touched() subtracts (1e-4 of the summed |terms|, bounded over the rectangle's pixels) and the
+            // box a pixel of margin: every tile outside it fails tile_touched(), i.e. the kept set is unchanged
+            // (tests/test_hip_parity.py::test_tight_candidate_box_keeps_the_same_instances).
+            if (cull == 1) {                            // (cull == 3: exact culling without the tight box, for the fuzz test)
                 const float A = a.z, B = a.w, C = t.x, det = A * C - B * B;
                 if (A > 0.0f && C > 0.0f && det > 0.0f) {
-                    const float ex = 16.0f * (float)w, ey = 16.0f * (float)h;                   // |dx|, |dy| inside the square
+                    const int x0r = (int)(r.x & 0xFFFFu), y0r = (int)(r.x >> 16), x1r = (int)(r.y & 0xFFFFu), y1r = (int)(r.y >> 16);
+                    // largest |dx|, |dy| between the centre and a pixel of the (grid-clamped) rectangle: for a centre off
+                    // the screen that is more than the rectangle's own extent
+                    const float ex = fmaxf(fabsf(a.x - 16.0f * (float)x0r), fabsf(a.x - (16.0f * (float)x1r - 1.0f)));
+                    const float ey = fmaxf(fabsf(a.y - 16.0f * (float)y0r), fabsf(a.y - (16.0f * (float)y1r - 1.0f)));
                     const float thr2 = thr + 2e-4f * (A * ex * ex + C * ey * ey) * 1.01f + 1e-3f;
                     if (thr2 > 0.0f) {
                         const float hx = __builtin_sqrtf(thr2 * C / det) * 1.001f + 1.0f;
                         const float hy = __builtin_sqrtf(thr2 * A / det) * 1.001f + 1.0f;
-                        const int x0r = (int)(r.x & 0xFFFFu), y0r = (int)(r.x >> 16), x1r = (int)(r.y & 0xFFFFu), y1r = (int)(r.y >> 16);
                         // pixels of tile t span [16 t, 16 t + 15]
                         const int tx0 = max(x0r, (int)__builtin_floorf((a.x - hx - 15.0f) * (1.0f / 16.0f))),
                                   tx1 = min(x1r, (int)__builtin_floorf((a.x + hx) * (1.0f / 16.0f)) + 1),
@@ -489,7 +495,9 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
             // SLOT: where backward parks its gradient record; the kept instances of one splat are contiguous.
             // The sort payload is this position itself, so no payload array is written (identity_payload)
             const uint32_t pos = out_base + count + (uint32_t)__popcll(mask & lt_mask);
-            keys[pos] = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+            const uint32_t tile_id = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
+            if (keys16) reinterpret_cast<uint16_t*>(keys)[pos] = (uint16_t)tile_id;      // (<= 65536 tiles: 16-bit sort keys)
+            else reinterpret_cast<uint32_t*>(keys)[pos] = tile_id;
             emit_gid[pos] = sId[wave][j];
             touched[pos] = 0;                       // (render_fwd_kernel sets it for the instances it evaluates)
             atomicAdd(&sCnt[wave][j], 1u);
@@ -512,32 +520,13 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     }
 }
 
-// After the stable tile sort: [start, end) of each tile.  The sort moved (tile id, emission index) pairs; the
-// compositing kernels translate emission index -> Gaussian id themselves (`emit_gid`, a small L2-resident gather
-// that rides in their staging pipeline) and backward stores each instance's gradient record at its EMISSION
+// After the stable tile sort the [start, end) of each tile comes out of the sort itself (scan_sort.hip: the last
+// pass of a two-pass sort derives the ranges from its scanned histogram).  The sort moved (tile id, emission index)
+// pairs; the compositing kernels translate emission index -> Gaussian id themselves (`emit_gid`, a small L2-resident
+// gather that rides in their staging pipeline) and backward stores each instance's gradient record at its EMISSION
 // position, where the records of one Gaussian are contiguous -- that turns the reference's float atomics into
 // plain stores plus a per-Gaussian run reduction (deterministic, and ~2x faster: the atomics were 44 % of the
 // compositing backward on this chip).
-__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t I, const uint32_t* __restrict__ keys,
-                                                          uint2* __restrict__ ranges) {
-    // four consecutive sorted keys per thread (one 16-byte load + the two neighbours): a quarter of the threads and load
-    // instructions of the one-key-per-thread form for the same 4 I bytes
-    const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
-    if (i0 >= I) return;
-    uint32_t k[6];                                            // keys[i0 - 1 .. i0 + 4]
-    const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);      // (the key buffer is padded: BinningState carves n >= I)
-    k[1] = q.x; k[2] = q.y; k[3] = q.z; k[4] = q.w;
-    k[0] = i0 ? keys[i0 - 1] : 0xFFFFFFFFu;
-    k[5] = i0 + 4u < I ? keys[i0 + 4u] : 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t i = i0 + (uint32_t)j;
-        if (i >= I) break;
-        const uint32_t t = k[j + 1];
-        if (i == 0 || k[j] != t) ranges[t].x = i;
-        if (i == I - 1 || k[j + 2] != t) ranges[t].y = i + 1;
-    }
-}
 
 // ------------------------------------------------------------------------------------ compositing
 // One wave per 16x16 tile.  Lane l owns column (l & 15) and rows (l >> 4) + 4k, k = 0..3, so the
@@ -551,7 +540,16 @@ constexpr int RENDER_WAVES = 4;
 // last long tiles run alone on their SIMDs at single-wave (latency-bound) speed.  Single workgroup:
 // block max -> 1024-bucket histogram in LDS -> scan -> scatter.  Order inside a bucket is arbitrary, which
 // only affects scheduling, never results.
-__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint2* __restrict__ ranges,
+// The last pass of the tile sort leaves tiles without an instance with an empty range start == end (the position
+// where their run would sit); the documented state -- what the reference's identifyTileRanges leaves, and what the
+// parity tests compare -- is (0, 0).  The forward ordering kernel is the first reader of the ranges and rewrites them.
+__device__ __forceinline__ uint2 normalise_empty_range(uint2* __restrict__ ranges, int t) {
+    uint2 r = ranges[t];
+    if (r.x == r.y && r.x != 0u) { r = make_uint2(0u, 0u); ranges[t] = r; }
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ work,
                                                           uint32_t* __restrict__ order) {
     auto key = [&](int t) -> uint32_t { if (work) return work[t]; uint2 r = ranges[t]; return r.y - r.x; };
@@ -560,6 +558,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
     __shared__ uint32_t smax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t m = 0;
+    if (!work)      // (forward order: this kernel is the first reader of the ranges the tile sort wrote)
+        for (int t = tid; t < ntiles; t += 1024) normalise_empty_range(ranges, t);
     for (int t = tid; t < ntiles; t += 1024) m = max(m, key(t));
     m = wave_max_u32(m);
     if (lane == 0) wsum[wave] = m;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const uint
 // memory is read once instead of three times and the three phases only touch LDS (30 -> ~10 us; this kernel sits
 // alone on the GPU twice per iteration).
 constexpr int ORDER_ITEMS = 32;
-__global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, uint2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ work,
                                                               uint32_t* __restrict__ order) {
     __shared__ uint32_t hist[1024];
@@ -614,6 +614,7 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const 
             const int t = tid + i * 1024;
             const uint2 r = ranges[t < ntiles ? t : ntiles - 1];
             key[i] = r.y - r.x;
+            if (t < ntiles && r.x == r.y && r.x != 0u) ranges[t] = make_uint2(0u, 0u);      // normalise_empty_range
         }
     }
 #pragma unroll
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, const 
 // XCD-partitioned variant: bucket = region * 128 + (127 - work / width); slot of the k-th heaviest tile of region r is
 // (k / 4) * 32 + r * 4 + (k % 4), i.e. the 4-tile workgroup w = slot / 4 belongs to region w % 8.  Unused slots hold ~0u.
 __global__ __launch_bounds__(1024) void tile_order_xcd_kernel(int ntiles, int nslots, int tiles_per_view, int gx, int B,
-                                                              const uint2* __restrict__ ranges,
+                                                              uint2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ work,
                                                               uint32_t* __restrict__ order) {
     __shared__ uint32_t hist[1024];
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(1024) void tile_order_xcd_kernel(int ntiles, int ns
         uint32_t k = 0;
         if (t < ntiles) {
             if (work) k = work[t];
-            else { const uint2 r = ranges[t]; k = r.y - r.x; }
+            else { const uint2 r = normalise_empty_range(ranges, t); k = r.y - r.x; }
         }
         key[i] = k;
         m = max(m, k);
@@ -726,7 +727,7 @@ static int xcd_block() {
 }
 
 // Returns the number of launch slots (== ntiles unless the XCD-partitioned order is on).
-int launch_tile_order(int ntiles, int tiles_per_view, int gx, const uint2* ranges, const uint32_t* work, uint32_t* order,
+int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, const uint32_t* work, uint32_t* order,
                       hipStream_t s) {
     const int B = xcd_block();
     if (B > 0 && ntiles <= ORDER_ITEMS * 1024 && ntiles >= 64) {
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
 
 // ------------------------------------------------------------------------------------ host driver
 extern thread_local char g_err[512];
-extern int g_tile_cull;
+extern int g_tile_cull;          // 0: reference rectangle binning, 1: exact culling, 3: exact culling without the tight box
 extern int g_small_scene_paths;
 int e3_fail(hipError_t e, const char* what);
 #define HIP_OK(expr)                                          \
@@ -1005,15 +1006,16 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                                                             : preprocess_kernel<4, false>);
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                            geom.offsets, bin_scan_desc, (int)scan_blocks(Q) + 1, geom.scratch,
-                                            (int)radix_sort_zero_words(Q, 32));
+                                            geom.offsets, bin_scan_desc, (int)scan_desc_words(Q));
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
         {
         ProfScope ps(PS_SORT_DEPTH, s);
-        launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, 32, geom.scratch, &keys_sorted,
-                                &order, s, true, true);
+        // culled splats carry the all-ones key: the first pass drops them, geom.nvis receives the kept count
+        const int rc = launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, 32, geom.scratch,
+                                               &keys_sorted, &order, s, true, geom.nvis);
+        if (rc) return rc;
         }
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0 || keys_sorted != geom.key0)
@@ -1023,13 +1025,14 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, keys_sorted,
+        bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, geom.nvis,
                                                                      geom.rect, vs.v[0].gx <= 255 && vs.v[0].gy <= 255,
                                                                      geom.rec, vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
-                                                                     nullptr, nullptr, nullptr, nullptr);
+                                                                     nullptr, 0, nullptr, nullptr, nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
-        launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
-                                (flags & E3_FLAG_COUNT_MAPPED) ? count_host : nullptr);
+        const int rc = launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
+                                               (flags & E3_FLAG_COUNT_MAPPED) ? count_host : nullptr);
+        if (rc) return rc;
         }
         KERNEL_OK("bin count + scan");
         // the instance count sizes the binning buffers: the op's single device->host read-back
@@ -1058,6 +1061,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         // at least one pass even for a single tile: the first pass is what materialises the identity payload
         const int tile_bits = ntiles > 1 ? ceil_log2((uint32_t)ntiles) : 1;
         const int passes = radix_passes(tile_bits);
+        const int keys16 = ntiles <= 65536 ? 1 : 0;           // 16-bit sort keys: a third of the sort's bytes less per pass
         // choose the emit target so that the final sorted values (slot indices) land in bin.perm
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.perm, *v1 = bin.vals_alt;
         if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
@@ -1067,24 +1071,31 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         {
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
-                                                                    geom.key0 /* sorted keys: four passes end here */,
-                                                                    geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
-                                                                    g_tile_cull, geom.offsets, nullptr, k0, bin.emit_gid,
-                                                                    geom.run, bin.touched);
+                                                                    geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
+                                                                    g_tile_cull, geom.offsets, nullptr, k0, keys16,
+                                                                    bin.emit_gid, geom.run, bin.touched);
         }
         KERNEL_OK("bin emit");
-        uint32_t *ks, *vs;
+        uint32_t* vs;
         {
+        // stable sort by tile id; the [start, end) of every tile comes out of the same launches (img.ranges: zeroed by
+        // the preprocess kernel, tiles without an instance stay / are rewritten as (0, 0) by the ordering kernel)
         ProfScope ps(PS_SORT_TILE, s);
-        launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s, true);
+        int rc;
+        if (keys16) {
+            uint16_t* ks16;
+            rc = launch_radix_sort_pairs_u16(reinterpret_cast<uint16_t*>(k0), reinterpret_cast<uint16_t*>(k1), v0, v1,
+                                             (size_t)I, tile_bits, bin.scratch, &ks16, &vs, s, true, nullptr, img.ranges,
+                                             (uint32_t)ntiles);
+        } else {
+            uint32_t* ks;
+            rc = launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s, true, nullptr,
+                                         nullptr, img.ranges, (uint32_t)ntiles);
+        }
+        if (rc) return rc;
         }
         KERNEL_OK("radix sort (tile)");
         if (vs != bin.perm) return e3_fail(hipErrorUnknown, "internal: sorted list not in perm");
-        {
-        ProfScope ps(PS_RANGES, s);
-        tile_ranges_kernel<<<dim3((I + 1023) / 1024), dim3(256), 0, s>>>(I, ks, img.ranges);
-        }
-        KERNEL_OK("tile_ranges_kernel");
     }
     int nslots = ntiles;
     {

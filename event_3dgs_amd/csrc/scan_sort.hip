@@ -5,17 +5,35 @@
 //
 // Radix pass = three launches:
 //   radix_hist     per-workgroup digit histogram (LDS atomics), digit-major global layout
-//   scan           exclusive scan of the 256 x nblocks counters -> global base of (digit, block)
+//   scan           exclusive scan of the 256 x nblocks counters -> global base of (digit, block); ONE launch
+//                  (chained scan with decoupled look-back)
 //   radix_scatter  stable ranking: each wave owns a contiguous run of the workgroup's keys and
 //                  ranks 64 keys per round with a wave64 ballot match (8 ballots for an 8-bit
 //                  digit); per-wave digit counters live in LDS; waves are combined by a
-//                  prefix over the 4 wave counters.  No inter-workgroup communication inside a
-//                  launch, so no agent-scope fences are needed.
+//                  prefix over the 4 wave counters; keys are staged through LDS so that the global stores of a
+//                  store instruction cover consecutive addresses inside each digit segment.
+//
+// The kernels are templated on the key type: the tile sort of a frame with <= 65536 tiles moves 16-bit keys
+// (a third of its bytes less per pass), the depth sort 32-bit keys.  Two extras serve the rasteriser:
+//   DROP   (first pass of the depth sort) keys equal to 0xFFFFFFFF -- splats the projection culled, a third of the
+//          keys of the benchmark scene -- are not counted and not scattered: the sort compacts while it sorts, the
+//          kept count goes to device memory, and the later passes (and everything behind the sort) read their element
+//          count from there.
+//   NOKEYS (last pass of the tile sort) only the payload is written: nobody reads the sorted keys once the tile
+//          ranges are known -- they are derived in the same kernel (see radix_scatter_kernel).
 #include "common.h"
 #include <stdlib.h>
 
+int e3_fail(hipError_t e, const char* what);
+#define LAUNCH_OK(name)                                       \
+    do {                                                      \
+        hipError_t _e = hipGetLastError();                    \
+        if (_e != hipSuccess) return e3_fail(_e, name);       \
+    } while (0)
+
 // ------------------------------------------------------------------------------------ scan
-// 3-phase scan: block sums -> spine (one workgroup, loops) -> block scan with carry-in.
+// 3-phase scan: block sums -> spine (one workgroup, loops) -> block scan with carry-in.  Needs no zeroed state:
+// used where no kernel in front of the scan could prepare the chained scan's descriptors (densify.hip).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                    uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
@@ -94,35 +112,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t
     }
 }
 
-void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
-                               hipStream_t s) {
-    if (n == 0) return;
+int launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch, bool inclusive,
+                              hipStream_t s) {
+    if (n == 0) return 0;
     size_t nb = scan_blocks(n);
     scan_reduce_kernel<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, n, scratch);
+    LAUNCH_OK("scan_reduce_kernel");
     scan_spine_kernel<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(scratch, nb);
+    LAUNCH_OK("scan_spine_kernel");
     if (inclusive)
         scan_final_kernel<true><<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, scratch);
     else
         scan_final_kernel<false><<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, scratch);
+    LAUNCH_OK("scan_final_kernel");
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------ single-launch scan
 // The same scan in ONE launch (chained scan with decoupled look-back): for the scans that sit between two kernels of
-// the list-building chain, where three launches of ~5 us each cost more than the scan itself.  Protocol as in
-// radix_onesweep_kernel (cdna_hip_programming.md G16, form R2): one 32-bit descriptor {2-bit status, 30-bit sum} per
-// workgroup, relaxed agent-scope atomics, logical workgroup ids from an atomic ticket.  Wave 0 of a workgroup looks
-// back 64 predecessors at a time.  `desc` = nb + 1 words (descriptors, then the ticket) that MUST be zero on entry:
-// the kernel in front of the scan in the stream zeroes them (radix_hist_kernel / preprocess_kernel), which costs
-// no extra command.  Sums must stay below 2^30.
-constexpr uint32_t SC_AGG = 1u << 30, SC_PREFIX = 2u << 30, SC_MASK = (1u << 30) - 1u;
+// the list-building chain, where three launches of ~5 us each cost more than the scan itself.  Protocol
+// (cdna_hip_programming.md G16, form R2): one 64-bit descriptor {2-bit status, 62-bit sum} per workgroup -- the data is
+// its own flag -- written and read with relaxed agent-scope atomics; logical workgroup ids come from an atomic ticket,
+// so a workgroup only ever waits for workgroups that have already started.  Wave 0 of a workgroup looks back 64
+// predecessors at a time.  `desc` = nb + 1 words (descriptors, then the ticket) that MUST be zero on entry: the kernel
+// in front of the scan in the stream zeroes them (radix_hist_kernel / preprocess_kernel), which costs no extra command.
+// The 32-bit elements may sum up to anything a uint32 holds (the 62-bit field cannot overflow; round 2 packed
+// {status, 30-bit sum} into one 32-bit word, which silently corrupted the status bits beyond 2^30 instances).
+constexpr unsigned long long SC_AGG = 1ull << 62, SC_PREFIX = 2ull << 62, SC_MASK = (1ull << 62) - 1ull;
 template <bool INCLUSIVE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32_t* in, uint32_t* out, size_t n,
-                                                                    uint32_t* desc, unsigned nb,
-                                                                    volatile int* total_host) {
+                                                                    unsigned long long* desc, unsigned nb,
+                                                                    volatile int* total_host, uint32_t* total_dev) {
     __shared__ uint32_t wtot[SCAN_THREADS / WAVE];
     __shared__ uint32_t s_bid, s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_bid = atomicAdd(desc + nb, 1u);
+    if (threadIdx.x == 0) s_bid = (uint32_t)atomicAdd(desc + nb, 1ull);
     __syncthreads();
     const uint32_t bid = s_bid;
     const size_t base = (size_t)bid * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
@@ -154,20 +178,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
     if (wave == 0) {
         const uint32_t total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
         if (lane == 0)
-            __hip_atomic_store(desc + bid, (bid == 0 ? SC_PREFIX : SC_AGG) | total, __ATOMIC_RELAXED,
+            __hip_atomic_store(desc + bid, (bid == 0 ? SC_PREFIX : SC_AGG) | (unsigned long long)total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
         int p = (int)bid - 1;                       // lane l looks at workgroup p - l
         while (p >= 0) {
             const int idx = p - lane;
-            const uint32_t d = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                        : SC_PREFIX;             // virtual workgroup -1: prefix 0
-            const uint32_t st = d >> 30;
+            const unsigned long long d = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                  : SC_PREFIX;             // virtual workgroup -1: prefix 0
+            const uint32_t st = (uint32_t)(d >> 62);
             const unsigned long long ready = __ballot(st != 0u), pre = __ballot(st == 2u);
             const int lead = (~ready) ? __builtin_ctzll(~ready) : 64;       // published entries in a row from lane 0
             const int firstpre = pre ? __builtin_ctzll(pre) : 64;
             const int use = firstpre < lead ? firstpre + 1 : lead;          // consumed this round
-            uint32_t c = lane < use ? (d & SC_MASK) : 0u;
+            uint32_t c = lane < use ? (uint32_t)(d & SC_MASK) : 0u;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
             excl += c;
@@ -177,7 +201,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
         }
         if (lane == 0) {
             if (bid != 0)
-                __hip_atomic_store(desc + bid, SC_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(desc + bid, SC_PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             s_excl = excl;
         }
     }
@@ -199,141 +224,230 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32
         for (int i = 0; i < SCAN_ITEMS; ++i)
             if (base + i < n) out[base + i] = v[i];
     }
-    // the grand total straight into host-visible (pinned, mapped) memory, by the thread that owns the last element:
-    // the host polls that word (E3_FLAG_COUNT_MAPPED) -- no separate publishing kernel, no copy command
-    if (total_host && base < n && n <= base + SCAN_ITEMS) {
-        *total_host = (int)run;
-        __threadfence_system();
+    // the grand total, by the thread that owns the last element: to device memory (the kernels behind a compacting sort
+    // pass read their element count there) and / or straight into host-visible (pinned, mapped) memory that the host
+    // polls (E3_FLAG_COUNT_MAPPED) -- no separate publishing kernel, no copy command
+    if (base < n && n <= base + SCAN_ITEMS) {
+        if (total_dev) *total_dev = run;
+        if (total_host) {
+            *total_host = (int)run;
+            __threadfence_system();
+        }
     }
 }
 
-void launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
-                             hipStream_t s, int* total_host) {
-    if (n == 0) return;
+int launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,
+                            hipStream_t s, int* total_host, uint32_t* total_dev) {
+    if (n == 0) return 0;
     const unsigned nb = (unsigned)scan_blocks(n);
+    unsigned long long* desc = reinterpret_cast<unsigned long long*>(desc_zeroed);
     if (inclusive)
-        scan_chained_kernel<true><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb, total_host);
+        scan_chained_kernel<true><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc, nb, total_host, total_dev);
     else
-        scan_chained_kernel<false><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc_zeroed, nb, total_host);
+        scan_chained_kernel<false><<<dim3(nb), dim3(SCAN_THREADS), 0, s>>>(in, out, n, desc, nb, total_host, total_dev);
+    LAUNCH_OK("scan_chained_kernel");
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------ radix sort
-__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
-                                                                  int shift, uint32_t* __restrict__ hist,
-                                                                  unsigned nblocks, uint32_t* __restrict__ scan_desc,
+// n: number of keys -- the host's figure, or (n_dev != NULL) whatever the device word holds (the kept count of a
+// compacting first pass).  Grids are sized by the host's upper bound; workgroups behind the device count only
+// contribute zero counters / exit.
+template <typename KeyT, bool DROP>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, size_t n_host,
+                                                                  const uint32_t* __restrict__ n_dev, int shift,
+                                                                  uint32_t* __restrict__ hist, unsigned nblocks,
+                                                                  unsigned long long* __restrict__ scan_desc,
                                                                   unsigned ndesc) {
     __shared__ uint32_t h[256];
     // (descriptors + ticket of the chained scan that follows in the stream: zeroed here instead of by a memset command)
-    if (blockIdx.x == 0) for (unsigned t = threadIdx.x; t < ndesc; t += SORT_THREADS) scan_desc[t] = 0u;
+    if (blockIdx.x == 0) for (unsigned t = threadIdx.x; t < ndesc; t += SORT_THREADS) scan_desc[t] = 0ull;
     h[threadIdx.x] = 0;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * SORT_TILE;
-    // (all loads first, unconditional with a clamped index: a load inside `if (idx < n)` next to its use waits for its own
-    // round trip in every unrolled iteration)
-    uint32_t k[SORT_ITEMS];
+    const size_t n = n_dev ? (size_t)*n_dev : n_host;
+    const size_t base = (size_t)blockIdx.x * SORT_TILE;
+    constexpr int PER = 16 / (int)sizeof(KeyT);          // keys per 16-byte load
+    if (base + SORT_TILE <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
+        // full tile: the order inside a histogram tile does not matter, so every thread takes 16 consecutive keys as
+        // 16-byte loads (all issued before the first use)
+        uint4 q[SORT_ITEMS / PER];
+        const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
-        k[i] = keys[idx < n ? idx : n - 1];
-    }
+        for (int i = 0; i < SORT_ITEMS / PER; ++i) q[i] = k4[(size_t)i * SORT_THREADS + threadIdx.x];
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
+        for (int i = 0; i < SORT_ITEMS / PER; ++i) {
+            const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (sizeof(KeyT) == 4) {
+                    if (!DROP || w[j] != 0xFFFFFFFFu) atomicAdd(&h[(w[j] >> shift) & 255u], 1u);
+                } else {
+                    atomicAdd(&h[((w[j] & 0xFFFFu) >> shift) & 255u], 1u);
+                    atomicAdd(&h[((w[j] >> 16) >> shift) & 255u], 1u);
+                }
+            }
+        }
+    } else if (base < n) {
+        // (all loads first, unconditional with a clamped index: a load inside `if (idx < n)` next to its use waits for its
+        // own round trip in every unrolled iteration)
+        uint32_t k[SORT_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+            k[i] = (uint32_t)keys[idx < n ? idx : n - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+            if (idx < n && (!DROP || k[i] != 0xFFFFFFFFu)) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// Final phase shared by both scatter kernels.  On entry wcnt[w][d] holds the per-wave digit counts, pos[r] the
-// rank of each key inside its (wave, digit) group, and thread d knows `gfirst`, the global position of this
-// workgroup's first key with digit d.  Keys are first placed at their workgroup-local sorted position in LDS
-// and then streamed out by consecutive threads, so the lanes of a store instruction write consecutive
-// addresses inside each digit's segment (avg 16 keys = 64 B) instead of 4-key fragments per (wave, digit).
-template <int ITEMS>
-struct StageLds {
-    uint32_t key[SORT_THREADS * ITEMS];
-    uint32_t val[SORT_THREADS * ITEMS];
-    uint32_t glob[256];     // global position minus local position, per digit
-    uint32_t wtot[SORT_THREADS / WAVE];
-};
-template <int ITEMS>
-__device__ __forceinline__ void staged_scatter(const uint32_t (&key)[ITEMS], const uint32_t (&val)[ITEMS],
-                                               const uint32_t (&pos)[ITEMS],
-                                               uint32_t (*wcnt)[256], uint32_t gfirst, size_t block_first, size_t wbase,
-                                               size_t n, int shift, uint32_t* __restrict__ keys_out,
-                                               uint32_t* __restrict__ vals_out, StageLds<ITEMS>& L) {
-    constexpr int TILE = SORT_THREADS * ITEMS;
-    constexpr int NW = SORT_THREADS / WAVE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = threadIdx.x;
-    uint32_t c[NW], total = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { c[w] = wcnt[w][d]; total += c[w]; }
-    // workgroup-local exclusive scan of the digit totals
-    uint32_t inc = total;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) L.wtot[wave] = inc;
-    __syncthreads();
-    uint32_t lbase = inc - total;
-    for (int w = 0; w < wave; ++w) lbase += L.wtot[w];
-    L.glob[d] = gfirst - lbase;
-    uint32_t l = lbase;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { wcnt[w][d] = l; l += c[w]; }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        size_t idx = wbase + (size_t)r * WAVE + lane;
-        if (idx < n) {
-            uint32_t dg = (key[r] >> shift) & 255u;
-            uint32_t lp = wcnt[wave][dg] + pos[r];
-            L.key[lp] = key[r];
-            L.val[lp] = val[r];
-        }
-    }
-    __syncthreads();
-    const uint32_t nvalid = (uint32_t)((n - block_first) < (size_t)TILE ? (n - block_first) : (size_t)TILE);
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        uint32_t lp = (uint32_t)j * SORT_THREADS + threadIdx.x;
-        if (lp < nvalid) {
-            uint32_t k = L.key[lp];
-            uint32_t dst = L.glob[(k >> shift) & 255u] + lp;
-            keys_out[dst] = k;
-            vals_out[dst] = L.val[lp];
-        }
-    }
+// After the stable tile sort: [start, end) of each tile.  (Used when the ranges are not derived inside the last
+// scatter pass: single-pass and three-pass tile sorts.)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ n_dev, uint32_t n_host,
+                                                          const KeyT* __restrict__ keys, uint2* __restrict__ ranges,
+                                                          uint32_t nranges) {
+    const uint32_t I = n_dev ? *n_dev : n_host;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    const uint32_t t = keys[i];
+    if (t >= nranges) return;
+    if (i == 0 || (uint32_t)keys[i - 1] != t) ranges[t].x = i;
+    if (i == I - 1 || (uint32_t)keys[i + 1] != t) ranges[t].y = i + 1;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+// LDS of one scatter workgroup: per-wave digit counters, the staged (key, value) pairs, per-digit global offsets.
+template <typename KeyT>
+struct ScatterLds {
+    uint32_t wcnt[SORT_THREADS / WAVE][256];
+    KeyT key[SORT_TILE];
+    uint32_t val[SORT_TILE];
+    uint32_t glob[256];     // global position minus local position, per digit
+    uint32_t wtot[SORT_THREADS / WAVE];
+    uint32_t nvalid;
+    uint32_t seg_tmp[8];    // seg_block()
+};
+
+// RANGES (last pass of a TWO-pass tile sort, NOKEYS): the input is sorted by the low digit and the workgroups of this
+// pass never straddle two low digits -- workgroup b handles (at most) SORT_TILE keys of ONE low-digit segment
+// (`seg` = the 257 segment boundaries the first pass left behind).  Then, in the digit-major scanned histogram,
+// offs[h][first workgroup of low digit l] is exactly where the run of tile (h << 8 | l) starts, and the run ends
+// where the last workgroup of l puts its last key of h: the tile ranges fall out of numbers this kernel holds anyway --
+// no pass over the sorted keys (tile_ranges_kernel), no sorted keys at all.
+struct SegBlock { uint32_t first, count, low, is_first, is_last; };
+__device__ __forceinline__ SegBlock seg_block(const uint32_t* __restrict__ seg, uint32_t b, uint32_t* s_tmp /* >= 8 words */) {
+    // thread d: segment d = [seg[d], seg[d+1]) is cut into ceil(len / SORT_TILE) workgroups; exclusive scan over d
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    const uint32_t s0 = seg[d], s1 = seg[d + 1];
+    const uint32_t nblk = (s1 - s0 + SORT_TILE - 1) / SORT_TILE;
+    uint32_t inc = nblk;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t bf = inc - nblk;
+    for (int w = 0; w < wave; ++w) bf += s_tmp[w];
+    __syncthreads();
+    if (d == 0) s_tmp[4] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (b >= bf && b < bf + nblk) {
+        const uint32_t k = b - bf;
+        s_tmp[0] = s0 + k * SORT_TILE;
+        s_tmp[1] = (s1 - s0 - k * SORT_TILE) < (uint32_t)SORT_TILE ? (s1 - s0 - k * SORT_TILE) : (uint32_t)SORT_TILE;
+        s_tmp[2] = (uint32_t)d;
+        s_tmp[3] = (k == 0 ? 1u : 0u) | (k + 1 == nblk ? 2u : 0u);
+        s_tmp[4] = 0u;
+    }
+    __syncthreads();
+    SegBlock r;
+    r.first = s_tmp[0]; r.count = s_tmp[4] ? 0u : s_tmp[1]; r.low = s_tmp[2];
+    r.is_first = s_tmp[4] ? 0u : (s_tmp[3] & 1u); r.is_last = s_tmp[4] ? 0u : (s_tmp[3] >> 1);
+    __syncthreads();
+    return r;
+}
+
+// same decomposition for the histogram of that pass
+template <typename KeyT>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_seg_kernel(const KeyT* __restrict__ keys,
+                                                                      const uint32_t* __restrict__ seg, int shift,
+                                                                      uint32_t* __restrict__ hist, unsigned nblocks,
+                                                                      unsigned long long* __restrict__ scan_desc,
+                                                                      unsigned ndesc) {
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t s_tmp[8];
+    if (blockIdx.x == 0) for (unsigned t = threadIdx.x; t < ndesc; t += SORT_THREADS) scan_desc[t] = 0ull;
+    h[threadIdx.x] = 0;
+    const SegBlock sb = seg_block(seg, blockIdx.x, s_tmp);      // (contains the barriers that publish h = 0)
+    if (sb.count) {
+        uint32_t k[SORT_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const uint32_t r = (uint32_t)i * SORT_THREADS + threadIdx.x;
+            k[i] = (uint32_t)keys[(size_t)sb.first + (r < sb.count ? r : sb.count - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const uint32_t r = (uint32_t)i * SORT_THREADS + threadIdx.x;
+            if (r < sb.count) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename KeyT, bool DROP, bool NOKEYS, bool RANGES>
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
-                                                                     uint32_t* __restrict__ keys_out,
-                                                                     uint32_t* __restrict__ vals_out, size_t n,
-                                                                     int shift, const uint32_t* __restrict__ offs,
-                                                                     unsigned nblocks) {
+                                                                     KeyT* __restrict__ keys_out,
+                                                                     uint32_t* __restrict__ vals_out, size_t n_host,
+                                                                     const uint32_t* __restrict__ n_dev, int shift,
+                                                                     const uint32_t* __restrict__ offs,
+                                                                     unsigned nblocks,
+                                                                     uint32_t* __restrict__ seg /* RANGES: in; else: out (or null) */,
+                                                                     uint2* __restrict__ ranges, uint32_t nranges) {
     constexpr int NW = SORT_THREADS / WAVE;          // 4 waves
     constexpr int WAVE_KEYS = SORT_TILE / NW;        // 1024 consecutive keys per wave
-    __shared__ uint32_t wcnt[NW][256];
-    __shared__ StageLds<SORT_ITEMS> stage;
+    __shared__ ScatterLds<KeyT> L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t n = n_dev ? (size_t)*n_dev : n_host;
+    size_t block_first = (size_t)blockIdx.x * SORT_TILE;
+    SegBlock sb;
+    if (RANGES) {
+        sb = seg_block(seg, blockIdx.x, L.seg_tmp);
+        block_first = sb.first;
+        n = (size_t)sb.first + sb.count;
+        if (sb.count == 0) return;                    // (uniform; no workgroup barrier is pending)
+    } else {
+        // segment boundaries of THIS pass's digit for a later RANGES pass: position of the first key of digit d = the
+        // scanned counter of (d, workgroup 0)
+        if (seg && blockIdx.x == 0) {
+            seg[threadIdx.x] = offs[(size_t)threadIdx.x * nblocks];
+            if (threadIdx.x == 0) seg[256] = (uint32_t)n;
+        }
+        if (block_first >= n) return;
+    }
 #pragma unroll
-    for (int w = 0; w < NW; ++w) wcnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < NW; ++w) L.wcnt[w][threadIdx.x] = 0;
     __syncthreads();
-    const size_t wbase = (size_t)blockIdx.x * SORT_TILE + (size_t)wave * WAVE_KEYS;
+    const size_t wbase = block_first + (size_t)wave * WAVE_KEYS;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         size_t idx = wbase + (size_t)r * WAVE + lane;
         bool ok = idx < n;
-        key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        key[r] = ok ? (uint32_t)keys_in[idx] : 0xFFFFFFFFu;
         val[r] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;   // no payload array: the payload is the index
     }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         size_t idx = wbase + (size_t)r * WAVE + lane;
-        bool ok = idx < n;
+        const bool ok = idx < n && (!DROP || key[r] != 0xFFFFFFFFu);
         uint32_t d = (key[r] >> shift) & 255u;
         // lanes holding the same digit (among valid lanes)
         uint64_t peers = __ballot(ok);
@@ -345,234 +459,146 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         uint32_t before = __popcll(peers & lt_mask);
         uint32_t cnt = __popcll(peers);
         uint32_t basep = 0;
-        if (ok) basep = wcnt[wave][d];
+        if (ok) basep = L.wcnt[wave][d];
         wave_sync();
-        if (ok && before == 0) wcnt[wave][d] = basep + cnt;
+        if (ok && before == 0) L.wcnt[wave][d] = basep + cnt;
         wave_sync();
-        pos[r] = basep + before;
+        pos[r] = ok ? basep + before : 0xFFFFFFFFu;
     }
     __syncthreads();
-    // digit = threadIdx.x: offs holds the global position of this workgroup's first key of each digit
-    staged_scatter(key, val, pos, wcnt, offs[(size_t)threadIdx.x * nblocks + blockIdx.x],
-                   (size_t)blockIdx.x * SORT_TILE, wbase, n, shift, keys_out, vals_out, stage);
-}
-
-// ------------------------------------------------------------------------------------ onesweep variant
-// One launch per digit instead of five: the digit histograms of ALL passes come from one upfront kernel,
-// and each pass fuses histogram + cross-workgroup prefix + scatter using a chained scan with decoupled
-// look-back.  Inter-workgroup protocol (cdna_hip_programming.md G16, form R2): each (block, digit) descriptor
-// is ONE 32-bit word {2-bit status, 30-bit count} written and read with relaxed agent-scope atomics
-// (sc1: write-through / L1-bypass), so the data is its own flag and no fence is needed.  Logical block ids
-// are handed out by an atomic ticket, so a block only ever waits for blocks that have already started
-// (no dependence on dispatch order or placement).  All descriptor words are zeroed by a memset before the pass.
-constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_MASK = (1u << 30) - 1u;
-
-// Keys per thread of the onesweep passes: the look-back chain is as long as the number of workgroups, so the depth
-// sort (one launch per digit over a few million keys) runs with bigger tiles than the three-kernel passes (measured:
-// 16 / 24 / 32 keys per thread -> 0.174 / 0.157 / 0.165 ms for the 3 M-key depth sort).
-constexpr int OS_ITEMS = 24;
-constexpr int OS_TILE = SORT_THREADS * OS_ITEMS;
-static inline size_t onesweep_blocks(size_t n) { return (n + OS_TILE - 1) / OS_TILE; }
-
-__global__ __launch_bounds__(SORT_THREADS) void radix_global_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
-                                                                         int passes, uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t h[4][256];
-    for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
+    // ---- digit = threadIdx.x: offs holds the global position of this workgroup's first key of each digit
+    const int d = threadIdx.x;
+    const uint32_t gfirst = offs[(size_t)d * nblocks + blockIdx.x];
+    uint32_t c[NW], total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { c[w] = L.wcnt[w][d]; total += c[w]; }
+    // workgroup-local exclusive scan of the digit totals
+    uint32_t inc = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) L.wtot[wave] = inc;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * OS_TILE;
-    uint32_t ones = 0;
-    uint32_t kk[OS_ITEMS];
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; ++i) {                       // loads first (see radix_hist_kernel)
-        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
-        kk[i] = keys[idx < n ? idx : n - 1];
-    }
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; ++i) {
-        size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
-        if (idx < n) {
-            uint32_t k = kk[i];
-            // (the all-ones key -- culled splats, a third of the depth keys -- would serialise 64 lanes on one LDS
-            // counter in every pass: counted in a register instead)
-            if (k == 0xFFFFFFFFu) ++ones;
-            else for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+    uint32_t lbase = inc - total;
+    for (int w = 0; w < wave; ++w) lbase += L.wtot[w];
+    L.glob[d] = gfirst - lbase;
+    if (d == SORT_THREADS - 1) L.nvalid = lbase + total;
+    if (RANGES) {
+        // runs of the tiles (d << shift | low): they start where the FIRST workgroup of the low digit puts its first key
+        // of d and end behind the last key of d of the LAST one.  Plain stores, every word written at most once; tiles
+        // without a key keep an empty range (start == end; tile_order_reg_kernel rewrites those as (0, 0)).
+        const uint32_t tile = ((uint32_t)d << shift) | sb.low;
+        if (tile < nranges) {                         // (digits beyond the last tile id hold no key)
+            if (sb.is_first) ranges[tile].x = gfirst;
+            if (sb.is_last) ranges[tile].y = gfirst + total;
         }
     }
+    uint32_t l = lbase;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ones += __shfl_xor(ones, o, 64);
-    if ((threadIdx.x & 63) == 0 && ones)
-        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][255], ones);
+    for (int w = 0; w < NW; ++w) { L.wcnt[w][d] = l; l += c[w]; }
     __syncthreads();
-    for (int p = 0; p < passes; ++p) {
-        uint32_t c = h[p][threadIdx.x];
-        if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c);
-    }
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void radix_onesweep_kernel(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, size_t n, int shift, const uint32_t* __restrict__ ghist /*256, this pass*/,
-    uint32_t* desc /* nblocks x 256, zeroed */, uint32_t* ticket /* zeroed */) {
-    constexpr int NW = SORT_THREADS / WAVE;
-    constexpr int WAVE_KEYS = OS_TILE / NW;
-    __shared__ uint32_t wcnt[NW][256];
-    __shared__ uint32_t wtot[NW];
-    __shared__ uint32_t s_bid;
-    __shared__ StageLds<OS_ITEMS> stage;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    // Keys are first placed at their workgroup-local sorted position in LDS and then streamed out by consecutive
+    // threads, so the lanes of a store instruction write consecutive addresses inside each digit's segment (avg 16
+    // keys) instead of 4-key fragments per (wave, digit).
 #pragma unroll
-    for (int w = 0; w < NW; ++w) wcnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t bid = s_bid;
-    const size_t wbase = (size_t)bid * OS_TILE + (size_t)wave * WAVE_KEYS;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t key[OS_ITEMS], val[OS_ITEMS], pos[OS_ITEMS];
-#pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-        size_t idx = wbase + (size_t)r * WAVE + lane;
-        bool ok = idx < n;
-        key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-        size_t idx = wbase + (size_t)r * WAVE + lane;
-        bool ok = idx < n;
-        uint32_t d = (key[r] >> shift) & 255u;
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        if (pos[r] != 0xFFFFFFFFu) {
+            uint32_t dg = (key[r] >> shift) & 255u;
+            uint32_t lp = L.wcnt[wave][dg] + pos[r];
+            L.key[lp] = (KeyT)key[r];
+            L.val[lp] = val[r];
         }
-        uint32_t before = __popcll(peers & lt_mask);
-        uint32_t cnt = __popcll(peers);
-        uint32_t basep = 0;
-        if (ok) basep = wcnt[wave][d];
-        wave_sync();
-        if (ok && before == 0) wcnt[wave][d] = basep + cnt;
-        wave_sync();
-        pos[r] = basep + before;
     }
     __syncthreads();
-    uint32_t gfirst;
-    {
-        // digit = threadIdx.x
-        const int d = threadIdx.x;
-        uint32_t c[NW], total = 0;
+    const uint32_t nvalid = L.nvalid;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { c[w] = wcnt[w][d]; total += c[w]; }
-        uint32_t* my = desc + (size_t)bid * 256 + d;
-        __hip_atomic_store(my, (bid == 0 ? OS_PREFIX : OS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // exclusive prefix of this digit over the preceding logical blocks (decoupled look-back)
-        // windowed: LB_WIN predecessors are fetched with independent loads, then consumed in order
-        uint32_t excl = 0;
-        constexpr int LB_WIN = 8;
-        int p = (int)bid - 1;
-        bool done_lb = p < 0;
-        while (!done_lb) {
-            uint32_t v[LB_WIN];
-#pragma unroll
-            for (int k = 0; k < LB_WIN; ++k)
-                v[k] = (p - k >= 0) ? __hip_atomic_load(desc + (size_t)(p - k) * 256 + d, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT)
-                                    : OS_PREFIX;            // virtual block -1: prefix 0
-            int used = 0;
-#pragma unroll
-            for (int k = 0; k < LB_WIN; ++k) {
-                if (done_lb || used != k) continue;
-                const uint32_t st = v[k] >> 30;
-                if (st == 0) continue;                      // not published yet: re-fetch from here
-                excl += v[k] & OS_MASK;
-                used = k + 1;
-                if (st == 2) done_lb = true;
-            }
-            p -= used;
-            if (!done_lb && used == 0) __builtin_amdgcn_s_sleep(1);
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        uint32_t lp = (uint32_t)j * SORT_THREADS + threadIdx.x;
+        if (lp < nvalid) {
+            uint32_t k = (uint32_t)L.key[lp];
+            uint32_t dst = L.glob[(k >> shift) & 255u] + lp;
+            if (!NOKEYS) keys_out[dst] = (KeyT)k;
+            vals_out[dst] = L.val[lp];
         }
-        if (bid != 0)
-            __hip_atomic_store(my, OS_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // exclusive scan of the global digit histogram over the 256 digits
-        uint32_t gh = ghist[d], inc = gh;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        uint32_t dbase = inc - gh;
-        for (int w = 0; w < wave; ++w) dbase += wtot[w];
-        gfirst = dbase + excl;
     }
-    __syncthreads();
-    staged_scatter(key, val, pos, wcnt, gfirst, (size_t)bid * OS_TILE, wbase, n, shift, keys_out, vals_out, stage);
 }
 
-static bool use_onesweep() {
-    static int v = -1;
-    // off by default since round 2: with the single-launch scan and the batched-load histogram a three-kernel pass of the
-    // depth sort (hist 4 us + scan 6 us + scatter 12 us on 3 M pairs) beats the look-back chain of a onesweep pass (28 us +
-    // its share of the global histogram) at every size measured; E3DGS_ONESWEEP=1 turns it back on
-    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v != 0;
-}
-static bool onesweep_small_keys() {     // tile-id sort (few bits, millions of pairs): classic passes by default
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP_TILE"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v != 0;
-}
-static size_t onesweep_max_blocks() {
-    static long v = -1;
-    if (v < 0) { const char* e = getenv("E3DGS_ONESWEEP_MAX_BLOCKS"); v = e ? atol(e) : 1024; }
-    return (size_t)v;
-}
+// workgroups of a segment-aligned (RANGES) pass over n keys
+static inline unsigned seg_blocks(size_t n) { return (unsigned)(sort_blocks(n) + 256); }
 
-static bool onesweep_chosen(size_t n, int nbits) {
-    const int passes = radix_passes(nbits);
-    return n > 0 && use_onesweep() && passes <= 4 &&
-           (nbits == 32 ? onesweep_blocks(n) <= onesweep_max_blocks() : onesweep_small_keys());
-}
-size_t radix_sort_zero_words(size_t n, int nbits) {
-    return onesweep_chosen(n, nbits) ? 1024 + 64 + (size_t)radix_passes(nbits) * onesweep_blocks(n) * 256 : 0;
-}
-
-void launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
-                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
-                             bool identity_payload, bool scratch_zeroed) {
-    uint32_t *ki = k0, *ko = k1, *vi = v0, *vo = v1;
+template <typename KeyT>
+static int radix_sort_pairs_t(KeyT* k0, KeyT* k1, uint32_t* v0, uint32_t* v1, size_t n, const uint32_t* n_dev_in, int nbits,
+                              uint32_t* scratch, KeyT** keys_out, uint32_t** vals_out, hipStream_t s, bool identity_payload,
+                              uint32_t* drop_count_dev, uint2* ranges_out, uint32_t nranges) {
+    KeyT *ki = k0, *ko = k1;
+    uint32_t *vi = v0, *vo = v1;
     if (identity_payload && nbits < 1) nbits = 1;        // the payload (0, 1, 2, ...) only exists after a pass
     const int passes = radix_passes(nbits);
-    // onesweep wins while every workgroup is co-resident and the chain is short (depth sort of P Gaussians);
-    // for the multi-million instance sort the plain three-kernel pass is faster on this chip
-    if (onesweep_chosen(n, nbits)) {
-        unsigned nb = (unsigned)onesweep_blocks(n);
-        // scratch: [ghist 4*256][ticket 64 per pass ...][desc passes * nb * 256]
-        uint32_t* ghist = scratch;
-        uint32_t* tickets = scratch + 1024;
-        uint32_t* desc = scratch + 1024 + 64;
-        if (!scratch_zeroed) (void)hipMemsetAsync(scratch, 0, radix_sort_zero_words(n, nbits) * sizeof(uint32_t), s);
-        radix_global_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, passes, ghist);
-        for (int p = 0; p < passes; ++p) {
-            radix_onesweep_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, (identity_payload && p == 0) ? nullptr : vi,
-                                                                         ko, vo, n, 8 * p, ghist + 256 * p,
-                                                                         desc + (size_t)p * nb * 256, tickets + p);
-            uint32_t* t = ki; ki = ko; ko = t;
-            t = vi; vi = vo; vo = t;
-        }
-    } else if (n > 0) {
-        unsigned nb = (unsigned)sort_blocks(n);
-        size_t hn = (size_t)nb * 256;
+    const bool fuse_ranges = ranges_out && passes == 2;
+    const uint32_t* n_dev = n_dev_in;
+    if (n > 0) {
+        // scratch: [hist: 256 x workgroups (segment-aligned upper bound)][seg: 257 (+pad)][scan descriptors (64-bit)]
+        const unsigned nb = (unsigned)sort_blocks(n), nb_seg = seg_blocks(n);
+        const size_t hn_max = (size_t)nb_seg * 256;
         uint32_t* hist = scratch;
-        uint32_t* scan_scratch = scratch + hn;
-        for (int shift = 0; shift < nbits; shift += 8) {
-            radix_hist_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, shift, hist, nb, scan_scratch,
-                                                                      (unsigned)scan_blocks(hn) + 1u);
-            launch_scan_chained_u32(hist, hist, hn, scan_scratch, false, s);
-            radix_scatter_kernel<<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(
-                ki, (identity_payload && shift == 0) ? nullptr : vi, ko, vo, n, shift, hist, nb);
-            uint32_t* t = ki; ki = ko; ko = t;
-            t = vi; vi = vo; vo = t;
+        uint32_t* seg = scratch + hn_max;
+        uint32_t* scan_scratch = seg + 260;               // (8-byte aligned: hn_max and 260 are even)
+        for (int p = 0; p < passes; ++p) {
+            const int shift = 8 * p;
+            const bool first = p == 0, last = p == passes - 1;
+            const bool drop = first && drop_count_dev != nullptr;
+            const bool ranges = last && fuse_ranges;
+            const unsigned blocks = ranges ? nb_seg : nb;
+            const size_t hn = (size_t)blocks * 256;
+            const unsigned ndesc = (unsigned)scan_blocks(hn) + 1u;
+            unsigned long long* desc = reinterpret_cast<unsigned long long*>(scan_scratch);
+            if (ranges)
+                radix_hist_seg_kernel<KeyT><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(ki, seg, shift, hist, blocks, desc, ndesc);
+            else if (drop)
+                radix_hist_kernel<KeyT, true><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(ki, n, n_dev, shift, hist, blocks, desc, ndesc);
+            else
+                radix_hist_kernel<KeyT, false><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(ki, n, n_dev, shift, hist, blocks, desc, ndesc);
+            LAUNCH_OK("radix_hist_kernel");
+            // (a compacting pass: the scan's grand total is the kept count)
+            int rc = launch_scan_chained_u32(hist, hist, hn, scan_scratch, false, s, nullptr, drop ? drop_count_dev : nullptr);
+            if (rc) return rc;
+            const uint32_t* vin = (identity_payload && first) ? nullptr : vi;
+            // (the pass in front of a RANGES pass leaves the boundaries of ITS digit's segments in `seg`)
+            uint32_t* seg_arg = (ranges || (fuse_ranges && p == passes - 2)) ? seg : nullptr;
+            if (ranges)
+                radix_scatter_kernel<KeyT, false, true, true><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(
+                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, ranges_out, nranges);
+            else if (drop)
+                radix_scatter_kernel<KeyT, true, false, false><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(
+                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, nullptr, 0u);
+            else
+                radix_scatter_kernel<KeyT, false, false, false><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(
+                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, nullptr, 0u);
+            LAUNCH_OK("radix_scatter_kernel");
+            if (drop) n_dev = drop_count_dev;           // the later passes sort the kept keys only
+            KeyT* t = ki; ki = ko; ko = t;
+            uint32_t* u = vi; vi = vo; vo = u;
+        }
+        if (ranges_out && !fuse_ranges) {
+            tile_ranges_kernel<KeyT><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(n_dev, (uint32_t)n, ki, ranges_out, nranges);
+            LAUNCH_OK("tile_ranges_kernel");
         }
     }
-    *keys_out = ki;
+    *keys_out = fuse_ranges ? nullptr : ki;         // (a RANGES pass writes no keys)
     *vals_out = vi;
+    return 0;
+}
+
+int launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
+                            uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
+                            bool identity_payload, uint32_t* drop_count_dev, const uint32_t* n_dev, uint2* ranges_out,
+                            uint32_t nranges) {
+    return radix_sort_pairs_t<uint32_t>(k0, k1, v0, v1, n, n_dev, nbits, scratch, keys_out, vals_out, s, identity_payload,
+                                        drop_count_dev, ranges_out, nranges);
+}
+
+int launch_radix_sort_pairs_u16(uint16_t* k0, uint16_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
+                                uint32_t* scratch, uint16_t** keys_out, uint32_t** vals_out, hipStream_t s,
+                                bool identity_payload, const uint32_t* n_dev, uint2* ranges_out, uint32_t nranges) {
+    return radix_sort_pairs_t<uint16_t>(k0, k1, v0, v1, n, n_dev, nbits > 16 ? 16 : nbits, scratch, keys_out, vals_out, s,
+                                        identity_payload, nullptr, ranges_out, nranges);
 }

@@ -137,6 +137,9 @@ def capture_checkpoint(groups, stats, active_sh_degree, spatial_lr_scale, lrs, s
     (EventTrainer.steps: the opacity group lags after resets)."""
     order = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
     state, pg = {}, []
+    if isinstance(step, dict) and "gauss" in step:
+        # EventTrainer.steps: {"gauss", "opacity", "c"} -- the five non-opacity groups share one count
+        step = {name: int(step["opacity" if name == "opacity" else "gauss"]) for name in order}
     for i, name in enumerate(order):
         st = step[name] if isinstance(step, dict) else step     # torch keeps one step count per parameter
         state[i] = {"step": torch.tensor(float(st)), "exp_avg": groups[name][1].clone(), "exp_avg_sq": groups[name][2].clone()}
@@ -150,7 +153,9 @@ def capture_checkpoint(groups, stats, active_sh_degree, spatial_lr_scale, lrs, s
 
 
 def restore_checkpoint(model_args):
-    """Inverse of capture_checkpoint / GaussianModel.restore (:77-93) -> (groups, stats dict, sh degree, lr scale)."""
+    """Inverse of capture_checkpoint / GaussianModel.restore (:77-93) -> (groups, stats dict, sh degree, lr scale).
+    The per-group Adam step counts of the optimizer state are in `restored_steps(model_args)`: a trainer resumed with
+    non-zero moments must continue their bias correction (EventTrainer.import_groups(groups, steps=...))."""
     (deg, xyz, f_dc, f_rest, scaling, rotation, opacity, max_radii2D, accum, denom, opt, lr_scale) = model_args
     params = {"xyz": xyz, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacity, "scaling": scaling, "rotation": rotation}
     by_name = {g["name"]: g["params"][0] for g in opt["param_groups"]}
@@ -161,6 +166,18 @@ def restore_checkpoint(model_args):
         v = st["exp_avg_sq"] if st else torch.zeros_like(p)
         groups[name] = [p.detach().clone(), m.clone(), v.clone()]
     return groups, dict(max_radii2D=max_radii2D, xyz_gradient_accum=accum, denom=denom), deg, lr_scale
+
+
+def restored_steps(model_args):
+    """Adam step counts of a checkpoint tuple in EventTrainer.steps form: {"gauss": n, "opacity": n} (the five
+    non-opacity groups of the reference share one count; "c" belongs to train.py's separate optimizer_c and is not
+    part of GaussianModel.capture())."""
+    opt = model_args[10]
+    by_name = {g["name"]: g["params"][0] for g in opt["param_groups"]}
+    def cnt(name):
+        st = opt["state"].get(by_name[name])
+        return int(float(st["step"])) if st and "step" in st else 0
+    return {"gauss": max(cnt(n) for n in ("xyz", "f_dc", "f_rest", "scaling", "rotation")), "opacity": cnt("opacity")}
 
 
 # ------------------------------------------------------------------------------------------------ COLMAP

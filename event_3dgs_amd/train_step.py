@@ -63,7 +63,7 @@ class EventTrainer:
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
-                 track_densification_stats=False, overlap_features=None):
+                 track_densification_stats=False, overlap_features=None, factorize_sh=None):
         self.device = torch.device(device)
         self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
@@ -97,7 +97,13 @@ class EventTrainer:
         # sum_views Y_k(dir) * dL/dcolour, so the ranks all-gather the 3 colour-gradient floats per (Gaussian, view) and
         # their camera centres (9 instead of 48 floats per Gaussian and rank) and each rebuilds the mean SH gradient
         # (e3dgs_sh_grad_from_colour).  E3DGS_FACTORIZE_SH=0 falls back to averaging the SH gradient itself.
-        self.factorize_sh = self.world > 1 and os.environ.get("E3DGS_FACTORIZE_SH", "1") != "0"
+        # The choice is made ONCE, at construction, identically on every rank (it decides which collectives a rank
+        # issues): a dataset whose triplets may mix frame sizes (utils/camera_utils.py:19-52 sizes every image on its
+        # own) must be trained with factorize_sh=False -- the mixed-size fallback of compute_gradients() has no per-view
+        # colour gradients to exchange, and ranks that disagree about the exchange would issue different collectives.
+        if factorize_sh is None:
+            factorize_sh = os.environ.get("E3DGS_FACTORIZE_SH", "1") != "0"
+        self.factorize_sh = self.world > 1 and bool(factorize_sh)
         # One rank: the same factorisation pays inside the GPU.  step() lets the backward hand out the per-view colour
         # gradients (9 floats per Gaussian) instead of the 48-float SH gradient, and ONE streaming kernel rebuilds that
         # gradient in registers and applies Adam to the SH coefficients (e3dgs_sh_adam_from_colour): 0.3 GB less HBM
@@ -106,6 +112,7 @@ class EventTrainer:
         self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
         self._gathered = None
         self._packed_views = 0         # views whose colour gradients the last backward left in _packed (0: none)
+        self._packed_cams = None       # (camera-centre tensors, versions) whose values sit in the tail of _packed
         self._xyz_prev = None          # the means the gradients were computed with (Adam moves them meanwhile)
         self._side = None
         self._feat_event = None
@@ -192,12 +199,19 @@ class EventTrainer:
                 out.setdefault(k, [None, None, None])[idx] = v
         return out
 
-    def import_groups(self, groups):
-        """Rebuild the flat buffers after the number of Gaussians changed (densification)."""
+    def import_groups(self, groups, steps=None):
+        """Rebuild the flat buffers from reference-layout groups (after a torch-side densification, or when resuming
+        from a checkpoint).  `steps`: Adam step counts that belong to the imported moments ({"gauss", "opacity"[, "c"]},
+        io_formats.restored_steps): without them a resumed trainer would restart the bias correction at step 1 with
+        non-zero moments (first updates ~10x too large)."""
         off, _ = self.seg["c"]
         c_val = float(self.c)
         c_mom = (float(self.exp_avg[off]), float(self.exp_avg_sq[off]))
         self._build(groups, c_value=c_val, c_moments=c_mom)
+        if steps is not None:
+            for k in ("gauss", "opacity", "c"):
+                if k in steps:
+                    self.steps[k] = int(steps[k])
 
     def densify_and_prune(self, stats, max_grad=0.0002, min_opacity=0.005, extent=1.0, max_screen_size=None,
                           percent_dense=0.01, sampler=None):
@@ -260,15 +274,23 @@ class EventTrainer:
         """Contiguous copies of the camera's (strided, scene/cameras.py:54-57) matrices, made once per camera
         instead of once per step (three tiny copy kernels per rasteriser call otherwise)."""
         src = (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
-        key = tuple((t.data_ptr(), t._version) for t in src)
+        # the cache entry holds the source tensors themselves and is matched by IDENTITY (+ in-place version): an
+        # (address, version) pair does not identify a tensor -- the caching allocator hands a freed block to the next
+        # tensor, at the same address, with version 0
         cached = getattr(cam, "_e3dgs_contig", None)
-        if cached is None or cached[0] != key:
-            cached = (key, tuple(t.contiguous() for t in src))
+        if cached is None or not EventTrainer._same_tensors(cached[0], src):
+            cached = ((src, tuple(t._version for t in src)), tuple(t.contiguous() for t in src))
             try:
                 cam._e3dgs_contig = cached
             except AttributeError:       # cameras with __slots__ / namedtuples: no caching
                 pass
         return cached[1]
+
+    @staticmethod
+    def _same_tensors(entry, tensors):
+        """entry = (tensors, versions) of a cache hit candidate: the same tensor OBJECTS, not modified in place since."""
+        kept, versions = entry
+        return len(kept) == len(tensors) and all(a is b and a._version == v for a, b, v in zip(kept, tensors, versions))
 
     def _settings(self, cam, bg, scaling_modifier=1.0):
         view, proj, campos = self._camera_tensors(cam)
@@ -405,6 +427,12 @@ class EventTrainer:
         sizes = {(int(s.image_height), int(s.image_width)) for s in settings}
         if len(sizes) != 1:
             # the reference sizes every image on its own (utils/camera_utils.py:19-52): a triplet may mix resolutions
+            if self.factorize_sh:
+                # (this rank would all-reduce the SH gradient while the ranks with a uniform triplet all-gather colour
+                # gradients: mismatched collectives hang or corrupt the exchange)
+                raise ValueError("a camera triplet with mixed frame sizes cannot be trained with the factorised SH "
+                                 "exchange: construct EventTrainer(..., factorize_sh=False) on every rank (or set "
+                                 "E3DGS_FACTORIZE_SH=0) for datasets that mix resolutions")
             return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
         # ---- the three renders (train.py:144,159,161)
         flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
@@ -440,11 +468,13 @@ class EventTrainer:
             out["sh"] = None
             out["colour_views"] = self._packed[:nv * P * 3].view(nv, P, 3)
             tail = self._packed[nv * P * 3:].view(nv, 3)
-            key = tuple((st.campos.data_ptr(), st.campos._version) for st in settings)
-            if getattr(self, "_packed_cams", None) != key:           # (same cameras as last iteration: already there)
-                for k, st in enumerate(settings):
-                    tail[k].copy_(st.campos)
-                self._packed_cams = key
+            # (same camera-centre tensors as last iteration, unmodified: already there.  The entry keeps the tensors alive
+            # and is matched by identity: a stale hit would rebuild the SH gradient with last iteration's directions)
+            cams = tuple(st.campos for st in settings)
+            if self._packed_cams is None or not self._same_tensors(self._packed_cams, cams):
+                for k, t in enumerate(cams):
+                    tail[k].copy_(t)
+                self._packed_cams = (cams, tuple(t._version for t in cams))
         if self.track_stats:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out)

@@ -467,6 +467,26 @@ int e3dgs_densify_apply(int P, int P_new, const int* counts4, const float* param
                         float* exp_avg_sq_new, char* scratch, void* stream);
 
 /*
+ * The rasteriser's sort, callable on its own: stable LSD radix sort of n (key, value) pairs on key bits [0, nbits).
+ * Replaces: cub::DeviceRadixSort::SortPairs of the reference op's binning stage ([UPSTREAM] rasterizer_impl.cu, SURVEY 2.1
+ * row "SortPairs"; the reference sorts 64-bit (tile << 32 | depth) keys, this library a 32-bit depth sort of the splats
+ * followed by a 16-/32-bit tile-id sort of the instances -- DESIGN.md section 4, decision 1).
+ *   key_bytes        4 (uint32 keys) or 2 (uint16 keys); keys0/keys1 and vals0/vals1 are ping-pong buffers of n elements,
+ *                    the input sits in (keys0, vals0); *result_index_host = 0 or 1 says which pair holds the result.
+ *   identity_payload != 0: vals0 is not read, the payload of element i is i.
+ *   kept_count_dev   (32-bit keys, may be NULL) keys equal to 0xFFFFFFFF are DROPPED; the number of kept pairs is stored
+ *                    there (device word) and only that many result elements are valid.
+ *   ranges           (may be NULL) uint32 (nranges, 2), zero on entry: ranges[k] = [first, last + 1) positions of key k in
+ *                    the result; keys without an element keep an empty range (start == end).  A two-pass sort (9..16
+ *                    key bits) derives the ranges inside its last pass and does NOT write the sorted keys.
+ *   scratch          e3dgs_sort_scratch_bytes(n) bytes, 8-byte aligned.
+ */
+size_t e3dgs_sort_scratch_bytes(size_t n);
+int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1,
+                     int identity_payload, char* scratch, uint32_t* kept_count_dev, uint32_t* ranges, uint32_t nranges,
+                     int* result_index_host, void* stream);
+
+/*
  * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * Slots: 0 preprocess, 1 sort_depth, 2 scan_emit, 3 sort_tile, 4 tile_ranges, 5 render_fwd,
  *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set

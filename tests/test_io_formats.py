@@ -101,6 +101,23 @@ def test_checkpoint_tuple_is_loadable_by_torch_adam(tmp_path):
             assert torch.equal(groups2[k][j], groups[k][j]), (k, j)
 
 
+def test_checkpoint_keeps_the_per_group_adam_step_counts():
+    """The trainer's step dict ({"gauss", "opacity", "c"}: the opacity group lags after resets) goes into the optimizer
+    state per parameter as torch keeps it, and comes back out: a resumed run continues the bias correction."""
+    from event_3dgs_amd.densify import DensifyStats
+    N = 5
+    shapes = {"xyz": (N, 3), "f_dc": (N, 1, 3), "f_rest": (N, 15, 3), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+    groups = {k: [torch.zeros(s), torch.ones(s), torch.ones(s)] for k, s in shapes.items()}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    tup = IO.capture_checkpoint(groups, DensifyStats(N, "cpu"), 3, 1.0, lrs, step={"gauss": 120, "opacity": 20, "c": 130})
+    state = tup[10]["state"]
+    assert [int(state[i]["step"]) for i in range(6)] == [120, 120, 120, 20, 120, 120]       # order: xyz f_dc f_rest opacity ...
+    assert IO.restored_steps(tup) == {"gauss": 120, "opacity": 20}
+    # the per-name form still works
+    tup = IO.capture_checkpoint(groups, DensifyStats(N, "cpu"), 3, 1.0, lrs, step={k: 7 for k in shapes})
+    assert IO.restored_steps(tup) == {"gauss": 7, "opacity": 7}
+
+
 def _make_dataset(root):
     """A tiny scene directory in the reference's layout, on top of the golden COLMAP model."""
     import shutil
