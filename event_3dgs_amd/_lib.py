@@ -67,6 +67,10 @@ def lib():
     L.e3dgs_rasterize_forward_multi_finish_colour.argtypes = (
         [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp, C.c_int, _fp, C.c_int]
         + [C.c_int, C.c_int, _fp, _fp, _pp, C.c_int, NOTIFY_FN, _vp, _vp])
+    L.e3dgs_rasterize_forward_multi_capacity.restype = C.c_int
+    L.e3dgs_rasterize_forward_multi_capacity.argtypes = (
+        [ALLOC_FN, _vp] * 3 + [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
+        + [_fp, _ip, C.c_int, C.c_int, C.c_int, _vp, NOTIFY_FN, _vp, _vp])
     L.e3dgs_rasterize_backward_multi.restype = C.c_int
     L.e3dgs_rasterize_backward_multi.argtypes = (
         [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
@@ -166,6 +170,7 @@ FLAG_BWD_ONLY_RENDER = 8
 FLAG_BWD_ONLY_GEOM = 16
 FLAG_COUNT_MAPPED = 64
 FLAG_DEFER_COLOR = 128
+FLAG_COUNT_DEVICE = 256
 ACC_STRIDE = 12
 
 EXPORTED_SYMBOLS = [
@@ -175,5 +180,5 @@ EXPORTED_SYMBOLS = [
     "e3dgs_sh_grad_from_colour", "e3dgs_sh_adam_from_colour",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
-    "e3dgs_sort_scratch_bytes", "e3dgs_sort_pairs",
+    "e3dgs_sort_scratch_bytes", "e3dgs_sort_pairs", "e3dgs_rasterize_forward_multi_capacity",
 ]

@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
                                                          const uint2* __restrict__ run_sorted,
                                                          const float* __restrict__ part, float4* __restrict__ gsum,
                                                          const uint32_t* __restrict__ nvis /* [1]: length of the order */,
-                                                         const uint8_t* __restrict__ touched /* per slot */) {
+                                                         const uint8_t* __restrict__ touched /* per slot */,
+                                                         const uint32_t* __restrict__ count_dev, uint32_t capacity) {
     __shared__ float sbuf[4][RR_CHUNK * E3_REC_FLOATS];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t j0 = blockIdx.x * 256u + wave * 64u, j = j0 + lane;
@@ -454,6 +455,8 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
     // sum, and no sum to store, for the rest -- the per-Gaussian kernels never read the sums of culled splats
     Q = __builtin_amdgcn_readfirstlane(*nvis);
     if (j0 >= Q) return;
+    // (forward with pre-sized buffers whose count did not fit: nothing was emitted, `run_sorted` is stale)
+    if (count_dev && *count_dev > capacity) return;
     const uint32_t nl = (Q - j0 < 64u ? Q - j0 : 64u) - 1u;          // last lane with a splat
     const uint2 rn = j < Q ? run_sorted[j] : make_uint2(0u, 0u);
     const uint32_t S0 = __builtin_amdgcn_readfirstlane(rn.x);
@@ -512,9 +515,11 @@ __global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const 
                                                               const float* __restrict__ part,
                                                               float4* __restrict__ gsum,
                                                               const uint8_t* __restrict__ touched,
-                                                              const uint32_t* __restrict__ nvis) {
+                                                              const uint32_t* __restrict__ nvis,
+                                                              const uint32_t* __restrict__ count_dev, uint32_t capacity) {
     const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (j >= *nvis) return;                  // (the order holds the kept splats only)
+    if (count_dev && *count_dev > capacity) return;
     const uint2 rn = run_sorted[j];
     const float* __restrict__ p = part + E3_REC_FLOATS * (size_t)rn.x;
     float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1090,12 +1095,21 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     ProfScope ps(PS_GEOM_BWD, s);
     // per-splat sums live behind the instance records in the caller's scratch: grad_acc is (num_rendered + Q, 12)
     float4* gsum = reinterpret_cast<float4*>(grad_acc + E3_ACC_STRIDE * (size_t)num_rendered);
+    // E3_FLAG_COUNT_DEVICE: num_rendered is the capacity of a forward_multi_capacity call; the count itself is the last
+    // element of the forward's scan of the per-wave instance counts
+    const uint32_t* count_dev = nullptr;
+    if (flags & E3_FLAG_COUNT_DEVICE) {
+        const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
+        count_dev = geom.offsets + (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
+    }
     if (num_rendered > 0 && Q <= E3_RUN_REDUCE_WAVE_MAX && g_small_scene_paths)
         run_reduce_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                    grad_acc, gsum, bin.touched, geom.nvis);
+                                                                                    grad_acc, gsum, bin.touched, geom.nvis,
+                                                                                    count_dev, (uint32_t)num_rendered);
     else if (num_rendered > 0)
         run_reduce_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
-                                                                                   grad_acc, gsum, geom.nvis, bin.touched);
+                                                                                   grad_acc, gsum, geom.nvis, bin.touched,
+                                                                                   count_dev, (uint32_t)num_rendered);
     else        // no instance at all (a radius can still be > 0 when every tile of the splat was culled): zero sums
     {
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);

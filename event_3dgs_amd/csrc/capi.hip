@@ -306,6 +306,48 @@ int e3dgs_rasterize_forward_multi_finish_colour(e3dgs_alloc_fn binning_alloc, vo
                                   image_buffer, num_rendered, out_color, debug, (hipStream_t)stream, &dc);
 }
 
+// ---- the same multi-view forward with NO host wait: binning buffers sized by the caller before the count is known
+int e3dgs_rasterize_forward_multi_capacity(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
+                                           void* binning_user, e3dgs_alloc_fn image_alloc, void* image_user, int nviews,
+                                           int P, int D, int M, const float* background, int width, int height,
+                                           const float* means3D, const float* shs, const float* opacities,
+                                           const float* scales, float scale_modifier, const float* rotations,
+                                           const float* const* viewmatrix, const float* const* projmatrix,
+                                           const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy,
+                                           float* out_color, int* radii, int debug, int flags, int capacity,
+                                           int* num_rendered_host, e3dgs_notify_fn before_colour, void* notify_user,
+                                           void* stream) {
+    g_err[0] = 0;
+    int rc = check_forward_args(P, D, M, width, height, shs, nullptr, scales, rotations, nullptr, flags, 3);
+    if (rc) return rc;
+    if (capacity < 1) return e3_fail(hipErrorInvalidValue, "capacity must be positive");
+    if (!num_rendered_host || !(flags & E3_FLAG_COUNT_MAPPED))
+        return e3_fail(hipErrorInvalidValue, "num_rendered_host must be device-mapped pinned memory (E3DGS_FLAG_COUNT_MAPPED): "
+                                             "it is how the caller learns the count, and whether it fitted the capacity");
+    ViewBatch vb;
+    rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
+    if (rc) return rc;
+    struct Keep { e3dgs_alloc_fn fn; void* user; char* ptr; };
+    static thread_local Keep kg, ki;
+    kg = Keep{geom_alloc, geom_user, nullptr};
+    ki = Keep{image_alloc, image_user, nullptr};
+    auto grab = [](void* u, size_t n) -> char* { Keep* k = (Keep*)u; k->ptr = k->fn(k->user, n); return k->ptr; };
+    rc = e3_forward_begin_impl(grab, &kg, grab, &ki, vb, P, D, M, width, height, means3D, shs, nullptr, opacities, scales,
+                               scale_modifier, rotations, nullptr, radii, debug, flags, num_rendered_host,
+                               (hipStream_t)stream);
+    if (rc) return rc;
+    DeferredColour dc;
+    const bool defer = (flags & E3_FLAG_DEFER_COLOR) != 0;
+    if (defer) {
+        dc.views = vb;
+        dc.D = D; dc.M = M; dc.flags = flags; dc.means3D = means3D; dc.shs = shs;
+        dc.before = before_colour; dc.user = notify_user;
+    }
+    return e3_forward_finish_impl(binning_alloc, binning_user, vb.n, P, width, height, background, kg.ptr, ki.ptr,
+                                  P > 0 ? capacity : 0, out_color, debug, (hipStream_t)stream, defer ? &dc : nullptr,
+                                  P > 0 ? 1 : 0);
+}
+
 int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,
                                    int width, int height, const float* means3D, const float* shs,
                                    const float* opacities, const float* scales, float scale_modifier,

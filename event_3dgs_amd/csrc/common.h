@@ -27,6 +27,7 @@
 #define E3_FLAG_BWD_ONLY_GEOM 16    // backward: run only the per-Gaussian backward (consumes grad_acc)
 #define E3_FLAG_COUNT_MAPPED 64     // begin: num_rendered_host is pinned + device-mapped; the GPU stores the count there
 #define E3_FLAG_DEFER_COLOR 128     // multi begin: no SH evaluation in preprocess; finish runs colour_kernel
+#define E3_FLAG_COUNT_DEVICE 256    // backward: num_rendered is the CAPACITY of a forward_multi_capacity call
 #define E3_MAX_VIEWS 4       // views per e3dgs_rasterize_backward_geom_multi call
 #define E3_ACC_STRIDE 12      // floats the CALLER provides per (tile, Gaussian) instance and per splat sum in grad_acc
 #define E3_REC_FLOATS 9       // floats of a per-instance gradient record as stored (packed, 36 B; the rest is slack)
@@ -339,7 +340,8 @@ struct DeferredColour {          // inputs of colour_kernel (E3_FLAG_DEFER_COLOR
 };
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc = nullptr);
+                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc = nullptr,
+                           int count_on_device = 0);
 int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_rendered, const float* background, int W,
                      int H, const float* means3D, const float* shs, const float* colors, const float* opacities,
                      const float* scales, float scale_modifier, const float* rots, const float* cov_pre,

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
                                                               void* __restrict__ keys, int keys16,
                                                               uint32_t* __restrict__ emit_gid,
                                                               uint2* __restrict__ run_sorted,
-                                                              uint8_t* __restrict__ touched) {
+                                                              uint8_t* __restrict__ touched,
+                                                              const uint32_t* __restrict__ total_dev, uint32_t capacity) {
     __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
     __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per splat of the wave (EMIT only)
     __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
@@ -383,6 +384,9 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     // `order` holds the splats the projection kept, by depth: the depth sort dropped the culled ones (their count is
     // only known on the device).  Waves behind the end have nothing to walk.
     const int nv = (int)__builtin_amdgcn_readfirstlane(*nvis);
+    // (buffers sized before the count was known: more instances than they hold -> nothing is written, see
+    // e3_forward_finish_impl)
+    if (EMIT && total_dev && *total_dev > capacity) return;
     if ((gw << gshift) >= nv) {
         if (!EMIT && lane == 0) wave_counts[gw] = 0u;
         return;
@@ -1028,7 +1032,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, geom.nvis,
                                                                      geom.rect, vs.v[0].gx <= 255 && vs.v[0].gy <= 255,
                                                                      geom.rec, vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
-                                                                     nullptr, 0, nullptr, nullptr, nullptr);
+                                                                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0u);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         const int rc = launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
                                                (flags & E3_FLAG_COUNT_MAPPED) ? count_host : nullptr);
@@ -1042,9 +1046,14 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     return 0;
 }
 
+// count_on_device: `num_rendered` is the CAPACITY the caller sized the binning buffers for before the instance count was
+// known (a training loop: the previous iteration's count plus a margin); the kernels read the count itself from device
+// memory, so no host wait sits between the two halves of the forward.  If the count turns out larger than the capacity
+// nothing is emitted or sorted (every tile list stays empty) and the caller, who gets the count through its mapped host
+// word as usual, repeats the call with larger buffers.
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc) {
+                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc, int count_on_device) {
     const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
     const int tiles_per_view = gx * gy;
     const int ntiles = tiles_per_view * nviews;
@@ -1057,7 +1066,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     char* bp = bin_alloc(bin_user, BinningState::required(I));
     if (!bp) return e3_fail(hipErrorOutOfMemory, "binning allocation callback returned NULL");
     BinningState bin = BinningState::from(bp, I);
-    if (I > 0) {
+    if (I > 0 && P > 0) {
         // at least one pass even for a single tile: the first pass is what materialises the identity payload
         const int tile_bits = ntiles > 1 ? ceil_log2((uint32_t)ntiles) : 1;
         const int passes = radix_passes(tile_bits);
@@ -1068,12 +1077,14 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
         const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
+        // the instance count on the device: the last element of the inclusive scan of the per-wave counts
+        const uint32_t* count_dev = count_on_device ? geom.offsets + nwaves : nullptr;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
                                                                     geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
                                                                     g_tile_cull, geom.offsets, nullptr, k0, keys16,
-                                                                    bin.emit_gid, geom.run, bin.touched);
+                                                                    bin.emit_gid, geom.run, bin.touched, count_dev, I);
         }
         KERNEL_OK("bin emit");
         uint32_t* vs;
@@ -1085,12 +1096,12 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         if (keys16) {
             uint16_t* ks16;
             rc = launch_radix_sort_pairs_u16(reinterpret_cast<uint16_t*>(k0), reinterpret_cast<uint16_t*>(k1), v0, v1,
-                                             (size_t)I, tile_bits, bin.scratch, &ks16, &vs, s, true, nullptr, img.ranges,
+                                             (size_t)I, tile_bits, bin.scratch, &ks16, &vs, s, true, count_dev, img.ranges,
                                              (uint32_t)ntiles);
         } else {
             uint32_t* ks;
             rc = launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s, true, nullptr,
-                                         nullptr, img.ranges, (uint32_t)ntiles);
+                                         count_dev, img.ranges, (uint32_t)ntiles);
         }
         if (rc) return rc;
         }

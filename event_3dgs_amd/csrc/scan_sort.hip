@@ -251,8 +251,15 @@ int launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_
 
 // ------------------------------------------------------------------------------------ radix sort
 // n: number of keys -- the host's figure, or (n_dev != NULL) whatever the device word holds (the kept count of a
-// compacting first pass).  Grids are sized by the host's upper bound; workgroups behind the device count only
-// contribute zero counters / exit.
+// compacting first pass; the instance count of a forward whose buffers were sized before the count was known).  Grids
+// are sized by the host's figure, which is then the CAPACITY of the buffers: workgroups behind the device count only
+// contribute zero counters / exit, and a device count beyond the capacity sorts nothing at all (the caller notices the
+// overflow when the count reaches it and repeats the call with larger buffers).
+__device__ __forceinline__ size_t device_count(const uint32_t* __restrict__ n_dev, size_t n_host) {
+    if (!n_dev) return n_host;
+    const size_t n = (size_t)*n_dev;
+    return n > n_host ? 0 : n;
+}
 template <typename KeyT, bool DROP>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, size_t n_host,
                                                                   const uint32_t* __restrict__ n_dev, int shift,
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
     if (blockIdx.x == 0) for (unsigned t = threadIdx.x; t < ndesc; t += SORT_THREADS) scan_desc[t] = 0ull;
     h[threadIdx.x] = 0;
     __syncthreads();
-    const size_t n = n_dev ? (size_t)*n_dev : n_host;
+    const size_t n = device_count(n_dev, n_host);
     const size_t base = (size_t)blockIdx.x * SORT_TILE;
     constexpr int PER = 16 / (int)sizeof(KeyT);          // keys per 16-byte load
     if (base + SORT_TILE <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
@@ -312,7 +319,7 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ n_dev, uint32_t n_host,
                                                           const KeyT* __restrict__ keys, uint2* __restrict__ ranges,
                                                           uint32_t nranges) {
-    const uint32_t I = n_dev ? *n_dev : n_host;
+    const uint32_t I = (uint32_t)device_count(n_dev, n_host);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     const uint32_t t = keys[i];
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
     constexpr int WAVE_KEYS = SORT_TILE / NW;        // 1024 consecutive keys per wave
     __shared__ ScatterLds<KeyT> L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    size_t n = n_dev ? (size_t)*n_dev : n_host;
+    size_t n = device_count(n_dev, n_host);
     size_t block_first = (size_t)blockIdx.x * SORT_TILE;
     SegBlock sb;
     if (RANGES) {

@@ -492,21 +492,25 @@ def wait_count(pending, timeout_s=10.0):
     command plus the runtime's wake-up latency, during which the GPU has nothing queued)."""
     import ctypes as C
     import time
-    if not (pending.flags & _lib.FLAG_COUNT_MAPPED):
-        torch.cuda.current_stream(pending.device).synchronize()
-        return
-    word = C.c_int.from_address(pending.count_host.data_ptr())
-    spins = 0
+    if isinstance(pending, dict):            # a forward_multi_capacity() result: always mapped
+        count_host, device = pending["count_host"], pending["device"]
+    else:
+        if not (pending.flags & _lib.FLAG_COUNT_MAPPED):
+            torch.cuda.current_stream(pending.device).synchronize()
+            return int(pending.count_host[0])
+        count_host, device = pending.count_host, pending.device
+    word = C.c_int.from_address(count_host.data_ptr())
+    spins, t0 = 0, None
     while word.value == -1:
         spins += 1
         if spins & 0xFFFF == 0:
-            t0 = getattr(pending, "_t0", None)
             if t0 is None:
-                pending._t0 = time.perf_counter()
+                t0 = time.perf_counter()
             elif time.perf_counter() - t0 > timeout_s:
-                torch.cuda.current_stream(pending.device).synchronize()      # surfaces a device error, if any
+                torch.cuda.current_stream(device).synchronize()      # surfaces a device error, if any
                 if word.value == -1:
                     raise RuntimeError("instance count never arrived")
+    return int(word.value)
 
 
 def prepare_multi_finish(pending):
@@ -556,6 +560,52 @@ def forward_multi_finish(pending):
                 flags=p.flags & ~(_lib.FLAG_COUNT_MAPPED | _lib.FLAG_DEFER_COLOR), inputs=p.inputs,
                 opacities=p.opacities, bg=p.bg, keep=p.keep,
                 geom=p.geom, binning=binning.tensor, image=p.image, pool=p.pool)
+
+
+def forward_multi_capacity(means3D, sh, opacities, scales, rotations, settings_list, capacity, count_host, flags=0,
+                           pool=None, before_colour=None):
+    """e3dgs_rasterize_forward_multi_capacity: the whole multi-view forward enqueued in one go, binning buffers sized for
+    `capacity` instances before the count is known (no host wait).  `count_host`: pinned int32[1]; it is armed with -1 here
+    and receives the instance count from the GPU -- poll it with wait_count(raw) before anything persistent consumes
+    the results; a count above `capacity` means nothing was emitted (repeat with a larger capacity).  The returned dict
+    has num_rendered = capacity (the scratch layouts backward_multi must use) and flags | FLAG_COUNT_DEVICE."""
+    import ctypes as C
+    L = _lib.lib()
+    _check_same_frame(settings_list)
+    rs = settings_list[0]
+    n = len(settings_list)
+    dev = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D_c, sh_c, opac_c = _prep(means3D, "means3D"), _prep(sh, "shs"), _prep(opacities, "opacities")
+    scales_c, rots_c = _prep(scales, "scales"), _prep(rotations, "rotations")
+    bg = _prep(rs.bg, "bg")
+    M = sh.shape[0] // 3 if (flags & _lib.FLAG_SH_PLANAR) else sh.shape[1]
+    arrays, keep = _view_arrays(settings_list)
+    flags = int(flags) | _lib.FLAG_COUNT_MAPPED
+    count_host[0] = -1
+    if pool is not None:
+        radii = pool.typed("radii", (n, P), torch.int32)
+        out_color = pool.typed("out_color", (n, 3, H, W))
+    else:
+        radii = torch.empty(n, P, dtype=torch.int32, device=dev)
+        out_color = torch.empty(n, 3, H, W, dtype=torch.float32, device=dev)
+    geom, binning, img = _Scratch(dev, pool, "geom"), _Scratch(dev, pool, "binning"), _Scratch(dev, pool, "image")
+    notify = _lib.NOTIFY_FN((lambda _u: before_colour()) if before_colour else (lambda _u: None))
+    with torch.cuda.device(dev):
+        rc = L.e3dgs_rasterize_forward_multi_capacity(
+            geom.cb, None, binning.cb, None, img.cb, None, n, P, int(rs.sh_degree), M, _lib.ptr(bg), W, H,
+            _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(opac_c), _lib.ptr(scales_c), float(rs.scale_modifier),
+            _lib.ptr(rots_c), *arrays, _lib.ptr(out_color), _lib.ptr(radii), int(bool(rs.debug)), flags, int(capacity),
+            count_host.data_ptr(), notify, None, _lib.current_stream())
+    _lib.check(rc, "e3dgs_rasterize_forward_multi_capacity")
+    return dict(color=out_color, radii=radii, num_rendered=int(capacity) if P else 0, capacity=int(capacity), M=M,
+                settings=rs, settings_list=list(settings_list),
+                flags=(flags & ~(_lib.FLAG_COUNT_MAPPED | _lib.FLAG_DEFER_COLOR)) | _lib.FLAG_COUNT_DEVICE,
+                inputs=(means3D_c, sh_c, None, scales_c, rots_c, None), opacities=opac_c, bg=bg, keep=keep,
+                geom=geom.tensor, binning=binning.tensor, image=img.tensor, pool=pool, count_host=count_host, device=dev)
 
 
 def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flags=0, pool=None):

@@ -109,6 +109,15 @@ class EventTrainer:
         # gradient in registers and applies Adam to the SH coefficients (e3dgs_sh_adam_from_colour): 0.3 GB less HBM
         # traffic per iteration at 1 M Gaussians, bit-identical parameters.  E3DGS_SH_VIA_COLOUR=0 disables it.
         self.sh_via_colour = self.world == 1 and os.environ.get("E3DGS_SH_VIA_COLOUR", "1") != "0"
+        # No host wait inside an iteration: the binning buffers of the forward are sized from the instance counts of the
+        # previous iterations (+ margin) and the kernels read the count from device memory
+        # (e3dgs_rasterize_forward_multi_capacity); the host looks at the count only after it has enqueued the backward,
+        # i.e. while the GPU still has most of the iteration in front of it, and BEFORE it enqueues the optimizer step: a
+        # count that did not fit costs a repeated forward / backward, never a wrong update.  E3DGS_NO_HOST_WAIT=0
+        # restores begin -> wait -> finish.
+        self.no_host_wait = os.environ.get("E3DGS_NO_HOST_WAIT", "1") != "0"
+        self._capacity = {}            # (N, views, H, W) -> instances the binning buffers are sized for
+        self.count_retries = 0         # iterations repeated because the count exceeded the capacity
         self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
         self._gathered = None
         self._packed_views = 0         # views whose colour gradients the last backward left in _packed (0: none)
@@ -413,6 +422,54 @@ class EventTrainer:
             if self.overlap_features:
                 self._feat_event = side.record_event()
 
+    CAPACITY_MARGIN = 1.25
+
+    def _forward_views(self, settings):
+        """The renders of one iteration as ONE multi-view pass.  Without a known capacity (first iteration, new size):
+        begin -> host wait for the count -> finish, and the count seeds the capacity.  Afterwards: everything enqueued
+        at once with the binning buffers sized by the capacity; _count_fits() is called once the backward is enqueued."""
+        v = self.views
+        flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
+        if self.overlap_features:
+            flags |= _lib.FLAG_DEFER_COLOR         # projection / sorts / binning do not read the SH coefficients ...
+        if self._counts is None:
+            self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
+        key = (self.N, len(settings), int(settings[0].image_height), int(settings[0].image_width))
+        cap = self._capacity.get(key) if self.no_host_wait else None
+        if cap is None:
+            pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
+                                                  settings, flags=flags, count_host=self._counts, pool=self._pool)
+            pend.before_colour = self.sync_features    # ... whose update (side stream) must be done before the colour kernel
+            rasterizer.prepare_multi_finish(pend)      # (host work done while the GPU still computes the count)
+            rasterizer.wait_count(pend)                # the host wait: the instance count (polled)
+            raw = rasterizer.forward_multi_finish(pend)
+            self._note_count(key, raw["num_rendered"])
+            return raw
+        raw = rasterizer.forward_multi_capacity(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
+                                                cap, self._counts, flags=flags, pool=self._pool,
+                                                before_colour=self.sync_features if self.overlap_features else None)
+        raw["capacity_key"] = key
+        return raw
+
+    def _note_count(self, key, count):
+        if not self.no_host_wait:
+            return
+        cap = self._capacity.get(key)
+        if cap is None or count > 0.95 * cap:          # (stable otherwise: the scratch pool and its pointers stay put)
+            self._capacity = {key: int(count * self.CAPACITY_MARGIN) + 65536}      # one frame size at a time
+
+    def _count_fits(self, raw):
+        """For a pre-sized forward: wait for its instance count (the GPU produced it early in the iteration; by now it is
+        busy with the kernels enqueued since) and say whether the buffers were large enough."""
+        if "capacity" not in raw:
+            return True
+        count = rasterizer.wait_count(raw)
+        self._note_count(raw["capacity_key"], count)
+        if count > raw["capacity"]:
+            self.count_retries += 1
+            return False
+        return True
+
     def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sh_via_colour=False):
         """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer.
         sh_via_colour (what step() uses on one rank): the SH segment of the gradient buffer is NOT written; the backward
@@ -420,8 +477,6 @@ class EventTrainer:
         SH-optimizer kernel.
         The returned scalars tensor, `last_scalars` and `last_radii` are VIEWS of persistent buffers that the next
         iteration overwrites (step() / step_image() return clones)."""
-        if self._counts is None:
-            self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
         v = self.views
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
         sizes = {(int(s.image_height), int(s.image_width)) for s in settings}
@@ -434,16 +489,20 @@ class EventTrainer:
                                  "exchange: construct EventTrainer(..., factorize_sh=False) on every rank (or set "
                                  "E3DGS_FACTORIZE_SH=0) for datasets that mix resolutions")
             return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
+        for _attempt in range(4):
+            scalars, raw = self._event_forward_backward(settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour)
+            if self._count_fits(raw):
+                break
+        else:
+            raise RuntimeError("the instance count kept outgrowing the binning capacity")
+        self.c_grad.copy_(scalars[1:2])
+        self.last_radii = raw["radii"][0]
+        self.last_scalars = scalars
+        return scalars
+
+    def _event_forward_backward(self, settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour):
         # ---- the three renders (train.py:144,159,161)
-        flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
-        if self.overlap_features:
-            flags |= _lib.FLAG_DEFER_COLOR         # projection / sorts / binning do not read the SH coefficients ...
-        pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
-                                              settings, flags=flags, count_host=self._counts, pool=self._pool)
-        pend.before_colour = self.sync_features    # ... whose update (side stream) must be done before the colour kernel
-        rasterizer.prepare_multi_finish(pend)      # (host work done while the GPU still computes the count)
-        rasterizer.wait_count(pend)                # the iteration's only host wait: the instance count (polled)
-        raw = rasterizer.forward_multi_finish(pend)
+        raw = self._forward_views(settings)
         imgs = raw["color"]
         key = ("event",) + tuple(imgs.shape)
         if self._loss_bufs is None or self._loss_bufs[0] != key:
@@ -478,10 +537,7 @@ class EventTrainer:
         if self.track_stats:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out)
-        self.c_grad.copy_(scalars[1:2])
-        self.last_radii = raw["radii"][0]
-        self.last_scalars = scalars
-        return scalars
+        return scalars, raw
 
     def _compute_gradients_separate(self, settings, gt_int, gt_now, gt_next, gt_blur):
         """The same iteration with one rasteriser call per camera, for triplets whose frames differ in size (the fused
@@ -625,19 +681,20 @@ class EventTrainer:
         return loss.clone()
 
     def compute_gradients_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):
-        if self._counts is None:
-            self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
-        v = self.views
-        flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
-        if self.overlap_features:
-            flags |= _lib.FLAG_DEFER_COLOR
-        pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
-                                              [self._settings(cam, bg)], flags=flags, count_host=self._counts,
-                                              pool=self._pool)
-        pend.before_colour = self.sync_features
-        rasterizer.prepare_multi_finish(pend)
-        rasterizer.wait_count(pend)
-        raw = rasterizer.forward_multi_finish(pend)
+        settings = [self._settings(cam, bg)]
+        for _attempt in range(4):
+            loss, raw = self._image_forward_backward(settings, gt_image, mode, lambda_dssim)
+            if self._count_fits(raw):
+                break
+        else:
+            raise RuntimeError("the instance count kept outgrowing the binning capacity")
+        self.c_grad.zero_()                        # the contrast threshold only exists in the event loss
+        self.last_radii = raw["radii"][0]
+        self.last_scalars = loss
+        return loss
+
+    def _image_forward_backward(self, settings, gt_image, mode, lambda_dssim):
+        raw = self._forward_views(settings)
         img = raw["color"][0]
         gt = gt_image if gt_image.dtype == torch.float32 else gt_image.float()
         gt = gt.contiguous()
@@ -659,10 +716,7 @@ class EventTrainer:
             out["means2D"] = self.viewspace_grad
         self._packed_views = 0                     # single render: the SH gradient itself is exchanged
         rasterizer.backward_multi(raw, dpix, out)
-        self.c_grad.zero_()                        # the contrast threshold only exists in the event loss
-        self.last_radii = raw["radii"][0]
-        self.last_scalars = loss
-        return loss
+        return loss, raw
 
     def step_image_autograd(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):
         """The same iteration through torch autograd (torch activations, drop-in operator, autograd losses): the

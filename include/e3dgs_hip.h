@@ -67,6 +67,8 @@ const char* e3dgs_last_error(void);
                                        Nothing in front of the compositing kernel reads `shs`, so a trainer may still
                                        be reducing / updating the SH coefficients of the previous iteration on
                                        another stream while this iteration projects, sorts and bins. */
+#define E3DGS_FLAG_COUNT_DEVICE 256   /* backward_multi: the forward was e3dgs_rasterize_forward_multi_capacity and
+                                        num_rendered is its `capacity` (the count itself sits in the geometry scratch) */
 #define E3DGS_FLAG_BWD_ONLY_RENDER 8   /* backward: only the compositing backward (pixels -> grad_acc) */
 #define E3DGS_FLAG_BWD_ONLY_GEOM 16    /* backward: only the per-Gaussian backward (grad_acc -> parameter gradients).
                                           Together these let a caller overlap the compositing backward of several
@@ -231,6 +233,27 @@ int e3dgs_rasterize_forward_multi_finish(
     int nviews, int P, int width, int height, const float* background,
     char* geom_buffer, char* image_buffer, int num_rendered,
     float* out_color, int debug, void* stream);
+
+/*
+ * The multi-view forward WITHOUT a host wait (a training loop: train.py:144-161 renders the same scene every iteration,
+ * and the instance count moves by a few percent between iterations).  The caller sizes the binning buffers for
+ * `capacity` instances BEFORE the count is known -- the previous iteration's count plus a margin -- and everything behind
+ * the count pass reads the count from device memory: begin and finish are enqueued back to back, and so may be the
+ * backward (e3dgs_rasterize_backward_multi with num_rendered = capacity: the scratch layouts are those of `capacity`
+ * instances).  *num_rendered_host must be device-mapped pinned memory (E3DGS_FLAG_COUNT_MAPPED is required): the GPU
+ * stores the count there; the caller polls it before it lets anything persistent consume the results (the optimizer
+ * step).  If the count exceeds the capacity nothing was emitted or sorted (all tile lists empty, the image is the
+ * background, the gradients are meaningless): the caller repeats the call with a larger capacity.
+ * Results are bit-identical to begin + wait + finish.  With E3DGS_FLAG_DEFER_COLOR `before_colour` (may be NULL) is
+ * called on the host right before the colour kernel is enqueued, as in ..._multi_finish_colour.
+ */
+int e3dgs_rasterize_forward_multi_capacity(
+    e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc, void* binning_user,
+    e3dgs_alloc_fn image_alloc, void* image_user, int nviews, int P, int D, int M, const float* background, int width,
+    int height, const float* means3D, const float* shs, const float* opacities, const float* scales,
+    float scale_modifier, const float* rotations, const float* const* viewmatrix, const float* const* projmatrix,
+    const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy, float* out_color, int* radii, int debug,
+    int flags, int capacity, int* num_rendered_host, e3dgs_notify_fn before_colour, void* notify_user, void* stream);
 
 /* finish() for a begin() issued with E3DGS_FLAG_DEFER_COLOR.  flags: E3DGS_FLAG_SH_PLANAR as given to begin().
  * before_colour (optional) is called on the host immediately before the colour kernel is enqueued: make `stream`

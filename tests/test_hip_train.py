@@ -858,3 +858,38 @@ def test_sh_optimizer_from_colour_gradients_is_bit_identical(deblur):
             assert torch.equal(a.flat, b.flat)
             a.active_sh_degree = b.active_sh_degree = 3
     assert a.steps == {"gauss": 6, "opacity": 5, "c": 6} and a.iteration == 6
+
+
+@pytest.mark.parametrize("mode", ["event", "gray"])
+def test_iteration_without_host_wait_is_bit_identical_and_survives_an_overflow(mode, monkeypatch):
+    """EventTrainer sizes the binning buffers from earlier counts and reads the count on the device
+    (e3dgs_rasterize_forward_multi_capacity): same parameters, bit for bit, as begin -> host wait -> finish; a capacity
+    that turns out too small costs a repeated forward / backward (count_retries), never a wrong update."""
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene(N=6000)
+    bg = torch.zeros(3, device=DEV)
+    gts = _gts(params, cams, bg)
+
+    def run(no_wait, sabotage=False):
+        monkeypatch.setenv("E3DGS_NO_HOST_WAIT", "1" if no_wait else "0")
+        tr = EventTrainer(params, DEV)
+        assert tr.no_host_wait == no_wait
+        for it in range(4):
+            if sabotage and it == 2:
+                (key, cap), = tr._capacity.items()
+                tr._capacity[key] = 1000                 # far below the real count: the forward emits nothing
+            if mode == "event":
+                tr.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
+            else:
+                tr.step_image(cams[0], gts[0], bg, mode="gray")
+        torch.cuda.synchronize()
+        return tr
+    ref = run(False)
+    new = run(True)
+    assert new.count_retries == 0 and len(new._capacity) == 1
+    assert torch.equal(ref.flat, new.flat) and torch.equal(ref.exp_avg_sq, new.exp_avg_sq)
+    hit = run(True, sabotage=True)
+    assert hit.count_retries == 1
+    assert torch.equal(ref.flat, hit.flat) and torch.equal(ref.exp_avg_sq, hit.exp_avg_sq)
+    (key, cap), = hit._capacity.items()
+    assert cap > 1000                                # regrown from the count that did not fit
