@@ -41,8 +41,10 @@ def algorithmic_bytes(slot, N, I, T, npx):
         "preprocess": 132 * N,
         "sort_depth": 16 * N * 4,                       # 4 passes x (8 B read + 8 B write) on P pairs
         "scan_emit": 8 * N + 20 * N + 8 * I,            # gather+scan, emit (u32 tile id + u32 Gaussian id)
-        "sort_tile": 16 * I * math.ceil(tile_bits / 8),
-        "tile_ranges": 4 * I + 8 * T,
+        # stable tile-id sort of (key, slot) pairs: 16-bit keys up to 65536 tiles; the first pass reads keys only (the
+        # payload is the position), the last pass writes slots only (the ranges come out of its histogram)
+        "sort_tile": (18 if T <= 65536 and 8 < tile_bits <= 16 else 16 * math.ceil(tile_bits / 8)) * I,
+        "tile_ranges": 12 * T,                          # launch-order kernel: ranges in, order out
         "render_fwd": 40 * I + 20 * npx + 12,
         "render_bwd": 40 * I + 20 * npx + 36 * I,
         "geom_bwd": 160 * N,
@@ -220,52 +222,67 @@ def main():
         ob = 28 * (FLOATS_PER_GAUSSIAN * N + 1)          # torch.optim.Adam: read g, p, m, v; write p, m, v
         stages["optimizer"] = {"avg_ms": round(opt_ms, 4), "launches": len(opt_events), "alg_GB": round(ob / 1e9, 4),
                                "alg_GBps": round(ob / 1e9 / (opt_ms / 1e3), 1)}
-    # the roofline object describes the kernel timed inside the timed region (the largest one: DESIGN.md section 5)
-    # measured HBM traffic of every stage (committed PMC profile of this workload, profiles/traffic_stages.json) next to
-    # the algorithmic bytes: the list-building stages move 2-3x their algorithmic bytes (gathers in depth order,
-    # sector granularity), which is what their launch durations have to be read against
-    spath = os.path.join(ROOT, "profiles", "traffic_stages.json")
-    if os.path.exists(spath) and cfg_name == "cfg3_1M_1080p_event":
+    # ---- committed PMC profile of this workload (profiles/traffic.json = summary.json of profiles/collect.py): measured
+    # HBM-side bytes per stage next to the algorithmic ones, instruction mix of the compositing kernels.  The profile
+    # names the sources it was taken on; if they are not the sources this run was built from, its numbers are reported
+    # as stale and the derived figures are dropped.
+    prof, prof_stale = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and cfg_name == "cfg3_1M_1080p_event":
         try:
-            per_stage = json.load(open(spath)).get("bytes_per_stage_launch", {})
-            for name, b in per_stage.items():
-                if name in stages and b:
-                    stages[name]["pmc_GB"] = round(b / 1e9, 4)
-                    stages[name]["pmc_GBps"] = round(b / 1e9 / (stages[name]["avg_ms"] / 1e3), 1)
+            prof = json.load(open(tpath))
+            prof_stale = prof.get("source_fingerprint") != source_fingerprint()
         except Exception:
-            pass
+            prof = None
+    # per-iteration view of the stages (a stage may be several launch groups per iteration)
+    n_iter_prof = max(kern.get("render_fwd", (0, 1))[1], 1)
+    for name, (ms, n) in kern.items():
+        if name in stages:
+            stages[name]["ms_per_iter"] = round(ms / n_iter_prof, 4) if name != dom_name or not timed[dom_name][1] else \
+                round(timed[dom_name][0] / max(timed[dom_name][1], 1), 4)
+    if prof and not prof_stale:
+        for name, rec in prof.get("stages", {}).items():
+            if name in stages and rec.get("bytes_per_iteration"):
+                stages[name]["pmc_GB_per_iter"] = round(rec["bytes_per_iteration"] / 1e9, 4)
+                stages[name]["pmc_GBps"] = round(rec["bytes_per_iteration"] / 1e9 / (stages[name]["ms_per_iter"] / 1e3), 1)
     dominant = dom_name if dom_name in stages else None
     roofline = None
     if dominant:
         s = stages[dominant]
-        traffic, insts = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath)).get(dominant + "_kernel", {})
-                traffic = rec.get("hbm_bytes_per_launch")
-                insts = rec.get("wave_instructions_per_launch")
-            except Exception:
-                traffic = insts = None
-        # what actually bounds compositing: instruction issue.  Nominal rate = one wave64 VALU instruction per 2 cycles
-        # per SIMD (MI355X_MICROARCH.md, register-file table) x 1024 SIMDs x 2.4 GHz; the instruction counts are the
-        # SQ_INSTS_* counters of the committed profile of this kernel (profiles/traffic.json), the time is this run's.
-        issue = None
-        if insts:
-            rate = 1024 * 2.4e9 / 2.0
-            t = s["avg_ms"] / 1e3
-            allinst = sum(insts.get(k, 0) for k in ("valu", "salu", "lds", "branch", "vmem"))
-            issue = {"valu_issue_frac": round(insts["valu"] / (rate * t), 3), "all_instructions_issue_frac": round(allinst / (rate * t), 3),
-                     "valu_wave_instructions": insts["valu"], "salu_wave_instructions": insts.get("salu"),
-                     "nominal_rate": "1 wave64 instruction / 2 cycles / SIMD, 1024 SIMDs, 2.4 GHz"}
+        traffic, issue = None, None
+        if prof and not prof_stale:
+            traffic = prof.get("traffic_per_kernel", {}).get(dominant + "_kernel", {}).get("hbm_bytes_per_launch")
+            sq = prof.get("sq", {}).get(dominant + "_kernel", {})
+            if sq.get("SQ_INSTS_VALU"):
+                # What bounds compositing is VALU throughput.  The per-instruction cost is MEASURED (tools/ubench/valu_rate,
+                # mixed_issue; profiles/<round>/ubench.txt): a wave64 v_fma_f32 issues every 1.20 ns per SIMD under load
+                # (2.9 cycles at the nominal 2.4 GHz: the chip clocks down), v_cmp / v_cndmask cost 1.6x, v_exp / v_rcp
+                # 2.7x, DPP 3.3x; SALU, LDS and branch instructions of other waves issue beside the VALU stream for
+                # +24 % (all three together, in this kernel's 27 : 11 : 3 : 4 ratio).
+                FMA_NS = 1.20
+                t = s["avg_ms"] / 1e3
+                valu = sq["SQ_INSTS_VALU"]
+                floor_fma = valu * FMA_NS * 1e-9 / 1024.0
+                issue = {"valu_wave_instructions": valu, "salu_wave_instructions": sq.get("SQ_INSTS_SALU"),
+                         "lds_wave_instructions": sq.get("SQ_INSTS_LDS"), "branch_wave_instructions": sq.get("SQ_INSTS_BRANCH"),
+                         "transcendental_wave_instructions": sq.get("SQ_INSTS_VALU_TRANS"),
+                         "valu_floor_ms_all_at_fma_rate": round(1e3 * floor_fma, 4),
+                         "valu_floor_frac": round(floor_fma / t, 3),
+                         "mixed_stream_ceiling_frac": round(floor_fma * 1.24 / t, 3),
+                         "wait_frac_of_wave_cycles": (round((sq.get("SQ_WAIT_ANY", 0) + sq.get("SQ_WAIT_INST_ANY", 0)) /
+                                                            sq["SQ_WAVE_CYCLES"], 3) if sq.get("SQ_WAVE_CYCLES") else None),
+                         "measured_rates": "tools/ubench/valu_rate + mixed_issue on this chip: 1.20 ns per wave64 v_fma_f32 "
+                                           "per SIMD; SALU + LDS + branch beside it: x1.24"}
         roofline = {"kernel": dominant + "_kernel", "bound": "hbm", "achieved": s["alg_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(s["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_stale": prof_stale, "profile_source_fingerprint": prof.get("source_fingerprint") if prof else None,
                     "avg_launch_ms": s["avg_ms"], "alg_bytes_per_launch": int(s["alg_GB"] * 1e9),
                     "views_per_launch": V, "issue": issue,
                     "note": "one launch composites the 3 views of the iteration (HIP events on the launch stream, timed "
-                            "region). Compositing is instruction-issue-bound, not HBM-bound (SURVEY 8d, DESIGN.md section 5): "
-                            + (f"VALU issue at {issue['valu_issue_frac']:.0%} of nominal, all instruction types "
-                               f"{issue['all_instructions_issue_frac']:.0%}; " if issue else "")
+                            "region). Compositing is VALU-throughput-bound, not HBM-bound (SURVEY 8d, DESIGN.md section 5): "
+                            + (f"its VALU instructions alone, all at the measured v_fma_f32 rate, need {issue['valu_floor_frac']:.0%} "
+                               f"of the kernel's time ({issue['mixed_stream_ceiling_frac']:.0%} with the measured cost of the "
+                               f"SALU / LDS / branch instructions beside them); " if issue else "")
                             + f"alpha evaluations/s = {256.0 * I / (s['avg_ms'] / 1e3) / 1e9:.1f} G/s"}
 
     # ---- the contrast-only sub-step north_star words the metric by: renders #2 and #3 forward,
@@ -304,6 +321,27 @@ def main():
         contrast = {"ms": round(cms, 3), "per_s": round(1e3 / cms, 1), "renders": 2,
                     "what": "renders #2,#3 fwd + log-contrast L1 (train.py:159-178) + backward of both; no optimizer"}
 
+    # ---- the drop-in path (the reference's unmodified train.py on the two drop-in packages), cfg3 and cfg2
+    dropin = None
+    if world == 1 and not args.no_substep:
+        dropin = {cfg_name: measure_dropin(params, (cam_int, cam_now, cam_next), gts, bg, dev, L)}
+        if cfg_name == "cfg3_1M_1080p_event":
+            N2, W2, H2, _ = CONFIGS["cfg2_200k_800px"]
+            p2 = synth.make_scene(N2, "trained", seed=0, device=dev)
+            cams2 = [orbit_camera(0, K, W2, H2, device=dev, daz=d) for d in (0.0, 0.005, 0.015)]
+            t2 = EventTrainer(p2, dev)
+            gts2 = [(torch.round(t2.render_raw(c_, bg)["color"].clamp(0, 1) * 255.0) / 255.0).contiguous() for c_ in cams2]
+            dropin["cfg2_200k_800px"] = measure_dropin(p2, cams2, gts2, bg, dev, L)
+            for _ in range(5):
+                t2.step(*cams2, *gts2, bg)
+            torch.cuda.synchronize(); tq = time.perf_counter()
+            for _ in range(20):
+                t2.step(*cams2, *gts2, bg)
+            torch.cuda.synchronize()
+            dropin["cfg2_200k_800px"]["fused_step_ms"] = round(1e3 * (time.perf_counter() - tq) / 20, 3)
+            del t2, p2, gts2
+        dropin[cfg_name]["fused_step_ms"] = round(1e3 * dt / args.steps, 3)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows, args.torch_rows)
@@ -329,7 +367,8 @@ def main():
                        "sh_colour_allgather_bytes_per_rank": grad_ag_bytes,
                        "sh_exchange_on_side_stream": bool(trainer.overlap_features), "dp_schedule": dp_schedule,
                        "loss": round(loss_val, 6)},
-            "roofline": roofline, "stages": stages, "contrast_only_substep": contrast, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "stages": stages, "contrast_only_substep": contrast,
+            "dropin_autograd_step": dropin, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
             # ranks the communicator itself reports (1: no process group) and whether the factorised / overlapped
             # exchange had to be replaced by the plain schedule (a failing exchange must not hide in a slower number)
@@ -340,6 +379,82 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_dropin(params, cams, gts, bg, dev, L, iters=8):
+    """The iteration a maintainer of the reference gets after swapping the two packages and running train.py UNMODIFIED
+    (train.py:144,159,161 three render() calls -> :165-203 loss in torch -> :211 loss.backward() -> :212 optimizer_c.step()
+    -> :330-332 optimizer.step()): render() with its forced torch-SH branch (gaussian_renderer/__init__.py:71-81),
+    torch activations (scene/gaussian_model.py:95-118), the GaussianRasterizer autograd operator through the compiled
+    extension (_C_native), the loss formulas of utils/loss_utils.py in torch, torch.optim.Adam over the six groups
+    (scene/gaussian_model.py:154-163) + Adam([c]).  Reported next to -- never instead of -- the fused iteration."""
+    import ctypes as C
+    import torch
+    from event_3dgs_amd import rasterizer
+    from event_3dgs_amd.renderer import GaussianView, PipelineParams, render
+    P = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    lr = dict(xyz=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20.0, opacity=0.05, scaling=5e-3, rotation=1e-3)
+    opt = torch.optim.Adam([{"params": [P[k]], "lr": lr[k], "name": k} for k in
+                            ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")], lr=0.0, eps=1e-15)
+    c = torch.nn.Parameter(torch.tensor([0.17], device=dev))
+    opt_c = torch.optim.Adam([c], lr=0.1)
+    pc = GaussianView(P, active_sh_degree=3, max_sh_degree=3)
+    pipe = PipelineParams()
+    lum = lambda im: (0.4124 * im[0] + 0.35758 * im[1] + 0.1804 * im[2]).unsqueeze(0)      # utils/loss_utils.py:24-28
+    ev = lambda a, b, cc: (torch.log(lum(b) + 1e-8) - torch.log(lum(a) + 1e-8)) / cc       # :234-249
+
+    def step():
+        imgs = [render(cam, pc, pipe, bg)["render"] for cam in cams]
+        img_diff, gt = ev(imgs[1], imgs[2], c), ev(gts[1], gts[2], 0.17)
+        loss1, loss2 = torch.abs(img_diff - gt).mean(), torch.abs(imgs[0] - gts[0]).mean()          # train.py:165-203
+        mask = (gt != 0).to(imgs[0].dtype)
+        loss = (0.9 * (loss1 * mask).sum() + 0.1 * (loss2 * (1 - mask)).sum()) / (mask.sum() + (1 - mask).sum())
+        loss.backward()
+        opt_c.step(); opt_c.zero_grad(set_to_none=True)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    host = []
+    for _ in range(3):                       # host time of one iteration with the GPU idle at entry (enqueue cost)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        step()
+        host.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    # rasteriser kernels of one iteration (HIP events around the library's stages)
+    L.e3dgs_profile_enable(0xFF)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ras = 0.0
+    for slot in range(8):
+        ms, n = C.c_double(0), C.c_int(0)
+        L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
+        ras += ms.value
+    L.e3dgs_profile_enable(0)
+    return {"ms": round(1e3 * wall, 3), "per_s": round(1.0 / wall, 2), "host_enqueue_ms": round(1e3 * sorted(host)[1], 3),
+            "rasteriser_kernels_ms": round(ras / 2, 3), "torch_side_ms": round(1e3 * wall - ras / 2, 3),
+            "native_extension": rasterizer.native_ext() is not None,
+            "what": "3 x render() (torch SH + activations, GaussianRasterizer via _C_native) + torch loss "
+                    "(train.py:165-203) + loss.backward() + torch.optim.Adam (6 groups) + Adam([c])"}
+
+
+def source_fingerprint():
+    """sha256 over the sources the library is built from: ties a committed profile (profiles/traffic*.json) to the code
+    it describes."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "event_3dgs_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    for f in [os.path.join(csrc, x) for x in files] + [os.path.join(ROOT, "include", "e3dgs_hip.h")]:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def self_launch(n):
@@ -398,6 +513,17 @@ def run_torch_cpu_baseline(inp, cams, bg, W, H, rows, budget_s=90.0):
     gy = (H + 15) // 16
     r0 = max(0, gy // 2 - rows // 2)
     total, detail = 0.0, []
+    # untimed warm-up (thread pool start, first-touch of the allocator arenas, autograd graph caches): the first timed view
+    # used to carry ~25 % of one-off cost
+    sub = slice(0, min(100_000, inp["means"].shape[0]))
+    wl = [torch.from_numpy(inp[k][sub]).clone().requires_grad_(True) for k in ("means", "opac", "shs", "scales", "rots")]
+    wimg, _, _ = torch_oracle.rasterize(
+        wl[0], wl[1], viewmatrix=cams[0].world_view_transform.cpu(), projmatrix=cams[0].full_proj_transform.cpu(),
+        campos=cams[0].camera_center.cpu(), bg=bg.cpu(), width=W, height=H, tanfovx=math.tan(cams[0].FoVx * 0.5),
+        tanfovy=math.tan(cams[0].FoVy * 0.5), shs=wl[2], sh_degree=3, scales=wl[3], rotations=wl[4],
+        tile_rows=(r0, r0 + 1), return_aux=True)
+    wimg.sum().backward()
+    del wl, wimg
     t_begin = time.perf_counter()
     for cam in cams:
         if detail and time.perf_counter() - t_begin > budget_s:       # slow host: remaining views cost what the mean did

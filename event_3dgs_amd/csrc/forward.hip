@@ -553,9 +553,21 @@ __device__ __forceinline__ uint2 normalise_empty_range(uint2* __restrict__ range
     return r;
 }
 
+// Longest-first deals tile rank r to wave slot r: the SIMD that gets rank s also gets ranks s + L, s + 2L, ... (L = one
+// wave per SIMD of the chip), always the heaviest of its layer.  Reversing every other layer ("snake") evens the sums
+// out, which matters when the launch is only one or two layers deep (small frames: all waves start at t = 0 and the
+// kernel takes as long as its most loaded SIMD).  snake = L, 0 = plain longest-first.
+__device__ __forceinline__ uint32_t snake_pos(uint32_t pos, uint32_t n, uint32_t snake) {
+    if (snake == 0u) return pos;
+    const uint32_t layer = pos / snake, first = layer * snake;
+    if ((layer & 1u) == 0u) return pos;
+    const uint32_t len = n - first < snake ? n - first : snake;
+    return first + (len - 1u - (pos - first));
+}
+
 __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ work,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, uint32_t snake) {
     auto key = [&](int t) -> uint32_t { if (work) return work[t]; uint2 r = ranges[t]; return r.y - r.x; };
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __r
     __syncthreads();
     for (int t = tid; t < ntiles; t += 1024) {
         uint32_t pos = atomicAdd(&hist[1023u - min(1023u, key(t) / width)], 1u);
-        order[pos] = (uint32_t)t;
+        order[snake_pos(pos, (uint32_t)ntiles, snake)] = (uint32_t)t;
     }
 }
 
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __r
 constexpr int ORDER_ITEMS = 32;
 __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, uint2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ work,
-                                                              uint32_t* __restrict__ order) {
+                                                              uint32_t* __restrict__ order, uint32_t snake) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t smax;
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, uint2*
         const int t = tid + i * 1024;
         if (t < ntiles) {
             uint32_t pos = atomicAdd(&hist[key[i]], 1u);
-            order[pos] = (uint32_t)t;
+            order[snake_pos(pos, (uint32_t)ntiles, snake)] = (uint32_t)t;
         }
     }
 }
@@ -725,6 +737,10 @@ __global__ __launch_bounds__(1024) void tile_order_xcd_kernel(int ntiles, int ns
     }
 }
 
+static uint32_t lpt_snake() {
+    static const uint32_t v = [] { const char* e = getenv("E3DGS_LPT_SNAKE"); return e ? (uint32_t)atoi(e) : 0u; }();
+    return v;
+}
 static int xcd_block() {
     static const int v = [] { const char* e = getenv("E3DGS_XCD_BLOCK"); return e ? atoi(e) : 0; }();
     return v;
@@ -749,9 +765,9 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
         }
     }
     if (ntiles <= ORDER_ITEMS * 1024)
-        tile_order_reg_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
+        tile_order_reg_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order, lpt_snake());
     else
-        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
+        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order, lpt_snake());
     return ntiles;
 }
 
