@@ -78,6 +78,13 @@ def window_parity(trainer, cam, bg, tile_rows, grad_seed=7):
         "n_contrib_equal": bool(np.array_equal(st["n_contrib"][y0:y1].cpu().numpy().astype(np.uint32), f.n_contrib[y0:y1])),
         "visible": int((f.radii > 0).sum()), "oracle_instances": f.num_rendered, "hip_instances": hip["num_rendered"],
     }
+    # n_contrib counts list POSITIONS.  With exact tile culling the HIP lists are ordered sub-sequences of the oracle's
+    # (rectangle-binned) lists, so positions are compared after mapping every HIP list position to the position of the
+    # same Gaussian in the oracle's list of that tile.
+    res["n_contrib_mapped_equal"] = _n_contrib_equal_after_mapping(
+        st["point_list"].cpu().numpy().astype(np.int64), st["ranges"].cpu().numpy().astype(np.int64),
+        st["n_contrib"].cpu().numpy().astype(np.int64), f.point_list.astype(np.int64), f.ranges.astype(np.int64),
+        f.n_contrib.astype(np.int64), W, H, r0, r1)
     gw = np.zeros((3, H, W), np.float32)
     gw[:, y0:y1] = np.random.default_rng(grad_seed).standard_normal((3, y1 - y0, W)).astype(np.float32)
     gb = f.backward(gw)
@@ -97,6 +104,98 @@ def window_parity(trainer, cam, bg, tile_rows, grad_seed=7):
     return res
 
 
+def _n_contrib_equal_after_mapping(pl_h, rg_h, nc_h, pl_o, rg_o, nc_o, W, H, r0, r1):
+    gx = (W + 15) // 16
+    for ty in range(r0, r1):
+        for tx in range(gx):
+            t = ty * gx + tx
+            lh, lo = pl_h[rg_h[t, 0]:rg_h[t, 1]], pl_o[rg_o[t, 0]:rg_o[t, 1]]
+            pos_o = {int(g): i + 1 for i, g in enumerate(lo)}           # a Gaussian occurs once per tile list
+            try:
+                to_o = np.array([0] + [pos_o[int(g)] for g in lh], np.int64)        # HIP position (1-based) -> oracle position
+            except KeyError:
+                return False                                             # a HIP instance the oracle does not have
+            if len(to_o) > 2 and not np.all(np.diff(to_o[1:]) > 0):
+                return False                                             # not an ORDERED sub-sequence
+            ys, xs = slice(ty * 16, min(H, ty * 16 + 16)), slice(tx * 16, min(W, tx * 16 + 16))
+            if not np.array_equal(to_o[nc_h[ys, xs]], nc_o[ys, xs]):
+                return False
+    return True
+
+
+def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
+    """The path bench.py TIMES against the C oracle at full size: ONE multi-view pass (rasterizer.forward_multi /
+    backward_multi) with the trainer's flags -- activations inside the kernels (E3DGS_FLAG_PREACT) on the raw parameters,
+    coefficient-major SH (E3DGS_FLAG_SH_PLANAR) -- instead of single-view calls on torch-activated AoS inputs
+    (window_parity).  The oracle gets the parameters activated with torch on the CPU and composites one window of tile
+    rows per view; the pixel gradients are supported on those windows; its gradients are summed over the views and taken
+    through torch's activations (chain rule by autograd) to the raw parameters.
+
+    The in-kernel activations differ from torch's by <= 1 ulp, and the rasteriser is discontinuous at its thresholds, so
+    -- unlike window_parity -- a handful of pixels / Gaussians may gain or lose ONE borderline contribution: the result
+    reports how many."""
+    from event_3dgs_amd import rasterizer
+    from oracle import c_oracle
+    dev = trainer.device
+    raw_cpu = {k: t.detach().cpu().clone().requires_grad_(True) for k, t in trainer.views.items()}
+    scales_a = torch.exp(raw_cpu["scaling"])
+    rots_a = torch.nn.functional.normalize(raw_cpu["rotation"])
+    opac_a = torch.sigmoid(raw_cpu["opacity"])
+    shs_np = np.ascontiguousarray(raw_cpu["features"].detach().t().reshape(-1, 16, 3).numpy())
+    P = raw_cpu["xyz"].shape[0]
+    W, H = int(cams[0].image_width), int(cams[0].image_height)
+    settings = [trainer._settings(c, bg) for c in cams]
+    v = trainer.views
+    hip = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
+                                   flags=trainer.FWD_FLAGS)
+    gw = np.zeros((len(cams), 3, H, W), np.float32)
+    rng = np.random.default_rng(grad_seed)
+    res = {"views": []}
+    acc = {k: 0.0 for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    for k, (cam, (r0, r1)) in enumerate(zip(cams, rows_per_view)):
+        y0, y1 = r0 * 16, min(H, r1 * 16)
+        gw[k, :, y0:y1] = rng.standard_normal((3, y1 - y0, W)).astype(np.float32)
+        f = c_oracle.Forward(means3D=raw_cpu["xyz"].detach().numpy(), opacities=opac_a.detach().numpy(),
+                             viewmatrix=cam.world_view_transform.contiguous().cpu().numpy(),
+                             projmatrix=cam.full_proj_transform.cpu().numpy(),
+                             campos=cam.camera_center.contiguous().cpu().numpy(), bg=bg.cpu().numpy(), width=W, height=H,
+                             tanfovx=settings[k].tanfovx, tanfovy=settings[k].tanfovy, shs=shs_np, sh_degree=3,
+                             scales=scales_a.detach().numpy(), rotations=rots_a.detach().numpy(), tile_rows=(r0, r1))
+        d = np.abs(hip["color"][k][:, y0:y1].cpu().numpy() - f.out_color[:, y0:y1])
+        res["views"].append({"image_max_abs": float(d.max()), "pixels_off_by_1e-4": float((d > 1e-4).mean()),
+                             "radii_mismatch": int((hip["radii"][k].cpu().numpy() != f.radii).sum()),
+                             "visible": int((f.radii > 0).sum())})
+        gb = f.backward(gw[k])
+        for name in acc:
+            acc[name] = acc[name] + np.asarray(gb[name], np.float64)
+        f.close()
+    # oracle gradients w.r.t. the RAW parameters: torch's chain rule through exp / normalize / sigmoid
+    t64 = lambda a, like: torch.from_numpy(np.asarray(a)).to(like.dtype).reshape(like.shape)
+    torch.autograd.backward([scales_a, rots_a, opac_a], [t64(acc["scales"], scales_a), t64(acc["rotations"], rots_a),
+                                                          t64(acc["opacities"], opac_a)])
+    ref = {"xyz": acc["means3D"], "scaling": raw_cpu["scaling"].grad.numpy(), "rotation": raw_cpu["rotation"].grad.numpy(),
+           "opacity": raw_cpu["opacity"].grad.numpy(),
+           "features": np.ascontiguousarray(acc["shs"].reshape(P, 48).T)}              # (P,16,3) -> (48,P) planar
+    e = lambda like: torch.full_like(like, float("nan"))
+    out = dict(means3D=e(v["xyz"]), sh=e(v["features"]), opacities=e(v["opacity"]), scales=e(v["scaling"]), rots=e(v["rotation"]))
+    rasterizer.backward_multi(hip, torch.from_numpy(gw).to(dev), out)
+    got = {"xyz": out["means3D"], "scaling": out["scales"], "rotation": out["rots"], "opacity": out["opacities"],
+           "features": out["sh"]}
+    res["grad"] = {}
+    for name, t in got.items():
+        a = t.cpu().numpy().astype(np.float64)
+        assert np.isfinite(a).all(), name
+        b = np.asarray(ref[name], np.float64).reshape(a.shape)
+        if name == "features":
+            a, b = a.T, b.T                                                              # rows = Gaussians
+        a2, b2 = a.reshape(P, -1), b.reshape(P, -1)
+        scale = 1e-3 * np.abs(b2).max()
+        per = np.abs(a2 - b2).max(axis=1) / (np.abs(b2).max(axis=1) + scale)
+        res["grad"][name] = {"rel_l2": rel_l2(a2, b2), "per_gaussian_q999": float(np.quantile(per, 0.999)),
+                             "per_gaussian_over_1e-3": int((per > 1e-3).sum())}
+    return res
+
+
 def assert_window_parity(res, grad_l2=1e-3, grad_pg=1e-3):
     assert res["radii_equal"], "radii differ from the oracle"
     assert res["image_max_abs"] == 0.0, res["image_max_abs"]            # bit-exact forward (DESIGN: arithmetic contract)
@@ -104,6 +203,7 @@ def assert_window_parity(res, grad_l2=1e-3, grad_pg=1e-3):
     assert res["hip_instances"] <= res["oracle_instances"]                 # exact tile culling only ever drops instances
     if res["hip_instances"] == res["oracle_instances"]:                    # n_contrib counts list POSITIONS: equal lists only
         assert res["n_contrib_equal"]
+    assert res["n_contrib_mapped_equal"]        # culled lists: positions mapped back to the oracle's lists
     for name, (l2, pg) in res["grad"].items():
         assert l2 <= grad_l2, (name, "rel L2", l2)
         assert pg <= grad_pg, (name, "per-Gaussian", pg)

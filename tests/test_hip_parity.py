@@ -417,6 +417,57 @@ def test_known_answer_scenarios_on_the_gpu(no_tile_cull):
         assert np.array_equal(st["point_list"].cpu().numpy().astype(np.uint32), f.point_list)
 
 
+def test_ka11_analytic_backward_on_the_gpu():
+    """The closed-form gradients of tests/test_oracle_known_answers.py::ka11_case (one isotropic Gaussian on the optical
+    axis, one-hot pixel gradient; derived by hand, from no implementation) through the HIP operator."""
+    import test_oracle_known_answers as ka
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    from event_3dgs_amd import rasterizer
+    case, gw, expect = ka.ka11_case()
+    dev = torch.device("cuda:0")
+    view, proj, campos = ka.cam()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32))).to(dev)
+    rs = GaussianRasterizationSettings(ka.H, ka.W, ka.TANF, ka.TANF, t(np.zeros(3)), 1.0, t(view), t(proj), 3, t(campos),
+                                       False, False)
+    raw = rasterizer.forward_raw(t(case["means"]), None, t(case["cols"]), t(case["opac"]), t(case["scales"]), t(ka.IDQ),
+                                 None, rs)
+    e = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float32, device=dev)
+    out = dict(means2D=e(1, 3), opacities=e(1, 1), colors=e(1, 3), means3D=e(1, 3), scales=e(1, 3), rots=e(1, 4))
+    rasterizer.backward_raw(raw, t(gw), out)
+    grads = {"colors": out["colors"].cpu().numpy(), "opacities": out["opacities"].cpu().numpy(),
+             "means3D": out["means3D"].cpu().numpy(), "scales": out["scales"].cpu().numpy(),
+             "means2D": out["means2D"].cpu().numpy(), "rotations": out["rots"].cpu().numpy()}
+    ka.check_ka11(grads, expect)
+
+
+def test_tight_candidate_box_keeps_the_same_instances():
+    """bin_kernel walks the tiles of the axis-aligned box of the (slack-inflated) alpha >= 1/255 ellipse instead of the
+    whole 3-sigma rectangle; tile_touched() still decides.  The kept instance set must not change -- also for large
+    splats whose centre lies far off the screen (their rectangle is clamped to the grid, so the distance from the centre
+    to its pixels is larger than the rectangle itself)."""
+    from event_3dgs_amd import _lib, rasterizer
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    for seed, boost, radius in ((3, 1.0, 4.0), (4, 6.0, 4.0), (5, 12.0, 2.2), (6, 25.0, 1.6)):
+        act, cam = scene(4000, 208, 144, seed=seed, scale_boost=boost, radius=radius)
+        rs = _settings(cam, (0, 0, 0), dev)
+        d = lambda x: x.to(dev)
+        got = {}
+        for mode in (1, 3):                          # 1: tight candidate box (default), 3: every tile of the rectangle
+            L.e3dgs_set_tile_cull(mode)
+            try:
+                raw = rasterizer.forward_raw(d(act["means3D"]), None, d(act["colors"]), d(act["opacities"]), d(act["scales"]),
+                                             d(act["rotations"]), None, rs)
+                st = rasterizer.state_views(raw, 4000, 208, 144)
+                got[mode] = (raw["num_rendered"], st["point_list"].cpu().numpy().copy(), st["ranges"].cpu().numpy().copy(),
+                             raw["color"].cpu().numpy().copy())
+            finally:
+                L.e3dgs_set_tile_cull(1)
+        assert got[1][0] == got[3][0] and got[1][0] > 0, (seed, got[1][0], got[3][0])
+        assert np.array_equal(got[1][1], got[3][1]) and np.array_equal(got[1][2], got[3][2])
+        assert np.array_equal(got[1][3], got[3][3])
+
+
 def test_argument_errors_of_the_operator_and_the_c_abi():
     """SURVEY 8b "Errors": the operator raises as the upstream one does (exactly one of SHs / colours and of
     scale+rotation / covariance; means3D must be (P,3); fp32 only), and the C ABI refuses bad arguments with a

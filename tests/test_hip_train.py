@@ -893,3 +893,34 @@ def test_iteration_without_host_wait_is_bit_identical_and_survives_an_overflow(m
     assert torch.equal(ref.flat, hit.flat) and torch.equal(ref.exp_avg_sq, hit.exp_avg_sq)
     (key, cap), = hit._capacity.items()
     assert cap > 1000                                # regrown from the count that did not fit
+
+
+def test_checkpoint_resume_continues_the_adam_bias_correction():
+    """capture_checkpoint(EventTrainer.steps) -> restore_checkpoint / restored_steps -> import_groups(steps=...): the
+    resumed trainer takes exactly the step the original takes next (a resume that restarted the step counts at 1 with
+    non-zero moments would move the parameters ~10x too far)."""
+    from event_3dgs_amd import io_formats as IO
+    from event_3dgs_amd.densify import DensifyStats
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene()
+    bg = torch.zeros(3, device=DEV)
+    gts = _gts(params, cams, bg)
+    a = EventTrainer(params, DEV)
+    for _ in range(3):
+        a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
+    a.reset_opacity()                                     # the opacity group's moments restart; its count does not
+    a.steps["opacity"] -= 1                               # (as after an iteration torch skipped for the opacity group)
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    tup = IO.capture_checkpoint(a.export_groups(), DensifyStats(a.N, DEV), a.active_sh_degree, 1.0, lrs, a.steps)
+    groups, _, deg, _ = IO.restore_checkpoint(tup)
+    b = EventTrainer(params, DEV, active_sh_degree=deg)
+    b.import_groups(groups, steps={**IO.restored_steps(tup), "c": a.steps["c"]})
+    off, _ = a.seg["c"]
+    for dst, src in ((b.flat, a.flat), (b.exp_avg, a.exp_avg), (b.exp_avg_sq, a.exp_avg_sq)):
+        dst[off] = src[off]                               # optimizer_c is not part of GaussianModel.capture()
+    b.iteration = a.iteration
+    assert b.steps == a.steps and torch.equal(a.flat, b.flat) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    for t in (a, b):
+        t.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat, b.flat)

@@ -182,3 +182,70 @@ def test_ka10_torch_oracle_gradients_vs_finite_differences():
         fd = float(f(plus) - f(minus)) / (2 * eps)
         an = float((leaves[k].grad * d).sum())
         assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (k, fd, an)
+
+
+def ka11_case():
+    """One isotropic Gaussian on the optical axis, one-hot pixel gradient: inputs + closed-form gradients.
+
+    With the mean at (0, 0, z) the projection Jacobian is diagonal (J02 = J12 = 0 and their derivatives w.r.t. x, y vanish),
+    so Sigma2 = diag(a, c), a = (f s_x / z)^2 + 0.3, c = (f s_y / z)^2 + 0.3, and for the pixel (u, v)
+        L = (g . col) alpha,   alpha = o exp(-(dx^2 / a + dy^2 / c) / 2),   dx = u - px, dy = v - py.
+    Every partial below is a textbook derivative of that expression -- nothing is taken from any implementation."""
+    z, s, o = 3.0, 0.12, 0.7
+    col = np.array([0.9, 0.4, 0.2])
+    u, v = 35, 29
+    g = np.array([0.5, -1.25, 2.0])
+    cx = cy = (W - 1) / 2.0
+    dx, dy = u - cx, v - cy
+    fz = FOCAL / z
+    a = c = (fz * s) ** 2 + 0.3
+    alpha = o * math.exp(-0.5 * (dx * dx / a + dy * dy / c))
+    assert 1 / 255 < alpha < 0.99
+    gc = float(g @ col)
+    expect = {
+        "colors": g * alpha,
+        "opacities": gc * alpha / o,
+        # d(dx)/d(mean_x) = -d(px)/dx = -f/z  ->  dL/dx = gc alpha (dx / a) f/z
+        "means3D_xy": np.array([gc * alpha * dx / a * fz, gc * alpha * dy / c * fz]),
+        # a = (f s / z)^2 + 0.3: da/dz = -2 f^2 s^2 / z^3 (and the same for c); px, py do not move with z on the axis
+        "means3D_z": gc * alpha * 0.5 * (dx * dx / a ** 2 + dy * dy / c ** 2) * (-2.0 * FOCAL ** 2 * s ** 2 / z ** 3),
+        # da/ds_x = 2 (f/z)^2 s_x; s_z does not enter Sigma2 on the axis
+        "scales": np.array([gc * alpha * 0.5 * dx * dx / a ** 2 * 2 * fz ** 2 * s,
+                            gc * alpha * 0.5 * dy * dy / c ** 2 * 2 * fz ** 2 * s, 0.0]),
+        # screen-space gradient in NDC units (scene/gaussian_model.py:405-407): d(px)/d(ndc_x) = W / 2
+        "means2D": np.array([gc * alpha * dx / a * (W / 2.0), gc * alpha * dy / c * (H / 2.0)]),
+    }
+    gw = np.zeros((3, H, W), np.float32)
+    gw[:, v, u] = g
+    return dict(means=[[0, 0, z]], scales=[[s, s, s]], opac=[o], cols=[col]), gw, expect
+
+
+def check_ka11(grads, expect, rtol=2e-4):
+    close = lambda a, b: np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=1e-7)
+    assert close(grads["colors"][0], expect["colors"])
+    assert close(np.asarray(grads["opacities"]).reshape(-1)[0], expect["opacities"])
+    assert close(grads["means3D"][0, :2], expect["means3D_xy"])
+    assert close(grads["means3D"][0, 2], expect["means3D_z"])
+    assert close(grads["scales"][0], expect["scales"])
+    assert close(grads["means2D"][0, :2], expect["means2D"])
+    assert np.allclose(grads["rotations"][0], 0.0, atol=1e-6)          # isotropic: the rotation cannot matter
+
+
+def test_ka11_analytic_backward_of_a_single_gaussian():
+    case, gw, expect = ka11_case()
+    f = run(case["means"], case["scales"], case["opac"], case["cols"])
+    check_ka11(f.backward(gw), expect)
+    # the independent PyTorch oracle (autograd) gives the same numbers
+    view, proj, campos = cam()
+    leaves = {k: torch.tensor(np.asarray(case[k], np.float64), requires_grad=True) for k in ("means", "scales", "opac", "cols")}
+    img, _ = torch_oracle.rasterize(leaves["means"], leaves["opac"].reshape(-1, 1), viewmatrix=torch.tensor(view, dtype=torch.float64),
+                                    projmatrix=torch.tensor(proj, dtype=torch.float64), campos=torch.tensor(campos, dtype=torch.float64),
+                                    bg=torch.zeros(3, dtype=torch.float64), width=W, height=H, tanfovx=TANF, tanfovy=TANF,
+                                    colors_precomp=leaves["cols"], scales=leaves["scales"],
+                                    rotations=torch.tensor(IDQ, dtype=torch.float64))
+    (img * torch.tensor(gw, dtype=torch.float64)).sum().backward()
+    assert np.allclose(leaves["means"].grad[0, :2].numpy(), expect["means3D_xy"], rtol=1e-5)
+    assert np.allclose(leaves["means"].grad[0, 2].item(), expect["means3D_z"], rtol=1e-5)
+    assert np.allclose(leaves["scales"].grad[0].numpy(), expect["scales"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(leaves["opac"].grad[0].item(), expect["opacities"], rtol=1e-5)
+    assert np.allclose(leaves["cols"].grad[0].numpy(), expect["colors"], rtol=1e-5)
