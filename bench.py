@@ -321,6 +321,43 @@ def main():
         contrast = {"ms": round(cms, 3), "per_s": round(1e3 / cms, 1), "renders": 2,
                     "what": "renders #2,#3 fwd + log-contrast L1 (train.py:159-178) + backward of both; no optimizer"}
 
+    # ---- several ranks: what the exchange costs, so that one JSON line diagnoses an 8-GPU run.  After the timed region:
+    #   exposed_comm_ms  = step time - time of the same step without any exchange (sync_grads=False: local Adam)
+    #   allreduce_ms / allgather_ms = the two collectives of the default schedule alone, on their real buffers
+    comm = None
+    if world > 1:
+        def timed_ms(fn, reps):
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        from event_3dgs_amd import parallel as par
+        nonsh = torch.zeros(11 * N + 1, device=dev)
+        colour = torch.zeros(9 * N + 9, device=dev)
+        gathered = torch.zeros(world, colour.numel(), device=dev)
+        ar_ms = timed_ms(lambda: par.allreduce_mean_(nonsh), 5)
+        ag_ms = timed_ms(lambda: par.allgather_async_(gathered, colour).wait(), 5)
+        sh = (nonsh.numel() + world - 1) // world
+        stag, shard = torch.zeros(world * sh, device=dev), torch.zeros(sh, device=dev)
+        rs_ms = timed_ms(lambda: (par.reduce_scatter_mean_async_(shard, stag).wait(),
+                                  par.allgather_flat_async_(stag, shard).wait()), 5)
+        local_ms = timed_ms(lambda: trainer.step(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur,
+                                                 sync_grads=False), max(3, args.steps // 2))
+        comm = {"exposed_comm_ms": round(1e3 * dt / args.steps - local_ms, 4), "local_step_ms": round(local_ms, 4),
+                "allreduce_ms": round(ar_ms, 4), "allreduce_bytes": 4 * nonsh.numel(),
+                "allgather_ms": round(ag_ms, 4), "allgather_bytes_per_rank": 4 * colour.numel(),
+                "reduce_scatter_plus_allgather_ms": round(rs_ms, 4),
+                "nonsh_schedule": trainer.dp_schedule, "sh_exchange": "factorised" if trainer.factorize_sh else "allreduce",
+                "sh_exchange_bytes": par.sh_exchange_bytes(world, N),
+                "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                       "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                                       "E3DGS_DP_SCHEDULE", "E3DGS_FACTORIZE_SH", "E3DGS_OVERLAP")}}
+        del nonsh, colour, gathered, stag, shard
+
     # ---- the drop-in path (the reference's unmodified train.py on the two drop-in packages), cfg3 and cfg2
     dropin = None
     if world == 1 and not args.no_substep:
@@ -374,7 +411,7 @@ def main():
             # exchange had to be replaced by the plain schedule (a failing exchange must not hide in a slower number)
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "comm_backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
-            "dp_fallback": dp_fallback,
+            "dp_fallback": dp_fallback, "comm": comm,
         }
         print(json.dumps(out))
     if world > 1:

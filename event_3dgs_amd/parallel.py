@@ -78,6 +78,50 @@ def allgather_async_(out, local, group=None):
     return PendingGather(out, work)
 
 
+def sh_exchange_bytes(world, n_gaussians, views_per_rank=3, sh_floats=48):
+    """Bytes a rank RECEIVES per iteration for the SH coefficients' gradient (48 of the 59 floats per Gaussian):
+      factorised  all-gather of the per-view colour gradients: (world - 1) blocks of views * 3 floats per Gaussian
+                  (+ every rank then reads world blocks from HBM to rebuild the mean gradient);
+      allreduce   ring all-reduce of the SH gradient itself: 2 (world - 1) / world * 48 floats per Gaussian.
+    The factorised exchange moves fewer bytes while world < 2 * 48 / (3 * views) (= 10.67 for an event triplet)."""
+    colour = 4 * 3 * views_per_rank * n_gaussians
+    fact = (world - 1) * colour
+    ar = int(2 * (world - 1) / max(world, 1) * 4 * sh_floats * n_gaussians)
+    return {"factorised_link_bytes": fact, "factorised_rebuild_read_bytes": world * colour, "allreduce_link_bytes": ar}
+
+
+def choose_sh_exchange(world, views_per_rank=3, sh_floats=48):
+    """'factorised' or 'allreduce' by the bytes that cross xGMI (sh_exchange_bytes), not by `world > 1`."""
+    b = sh_exchange_bytes(world, 1, views_per_rank, sh_floats)
+    return "factorised" if world > 1 and b["factorised_link_bytes"] < b["allreduce_link_bytes"] else "allreduce"
+
+
+class PendingShard:
+    def __init__(self, out, work, divide_by):
+        self.out, self.work, self.divide_by = out, work, divide_by
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            if self.divide_by:
+                self.out.div_(self.divide_by)
+        return self.out
+
+
+def reduce_scatter_mean_async_(out_shard, staging, group=None):
+    """Mean over the ranks of `staging` (world * shard elements), rank r keeping elements [r * shard, (r + 1) * shard):
+    the first half of the direct reduce-scatter + all-gather schedule -- every rank then runs the optimizer
+    on its shard only and the updated parameters are all-gathered."""
+    op, divide = _mean_op(group)
+    work = dist.reduce_scatter_tensor(out_shard, staging, op=op, group=group, async_op=True)
+    return PendingShard(out_shard, work, dist.get_world_size(group) if divide else 0)
+
+
+def allgather_flat_async_(full, shard, group=None):
+    """All-gather of one equally sized shard per rank into the flat tensor `full` (world * shard elements)."""
+    return PendingShard(full, dist.all_gather_into_tensor(full, shard, group=group, async_op=True), 0)
+
+
 def rank_camera_indices(rank, world, n_cameras, iteration, seed=0, exclude=(5, 25, 45, 65, 85), mode="event"):
     """Deterministic per-rank camera draw mirroring train.py:116-131: index in [2, n-4] in event mode ([2, n-3]
     otherwise), the held-out evaluation views shifted down by one in event / gray mode.  Every rank can recompute

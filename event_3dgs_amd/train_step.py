@@ -63,7 +63,7 @@ class EventTrainer:
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
-                 track_densification_stats=False, overlap_features=None, factorize_sh=None):
+                 track_densification_stats=False, overlap_features=None, factorize_sh=None, dp_schedule=None):
         self.device = torch.device(device)
         self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
@@ -79,6 +79,19 @@ class EventTrainer:
         self.steps = {"gauss": 0, "opacity": 0, "c": 0}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        # Exchange of the non-SH groups (11 floats per Gaussian + c) between the ranks:
+        #   "allreduce"  in-place mean (RCCL picks ring / tree), every rank then runs Adam on all of them;
+        #   "rs_ag"      the direct schedule of SURVEY 5.8: reduce-scatter of the gradients, Adam on the OWNED shard only
+        #                (1 / world of the optimizer's HBM traffic and of its moments' updates), all-gather of the updated
+        #                parameters.  Same bytes on the links; the replicas stay bit-identical (everyone receives the same
+        #                updated shards).  The moments of the other ranks' shards are stale on this rank until
+        #                sync_optimizer_state() gathers them (export, densification, checkpoints do).
+        sched = os.environ.get("E3DGS_DP_SCHEDULE") or dp_schedule or "allreduce"
+        if sched not in ("allreduce", "rs_ag"):
+            raise ValueError("dp_schedule must be 'allreduce' or 'rs_ag'")
+        self.dp_schedule = sched if self.world > 1 else "allreduce"
+        self._shard = None
         self.track_stats = track_densification_stats
         # The SH coefficients are 48 of the 59 floats per Gaussian, and nothing in front of the compositing kernel reads
         # them (E3DGS_FLAG_DEFER_COLOR).  With overlap_features their gradient averaging + Adam run on a second stream
@@ -102,7 +115,10 @@ class EventTrainer:
         # own) must be trained with factorize_sh=False -- the mixed-size fallback of compute_gradients() has no per-view
         # colour gradients to exchange, and ranks that disagree about the exchange would issue different collectives.
         if factorize_sh is None:
-            factorize_sh = os.environ.get("E3DGS_FACTORIZE_SH", "1") != "0"
+            env = os.environ.get("E3DGS_FACTORIZE_SH")
+            # by the bytes that cross the links (parallel.sh_exchange_bytes): 9 floats per Gaussian from every other rank
+            # against a ring all-reduce of 48 -- the factorised exchange wins while world < 10.67
+            factorize_sh = (env != "0") if env is not None else parallel.choose_sh_exchange(self.world) == "factorised"
         self.factorize_sh = self.world > 1 and bool(factorize_sh)
         # One rank: the same factorisation pays inside the GPU.  step() lets the backward hand out the per-view colour
         # gradients (9 floats per Gaussian) instead of the 48-float SH gradient, and ONE streaming kernel rebuilds that
@@ -165,6 +181,7 @@ class EventTrainer:
     def _bind(self, N):
         """Typed views into the flat buffers of N Gaussians + everything else that depends on N."""
         self.N = N
+        self._shard = None             # (rs_ag schedule) shard-local optimizer state is rebuilt from the flat buffers
         assert self.flat.numel() == N * FLOATS_PER_GAUSSIAN + 1
         if self.flat_grad is None or self.flat_grad.numel() != self.flat.numel():
             self.flat_grad = torch.zeros_like(self.flat)
@@ -194,6 +211,7 @@ class EventTrainer:
     def export_groups(self):
         """Reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]  (scene/gaussian_model.py:154-163 groups)."""
         self.sync_features()
+        self.sync_optimizer_state()
         N = self.N
         out = {}
         for idx, buf in enumerate((self.flat, self.exp_avg, self.exp_avg_sq)):
@@ -231,6 +249,7 @@ class EventTrainer:
         densify.densify_and_prune is the same algorithm in torch on the reference layout (golden-pinned)."""
         import ctypes as C
         self.sync_features()
+        self.sync_optimizer_state()
         L = _lib.lib()
         N, dev = self.N, self.device
         scratch = torch.empty(L.e3dgs_densify_scratch_bytes(N), dtype=torch.uint8, device=dev)
@@ -270,6 +289,7 @@ class EventTrainer:
         its Adam moments zeroed -- in place on the opacity segment (the other groups, their moments and this
         iteration's gradients stay, as in the reference, where only the opacity parameter is replaced)."""
         self.sync_features()
+        self.sync_optimizer_state()
         o = self.views["opacity"]
         x = torch.min(torch.sigmoid(o), torch.ones_like(o) * 0.01)
         o.copy_(torch.log(x / (1 - x)))
@@ -344,6 +364,8 @@ class EventTrainer:
                 self.steps[name] += 1
                 st[name] = self.steps[name]
         dist_on = self.world > 1 and sync_grads
+        if self.world > 1 and (not dist_on or "gaussians" in skip):
+            self.sync_optimizer_state()        # (rs_ag: these paths update the FULL moment buffers on every rank)
         if "gaussians" in skip:
             if st["c"]:
                 if dist_on:
@@ -388,7 +410,11 @@ class EventTrainer:
         mean = (lambda c: parallel.allreduce_mean_async_(self.flat_grad[c[1]:c[1] + c[2]], self.pg)) if dist_on else \
                (lambda c: None)
         # every rank issues its collectives in the same order: small groups first, then the SH exchange
-        pend_small = [(c, mean(c)) for c in small]
+        sharded = dist_on and self.dp_schedule == "rs_ag"
+        if not dist_on:
+            self.sync_optimizer_state()            # (a local step updates the full moment buffers)
+        pend_small = [] if sharded else [(c, mean(c)) for c in small]
+        pend_shard = self._nonsh_reduce_scatter() if sharded else None
         with torch.cuda.stream(side):
             if grads_ready is not None:
                 side.wait_event(grads_ready)
@@ -401,6 +427,8 @@ class EventTrainer:
             if p is not None:
                 p.wait()
             self._adam_chunk(c, it, st)
+        if sharded:
+            self._nonsh_adam_shard_and_allgather(pend_shard, it, st)
         with torch.cuda.stream(side):
             if fact:
                 if gather is not None:
@@ -601,10 +629,83 @@ class EventTrainer:
 
     def _allreduce_and_adam(self, it, st):
         chunks = self._comm_chunks()
+        sharded = self.dp_schedule == "rs_ag"
+        if sharded:                                   # non-SH groups: reduce-scatter -> Adam on the shard -> all-gather
+            pend_shard = self._nonsh_reduce_scatter()
+            chunks = [c for c in chunks if c[0] == "features"]
         pend = [parallel.allreduce_mean_async_(self.flat_grad[off:off + n], self.pg) for _, off, n in chunks]
+        if sharded:
+            self._nonsh_adam_shard_and_allgather(pend_shard, it, st)
         for c, p in zip(chunks, pend):
             p.wait()
             self._adam_chunk(c, it, st)
+
+    # ---- direct reduce-scatter + all-gather schedule for the non-SH groups (dp_schedule == "rs_ag")
+    # staging order: xyz (3N) | opacity (N) | scaling (3N) | rotation (4N) | c (1), padded to world * shard elements
+    def _nonsh_regions(self):
+        t_off = self.seg["opacity"][0]
+        return (self.seg["xyz"], (t_off, self.flat.numel() - t_off))
+
+    def _ensure_shards(self):
+        if self._shard is not None:
+            return self._shard
+        n = sum(r[1] for r in self._nonsh_regions())
+        sh = (n + self.world - 1) // self.world
+        z = lambda k: torch.zeros(k, dtype=torch.float32, device=self.device)
+        S = dict(n=n, size=sh, g=z(self.world * sh), p=z(self.world * sh), gs=z(sh), ps=z(sh), m=z(sh), v=z(sh))
+        for buf, dst in ((self.exp_avg, S["m"]), (self.exp_avg_sq, S["v"])):       # this rank's slice of the moments
+            self._stage(buf, S["p"])
+            dst.copy_(S["p"][self.rank * sh:(self.rank + 1) * sh])
+        self._shard = S
+        return S
+
+    def _stage(self, flat_buf, staging):
+        o = 0
+        for off, n in self._nonsh_regions():
+            staging[o:o + n].copy_(flat_buf[off:off + n])
+            o += n
+
+    def _unstage(self, staging, flat_buf):
+        o = 0
+        for off, n in self._nonsh_regions():
+            flat_buf[off:off + n].copy_(staging[o:o + n])
+            o += n
+
+    def _nonsh_reduce_scatter(self):
+        S = self._ensure_shards()
+        self._stage(self.flat_grad, S["g"])
+        return parallel.reduce_scatter_mean_async_(S["gs"], S["g"], self.pg)
+
+    def _nonsh_adam_shard_and_allgather(self, pend, it, st):
+        S = self._shard
+        sh, n, N = S["size"], S["n"], self.N
+        a = self.rank * sh
+        b = min(a + sh, n)
+        self._stage(self.flat, S["p"])
+        S["ps"].copy_(S["p"][a:a + sh])
+        pend.wait()                                       # mean gradient of the owned shard
+        if b > a:
+            ends_abs = (3 * N, 4 * N, 7 * N, 11 * N, 11 * N + 1)                   # xyz | opacity | scaling | rotation | c
+            ends = tuple(min(max(e - a, 0), b - a) for e in ends_abs)
+            lrs = (self.xyz_lr(it), self.lrs["opacity"], self.lrs["scaling"], self.lrs["rotation"], self.c_lr)
+            g, o, c = st["gauss"], st["opacity"], st["c"]
+            k = b - a
+            losses.adam_step_segments_(S["ps"][:k], S["gs"][:k], S["m"][:k], S["v"][:k], ends, lrs,
+                                       (1e-15,) * 4 + (1e-8,), (g, o, g, g, c))
+        parallel.allgather_flat_async_(S["p"], S["ps"], self.pg).wait()
+        self._unstage(S["p"], self.flat)
+
+    def sync_optimizer_state(self):
+        """dp_schedule == "rs_ag": gather the moments every rank keeps for its own shard of the non-SH groups into the
+        full exp_avg / exp_avg_sq buffers (collective: every rank calls it -- before exporting, checkpointing, densifying
+        or resetting).  A no-op for the other schedules."""
+        S = self._shard
+        if S is None or self.world == 1:
+            return
+        for shard, full in ((S["m"], self.exp_avg), (S["v"], self.exp_avg_sq)):
+            parallel.allgather_flat_async_(S["p"], shard, self.pg).wait()
+            self._unstage(S["p"], full)
+        self._shard = None                                 # rebuilt from the (now complete) flat buffers when next needed
 
     def _adam_chunk(self, chunk, it, st):
         kind, off, n = chunk

@@ -33,10 +33,10 @@ def test_mismatched_world_size_is_an_error():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("force_fallback", [False, True])
-def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback):
+@pytest.mark.parametrize("force_fallback,schedule", [(False, "allreduce"), (False, "rs_ag"), (True, "allreduce")])
+def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback, schedule):
     """The driver's command form on a one-GPU box: both ranks share cuda:0 and talk over gloo (test hooks of bench.py)."""
-    env = dict(os.environ, E3DGS_BENCH_BACKEND="gloo", E3DGS_BENCH_DEVICE="0")
+    env = dict(os.environ, E3DGS_BENCH_BACKEND="gloo", E3DGS_BENCH_DEVICE="0", E3DGS_DP_SCHEDULE=schedule)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     if force_fallback:
         env["E3DGS_BENCH_FORCE_FALLBACK"] = "1"
@@ -50,3 +50,9 @@ def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback):
     assert out["scaling"] == "weak" and out["value"] > 0
     assert out["dp_fallback"] is force_fallback
     assert out["config"]["workload"] == "tiny"
+    # the exchange is diagnosable from the line alone
+    comm = out["comm"]
+    for key in ("exposed_comm_ms", "allreduce_ms", "allgather_ms", "reduce_scatter_plus_allgather_ms", "local_step_ms"):
+        assert isinstance(comm[key], float), key
+    assert comm["nonsh_schedule"] == schedule and "NCCL_ALGO" in comm["env"] and "NCCL_PROTO" in comm["env"]
+    assert comm["sh_exchange"] == ("allreduce" if force_fallback else "factorised")

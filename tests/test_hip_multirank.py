@@ -34,17 +34,24 @@ def _inputs(rank):
     return params, cams, gts, bg
 
 
-def _worker(rank, world, port, out, overlap, factorize):
+def _worker(rank, world, port, out, overlap, factorize, schedule="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["E3DGS_FACTORIZE_SH"] = "1" if factorize else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from event_3dgs_amd.train_step import EventTrainer
     params, cams, gts, bg = _inputs(rank)
-    tr = EventTrainer(params, DEV, overlap_features=overlap)
+    tr = EventTrainer(params, DEV, overlap_features=overlap, dp_schedule=schedule)
     assert tr.world == 2 and tr.overlap_features == overlap and tr.factorize_sh == factorize
+    assert tr.dp_schedule == schedule and tr.rank == rank
     for _ in range(STEPS):
         tr.step(*cams, *gts, bg)
+    if schedule == "rs_ag":
+        # every rank only advanced the moments of its own shard of the non-SH groups ...
+        off, n = tr.seg["xyz"]
+        stale = tr.exp_avg[off:off + n].clone()
+        tr.sync_optimizer_state()                       # ... until they are gathered (export / densify / checkpoint do)
+        assert not torch.equal(stale, tr.exp_avg[off:off + n])
     torch.cuda.synchronize()
     torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu(), "seg": dict(tr.seg)},
                f"{out}.{rank}")
@@ -93,6 +100,23 @@ def test_two_ranks_equal_single_process_emulation(tmp_path, overlap, factorize):
     for _ in range(STEPS):
         solo.step(*ca, *ga, bg)
     assert not torch.equal(solo.flat.cpu(), r0["flat"])
+
+
+@pytest.mark.parametrize("overlap,factorize", [(False, False), (True, True)])
+def test_reduce_scatter_allgather_schedule_equals_the_allreduce_schedule(tmp_path, overlap, factorize):
+    """dp_schedule="rs_ag" (reduce-scatter of the non-SH gradients, Adam on the owned shard, all-gather of the
+    updated parameters): replicas bit-identical, and -- two ranks over gloo sum two numbers either way -- bit-identical to
+    the all-reduce schedule, parameters and (after sync_optimizer_state) moments."""
+    res = {}
+    for sched in ("allreduce", "rs_ag"):
+        out = str(tmp_path / sched)
+        mp.spawn(_worker, args=(2, _free_port(), out, overlap, factorize, sched), nprocs=2, join=True)
+        r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+        for k in ("flat", "m", "v"):
+            assert torch.equal(r0[k], r1[k]), (sched, k)
+        res[sched] = r0
+    for k in ("flat", "m", "v"):
+        assert torch.equal(res["allreduce"][k], res["rs_ag"][k]), k
 
 
 def _fit_worker(rank, world, port, out):

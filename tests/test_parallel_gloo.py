@@ -51,6 +51,14 @@ def _worker(rank, world, port, out):
     local = torch.full((5,), float(rank + 1))
     gathered = parallel.allgather_async_(torch.zeros(world, 5), local).wait()
     assert torch.equal(gathered, torch.tensor([[1.0] * 5, [2.0] * 5]))
+    # the direct schedule: reduce-scatter of the mean + all-gather of the shards == the all-reduced mean
+    n = flat.numel()
+    sh = (n + world - 1) // world
+    staging = torch.zeros(world * sh)
+    staging[:n] = _view_grad(act, rank, 64, 48)
+    shard = parallel.reduce_scatter_mean_async_(torch.empty(sh), staging).wait()
+    full = parallel.allgather_flat_async_(torch.empty(world * sh), shard).wait()
+    assert torch.equal(full[:n], flat)
     idx = [parallel.rank_camera_indices(r, world, 100, iteration=7) for r in range(world)]
     if rank == 0:
         torch.save({"flat": flat, "idx": idx}, out)
@@ -99,3 +107,13 @@ def test_comm_chunks_tile_the_flat_buffer():
         feats = [c for c in chunks if c[0] == "features"]
         assert feats[0][1] == seg["features"][0] and sum(c[2] for c in feats) == 48 * N
         assert feats[0][2] >= min(3 * N, 48 * N)          # all f_dc rows sit in the first feature chunk
+
+
+def test_sh_exchange_is_chosen_by_link_bytes():
+    """Factorised (all-gather of 9 floats per Gaussian and rank) against a ring all-reduce of the 48 SH-gradient floats:
+    252 vs 336 MB per rank at 8 ranks and 1 M Gaussians; the all-reduce moves fewer bytes from 11 ranks on."""
+    from event_3dgs_amd import parallel
+    b = parallel.sh_exchange_bytes(8, 1_000_000)
+    assert b["factorised_link_bytes"] == 7 * 36_000_000 and b["allreduce_link_bytes"] == 336_000_000
+    assert [parallel.choose_sh_exchange(w) for w in (1, 2, 8, 10, 11, 16)] == \
+        ["allreduce", "factorised", "factorised", "factorised", "allreduce", "allreduce"]
