@@ -16,6 +16,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+// chained-scan descriptor of bin_fused_kernel (same format as scan_sort.hip's): {2-bit status, 62-bit sum}
+constexpr unsigned long long SCD_AGG = 1ull << 62, SCD_PREFIX = 2ull << 62, SCD_MASK = (1ull << 62) - 1ull;
+
 // ------------------------------------------------------------------------------------ SH colour
 // element (k, ch) of one Gaussian's SH block lives at sh[(k*3 + ch) * st]: st = 1 for the reference's
 // (P,M,3) layout, st = P for the coefficient-major layout (E3_FLAG_SH_PLANAR, coalesced across lanes)
@@ -358,40 +361,22 @@ __device__ __forceinline__ bool tile_touched(float x0, float y0, float A, float 
 // hundreds of tiles) 64 splats per wave would leave most of the chip idle, so a wave then owns only 1 << gshift of
 // them (e3_bin_group_shift: at least 8192 waves whenever there are that many splats).
 constexpr int BIN_WAVES = 4;
-template <bool EMIT>
-__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift, int nviews, int ntiles,
-                                                              const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ nvis /* [1]: length of `order` */,
-                                                              const uint2* __restrict__ rect, int packed_rect,
-                                                              const float4* __restrict__ rec, int gx, int cull,
-                                                              const uint32_t* __restrict__ wave_offsets,
-                                                              uint32_t* __restrict__ wave_counts,
-                                                              void* __restrict__ keys, int keys16,
-                                                              uint32_t* __restrict__ emit_gid,
-                                                              uint2* __restrict__ run_sorted,
-                                                              uint8_t* __restrict__ touched,
-                                                              const uint32_t* __restrict__ total_dev, uint32_t capacity) {
-    __shared__ float4 sA[BIN_WAVES][WAVE];     // x, y, conic.x, conic.y
-    __shared__ uint32_t sCnt[BIN_WAVES][WAVE]; // kept instances per splat of the wave (EMIT only)
-    __shared__ float4 sB[BIN_WAVES][WAVE];     // conic.z, thr, xmin|ymin<<16, width
-    __shared__ uint32_t sIncl[BIN_WAVES][WAVE];
-    __shared__ uint32_t sId[BIN_WAVES][WAVE];
-    __shared__ float4 sD[BIN_WAVES][WAVE];       // -B/C, -B/A, 1/width, first tile id of the splat's view
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * BIN_WAVES + wave;
-    const int s = (gw << gshift) + lane;
-    if ((gw << gshift) >= P) return;
-    // `order` holds the splats the projection kept, by depth: the depth sort dropped the culled ones (their count is
-    // only known on the device).  Waves behind the end have nothing to walk.
-    const int nv = (int)__builtin_amdgcn_readfirstlane(*nvis);
-    // (buffers sized before the count was known: more instances than they hold -> nothing is written, see
-    // e3_forward_finish_impl)
-    if (EMIT && total_dev && *total_dev > capacity) return;
-    if ((gw << gshift) >= nv) {
-        if (!EMIT && lane == 0) wave_counts[gw] = 0u;
-        return;
-    }
-    const bool mine = lane < (1 << gshift) && s < nv;
+
+// LDS tables of one binning wave: what the candidate walk needs of its (up to) 64 splats
+struct BinTables {
+    float4 A[WAVE];       // x, y, conic.x, conic.y
+    float4 B[WAVE];       // conic.z, thr, xmin|ymin<<16, width
+    float4 D[WAVE];       // -B/C, -B/A, 1/width, first tile id of the splat's view
+    uint32_t incl[WAVE];  // inclusive scan of the candidate counts
+    uint32_t id[WAVE];    // splat ids
+    uint32_t cnt[WAVE];   // kept instances per splat (emission)
+};
+
+// Gathers the records of the wave's splats (depth-sorted positions s of `order`), derives the candidate rectangles and
+// fills the wave's tables.  Returns the number of candidate (splat, tile) items of the wave (wave-uniform).
+__device__ __forceinline__ uint32_t bin_load_tables(BinTables& T, int lane, bool mine, int s, int nviews, int ntiles,
+                                                    const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
+                                                    int packed_rect, const float4* __restrict__ rec, int cull) {
     uint32_t n = 0, g = 0;
     float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
     if (mine) {
@@ -417,10 +402,9 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
             float thr = 2.0f * logf(255.0f * t.y);
             thr = thr + fabsf(thr) * 1e-4f + 1e-3f + 2e-3f * (fabsf(a.z) + 2.0f * fabsf(a.w) + fabsf(t.x));
             uint32_t xy0 = r.x;
-#ifndef E3_NO_TIGHT_RECT
             // Candidate rectangle: the reference walks every tile of the 3-sigma square; tile_touched() then keeps those the
-            // ellipse q <= thr can reach.  Nearly half of the candidates fail that test, and every one costs both binning
-            // passes a search + test.  The axis-aligned box of the (inflated) ellipse is known in closed form --
+            // ellipse q <= thr can reach.  Nearly half of the candidates fail that test, and every one costs the binning
+            // walk a search + test.  The axis-aligned box of the (inflated) ellipse is known in closed form --
             // |dx| <= sqrt(thr' C / det), |dy| <= sqrt(thr' A / det) -- so only its tiles are walked.  thr' carries the
             // relative slack tile_touched() subtracts (1e-4 of the summed |terms|, bounded over the rectangle's pixels) and the
             // box a pixel of margin: every tile outside it fails tile_touched(), i.e. the kept set is unchanged
@@ -450,7 +434,6 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
                     } else n = 0u;                      // 255 o < 1 everywhere (with slack): nothing can be kept
                 }
             }
-#endif
             b = make_float4(t.x, thr, __uint_as_float(xy0), __uint_as_float(w));
         }
     }
@@ -462,18 +445,29 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     }
     // (made scalar explicitly: a trip count that sits in a VGPR makes the candidate loop a divergent loop)
     const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
-    sA[wave][lane] = a; sB[wave][lane] = b; sIncl[wave][lane] = incl; sId[wave][lane] = g;
+    T.A[lane] = a; T.B[lane] = b; T.incl[lane] = incl; T.id[lane] = g;
     {
         const uint32_t tbase = nviews > 1 ? (g % (uint32_t)nviews) * (uint32_t)ntiles : 0u;
         const float fw = (float)__float_as_uint(b.w);
-        sD[wave][lane] = n ? make_float4(-a.w / b.x, -a.w / a.z, 1.0f / fw, __uint_as_float(tbase))
-                           : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        T.D[lane] = n ? make_float4(-a.w / b.x, -a.w / a.z, 1.0f / fw, __uint_as_float(tbase))
+                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (EMIT) sCnt[wave][lane] = 0;
+    T.cnt[lane] = 0;
     wave_sync();
+    return total;
+}
+
+// The flattened candidate walk of one wave: 64 candidate (splat, tile) items at a time.  EMIT = false counts the kept
+// items; EMIT = true replays the identical walk and writes (tile id, splat id) compacted with a ballot prefix at
+// out_base + (position among the wave's kept items).  Emission order = depth order of the splats, row-major inside a
+// rectangle -- exactly the order the reference's per-Gaussian loop produces, so a stable sort on the tile id alone
+// finishes the job.  Returns the number of kept items (wave-uniform).
+template <bool EMIT>
+__device__ __forceinline__ uint32_t bin_walk(BinTables& T, int lane, uint32_t total, int gx, int cull, uint32_t out_base,
+                                             void* __restrict__ keys, int keys16, uint32_t* __restrict__ emit_gid,
+                                             uint8_t* __restrict__ touched) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t count = 0;
-    const uint32_t out_base = EMIT ? __builtin_amdgcn_readfirstlane(wave_offsets[gw]) : 0u;
     for (uint32_t m0 = 0; m0 < total; m0 += WAVE) {
         const uint32_t m = m0 + lane;
         const bool active = m < total;
@@ -482,11 +476,11 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
             int mid = (lo + hi) >> 1;
-            if (sIncl[wave][mid] > m) hi = mid; else lo = mid + 1;
+            if (T.incl[mid] > m) hi = mid; else lo = mid + 1;
         }
         const int j = lo;
-        const uint32_t excl = j ? sIncl[wave][j - 1] : 0u;
-        const float4 A4 = sA[wave][j], B4 = sB[wave][j], D4 = sD[wave][j];
+        const uint32_t excl = j ? T.incl[j - 1] : 0u;
+        const float4 A4 = T.A[j], B4 = T.B[j], D4 = T.D[j];
         const uint32_t k = m - excl, w = __float_as_uint(B4.w), xy0 = __float_as_uint(B4.z);
         uint32_t row = (uint32_t)(((float)k + 0.5f) * D4.z);       // w, k < 2^24: exact after the fix-up
         if (row * w > k) --row;
@@ -502,26 +496,158 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
             const uint32_t tile_id = __float_as_uint(D4.w) + (uint32_t)ty * (uint32_t)gx + (uint32_t)tx;
             if (keys16) reinterpret_cast<uint16_t*>(keys)[pos] = (uint16_t)tile_id;      // (<= 65536 tiles: 16-bit sort keys)
             else reinterpret_cast<uint32_t*>(keys)[pos] = tile_id;
-            emit_gid[pos] = sId[wave][j];
+            emit_gid[pos] = T.id[j];
             touched[pos] = 0;                       // (render_fwd_kernel sets it for the instances it evaluates)
-            atomicAdd(&sCnt[wave][j], 1u);
+            atomicAdd(&T.cnt[j], 1u);
         }
         count += (uint32_t)__popcll(mask);
     }
+    return count;
+}
+
+// run of each splat of the wave, stored at its DEPTH-SORTED position: (first slot, kept instances)
+__device__ __forceinline__ void bin_store_runs(BinTables& T, int lane, bool mine, int s, uint32_t out_base,
+                                               uint2* __restrict__ run_sorted) {
+    wave_sync();
+    const uint32_t c = T.cnt[lane];
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (mine) run_sorted[s] = make_uint2(out_base + inc - c, c);
+}
+
+// Two-pass form (the operator: the binning buffers are allocated between the passes, with the exact count): EMIT=false
+// counts the kept items per wave (-> inclusive scan -> total instance count I), EMIT=true replays the walk and writes.
+template <bool EMIT>
+__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift, int nviews, int ntiles,
+                                                              const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ nvis /* [1]: length of `order` */,
+                                                              const uint2* __restrict__ rect, int packed_rect,
+                                                              const float4* __restrict__ rec, int gx, int cull,
+                                                              const uint32_t* __restrict__ wave_offsets,
+                                                              uint32_t* __restrict__ wave_counts,
+                                                              void* __restrict__ keys, int keys16,
+                                                              uint32_t* __restrict__ emit_gid,
+                                                              uint2* __restrict__ run_sorted,
+                                                              uint8_t* __restrict__ touched,
+                                                              const uint32_t* __restrict__ total_dev, uint32_t capacity) {
+    __shared__ BinTables tabs[BIN_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * BIN_WAVES + wave;
+    const int s = (gw << gshift) + lane;
+    if ((gw << gshift) >= P) return;
+    // `order` holds the splats the projection kept, by depth: the depth sort dropped the culled ones (their count is
+    // only known on the device).  Waves behind the end have nothing to walk.
+    const int nv = (int)__builtin_amdgcn_readfirstlane(*nvis);
+    // (buffers sized before the count was known: more instances than they hold -> nothing is written, see
+    // e3_forward_finish_impl)
+    if (EMIT && total_dev && *total_dev > capacity) return;
+    if ((gw << gshift) >= nv) {
+        if (!EMIT && lane == 0) wave_counts[gw] = 0u;
+        return;
+    }
+    const bool mine = lane < (1 << gshift) && s < nv;
+    BinTables& T = tabs[wave];
+    const uint32_t total = bin_load_tables(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull);
+    const uint32_t out_base = EMIT ? __builtin_amdgcn_readfirstlane(wave_offsets[gw]) : 0u;
+    const uint32_t count = bin_walk<EMIT>(T, lane, total, gx, cull, out_base, keys, keys16, emit_gid, touched);
     if (!EMIT) {
         if (lane == 0) wave_counts[gw] = count;
     } else {
-        // run of each splat, stored at its DEPTH-SORTED position: (first slot, kept instances)
-        wave_sync();
-        const uint32_t c = sCnt[wave][lane];
-        uint32_t inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (mine) run_sorted[s] = make_uint2(out_base + inc - c, c);
+        bin_store_runs(T, lane, mine, s, out_base, run_sorted);
     }
+}
+
+// Single-launch form (a forward whose binning buffers were sized BEFORE the count is known,
+// e3dgs_rasterize_forward_multi_capacity): the records are gathered ONCE -- that gather, 48 bytes at a random address per
+// splat, is what bounds a binning pass -- the wave walks its candidates to count them, the workgroups chain their counts
+// with decoupled look-back (descriptors as in scan_chained_kernel: {status, sum} in one 64-bit word, logical workgroup
+// ids from an atomic ticket so that a workgroup only ever waits for workgroups that have started), and the wave walks
+// the candidates again -- tables still in LDS -- to emit.  The last active workgroup publishes the instance count
+// (device word for the kernels behind, mapped host word for the caller).  A wave whose items would not fit the capacity
+// writes nothing: the count then exceeds the capacity and everything behind treats the forward as empty.
+__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_fused_kernel(int P, int gshift, int nviews, int ntiles,
+                                                                    const uint32_t* __restrict__ order,
+                                                                    const uint32_t* __restrict__ nvis,
+                                                                    const uint2* __restrict__ rect, int packed_rect,
+                                                                    const float4* __restrict__ rec, int gx, int cull,
+                                                                    unsigned long long* desc /* nblocks + 1, zeroed */,
+                                                                    unsigned nblocks, void* __restrict__ keys, int keys16,
+                                                                    uint32_t* __restrict__ emit_gid,
+                                                                    uint2* __restrict__ run_sorted,
+                                                                    uint8_t* __restrict__ touched,
+                                                                    uint32_t* __restrict__ total_dev,
+                                                                    volatile int* total_host, uint32_t capacity) {
+    __shared__ BinTables tabs[BIN_WAVES];
+    __shared__ uint32_t s_bid, s_excl, s_cnt[BIN_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_bid = (uint32_t)atomicAdd(desc + nblocks, 1ull);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const int nv = (int)__builtin_amdgcn_readfirstlane(*nvis);
+    const int per_block = BIN_WAVES << gshift;                   // splats per workgroup
+    const int first = (int)bid * per_block;
+    if (nv <= 0) {                                               // nothing visible at all: the count is 0
+        if (bid == 0 && threadIdx.x == 0) {
+            *total_dev = 0u;
+            if (total_host) { *total_host = 0; __threadfence_system(); }
+        }
+        return;
+    }
+    if (first >= nv) return;                                     // (workgroups behind the last splat: nobody looks back at them)
+    const int gw = (int)bid * BIN_WAVES + wave;
+    const int s = (gw << gshift) + lane;
+    const bool mine = lane < (1 << gshift) && s < nv;
+    BinTables& T = tabs[wave];
+    const uint32_t total = bin_load_tables(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull);
+    const uint32_t count = bin_walk<false>(T, lane, total, gx, cull, 0u, nullptr, 0, nullptr, nullptr);
+    if (lane == 0) s_cnt[wave] = count;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t agg = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (lane == 0)
+            __hip_atomic_store(desc + bid, (bid == 0 ? SCD_PREFIX : SCD_AGG) | (unsigned long long)agg, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        int p = (int)bid - 1;                       // lane l looks at workgroup p - l
+        while (p >= 0) {
+            const int idx = p - lane;
+            const unsigned long long d = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                  : SCD_PREFIX;
+            const uint32_t st = (uint32_t)(d >> 62);
+            const unsigned long long ready = __ballot(st != 0u), pre = __ballot(st == 2u);
+            const int lead = (~ready) ? __builtin_ctzll(~ready) : 64;
+            const int firstpre = pre ? __builtin_ctzll(pre) : 64;
+            const int use = firstpre < lead ? firstpre + 1 : lead;
+            uint32_t c = lane < use ? (uint32_t)(d & SCD_MASK) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            excl += c;
+            if (firstpre < lead) break;
+            p -= use;
+            if (use == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) {
+            if (bid != 0)
+                __hip_atomic_store(desc + bid, SCD_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if (first + per_block >= nv) {          // the last workgroup with a splat: the grand total
+                *total_dev = excl + agg;
+                if (total_host) { *total_host = (int)(excl + agg); __threadfence_system(); }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t out_base = s_excl;
+    for (int w = 0; w < wave; ++w) out_base += s_cnt[w];
+    out_base = __builtin_amdgcn_readfirstlane(out_base);
+    if (out_base + count > capacity) return;                     // (would not fit: see above)
+    bin_walk<true>(T, lane, total, gx, cull, out_base, keys, keys16, emit_gid, touched);
+    bin_store_runs(T, lane, mine, s, out_base, run_sorted);
 }
 
 // After the stable tile sort the [start, end) of each tile comes out of the sort itself (scan_sort.hip: the last
@@ -994,7 +1120,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                           const ViewBatch& views, int P, int D, int M, int W, int H, const float* means3D,
                           const float* shs, const float* colors, const float* opac, const float* scales,
                           float scale_modifier, const float* rots, const float* cov_pre, int* radii, int debug,
-                          int flags, int* count_host, hipStream_t s) {
+                          int flags, int* count_host, hipStream_t s, int skip_count) {
     const ViewSet vs = make_view_set(views, W, H, scale_modifier);
     const int nv = vs.n;
     const int ntiles = vs.v[0].gx * vs.v[0].gy;
@@ -1026,7 +1152,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                                                             : preprocess_kernel<4, false>);
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                            geom.offsets, bin_scan_desc, (int)scan_desc_words(Q));
+                                            geom.offsets, bin_scan_desc, (int)bin_desc_words(Q));
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
@@ -1040,6 +1166,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0 || keys_sorted != geom.key0)
             return e3_fail(hipErrorUnknown, "internal: depth order not in ord0 / key0");
+        if (skip_count) return 0;       // (pre-sized binning buffers: bin_fused_kernel counts and emits in `finish`)
         const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
         const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
@@ -1069,7 +1196,8 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
 // word as usual, repeats the call with larger buffers.
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc, int count_on_device) {
+                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc, int count_on_device,
+                           int* count_host_mapped) {
     const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
     const int tiles_per_view = gx * gy;
     const int ntiles = tiles_per_view * nviews;
@@ -1097,10 +1225,18 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         const uint32_t* count_dev = count_on_device ? geom.offsets + nwaves : nullptr;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
-                                                                    geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
-                                                                    g_tile_cull, geom.offsets, nullptr, k0, keys16,
-                                                                    bin.emit_gid, geom.run, bin.touched, count_dev, I);
+        if (count_on_device == 2)
+            // one launch: count, chain the counts across the workgroups, emit (records gathered once); the count goes to
+            // geom.offsets[nwaves] for the kernels behind and to the caller's mapped host word
+            bin_fused_kernel<<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(
+                (int)Q, gshift, nviews, tiles_per_view, geom.ord0, geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
+                g_tile_cull, reinterpret_cast<unsigned long long*>(geom.scratch + sort_scratch_words(Q)), bb, k0, keys16,
+                bin.emit_gid, geom.run, bin.touched, geom.offsets + nwaves, count_host_mapped, I);
+        else
+            bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
+                                                                        geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec,
+                                                                        gx, g_tile_cull, geom.offsets, nullptr, k0, keys16,
+                                                                        bin.emit_gid, geom.run, bin.touched, count_dev, I);
         }
         KERNEL_OK("bin emit");
         uint32_t* vs;
