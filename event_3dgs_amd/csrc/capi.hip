@@ -332,12 +332,9 @@ int e3dgs_rasterize_forward_multi_capacity(e3dgs_alloc_fn geom_alloc, void* geom
     kg = Keep{geom_alloc, geom_user, nullptr};
     ki = Keep{image_alloc, image_user, nullptr};
     auto grab = [](void* u, size_t n) -> char* { Keep* k = (Keep*)u; k->ptr = k->fn(k->user, n); return k->ptr; };
-    // E3DGS_FUSED_BIN=0: count pass + scan in `begin`, emission in `finish` (two gathers of the splat records) instead of
-    // the single-launch bin_fused_kernel
-    static const int fused = [] { const char* e = getenv("E3DGS_FUSED_BIN"); return (e && e[0] == '0') ? 0 : 1; }();
     rc = e3_forward_begin_impl(grab, &kg, grab, &ki, vb, P, D, M, width, height, means3D, shs, nullptr, opacities, scales,
                                scale_modifier, rotations, nullptr, radii, debug, flags, num_rendered_host,
-                               (hipStream_t)stream, fused);
+                               (hipStream_t)stream);
     if (rc) return rc;
     DeferredColour dc;
     const bool defer = (flags & E3_FLAG_DEFER_COLOR) != 0;
@@ -348,7 +345,7 @@ int e3dgs_rasterize_forward_multi_capacity(e3dgs_alloc_fn geom_alloc, void* geom
     }
     return e3_forward_finish_impl(binning_alloc, binning_user, vb.n, P, width, height, background, kg.ptr, ki.ptr,
                                   P > 0 ? capacity : 0, out_color, debug, (hipStream_t)stream, defer ? &dc : nullptr,
-                                  P > 0 ? (fused ? 2 : 1) : 0, num_rendered_host);
+                                  P > 0 ? 1 : 0);
 }
 
 int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,

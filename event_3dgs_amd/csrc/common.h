@@ -163,17 +163,6 @@ static inline int e3_bin_group_shift(size_t Q, int adaptive) {
     while (sh > 0 && ((Q + ((size_t)1 << sh) - 1) >> sh) < 8192) --sh;
     return sh;
 }
-// words (uint32) of the zeroed descriptors behind the depth sort's scratch: the chained scan of the per-wave instance
-// counts (two-pass binning) or the look-back chain of bin_fused_kernel (one descriptor per workgroup of 4 waves + ticket)
-static inline size_t bin_desc_words(size_t Q) {
-    size_t w = 2 * ((Q + SCAN_TILE - 1) / SCAN_TILE + 1);
-    for (int adaptive = 0; adaptive < 2; ++adaptive) {
-        const int sh = e3_bin_group_shift(Q, adaptive);
-        const size_t nwaves = (Q + ((size_t)1 << sh) - 1) >> sh, blocks = (nwaves + 3) / 4;
-        if (2 * (blocks + 1) > w) w = 2 * (blocks + 1);
-    }
-    return w;
-}
 // run_reduce: below this many splats one WAVE sums a splat's records (lanes stride over the run) instead of one thread
 constexpr size_t E3_RUN_REDUCE_WAVE_MAX = 262144;
 
@@ -215,7 +204,7 @@ struct GeomState {
         g.ord1 = carve<uint32_t>(p, n);
         g.tiles = carve<uint32_t>(p, n);
         g.offsets = carve<uint32_t>(p, n + 64);      // [0] = 0, then one entry per binning wave (<= n of them)
-        g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + bin_desc_words(n) + 64);
+        g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_desc_words(n) + 64);
         g.total = carve<uint32_t>(p, 64);
         g.nvis = g.total + 16;
         return g;
@@ -340,7 +329,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                           const ViewBatch& views, int P, int D, int M, int W, int H, const float* means3D,
                           const float* shs, const float* colors, const float* opac, const float* scales,
                           float scale_modifier, const float* rots, const float* cov_pre, int* radii, int debug,
-                          int flags, int* count_host, hipStream_t s, int skip_count = 0);
+                          int flags, int* count_host, hipStream_t s);
 struct DeferredColour {          // inputs of colour_kernel (E3_FLAG_DEFER_COLOR), handed to `finish`
     ViewBatch views;
     int D, M, flags;
@@ -352,7 +341,7 @@ struct DeferredColour {          // inputs of colour_kernel (E3_FLAG_DEFER_COLOR
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
                            float* out_color, int debug, hipStream_t s, const DeferredColour* dc = nullptr,
-                           int count_on_device = 0, int* count_host_mapped = nullptr);
+                           int count_on_device = 0);
 int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_rendered, const float* background, int W,
                      int H, const float* means3D, const float* shs, const float* colors, const float* opacities,
                      const float* scales, float scale_modifier, const float* rots, const float* cov_pre,

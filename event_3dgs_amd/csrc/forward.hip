@@ -16,9 +16,6 @@
 #include "common.h"
 #include <stdlib.h>
 
-// chained-scan descriptor of bin_fused_kernel (same format as scan_sort.hip's): {2-bit status, 62-bit sum}
-constexpr unsigned long long SCD_AGG = 1ull << 62, SCD_PREFIX = 2ull << 62, SCD_MASK = (1ull << 62) - 1ull;
-
 // ------------------------------------------------------------------------------------ SH colour
 // element (k, ch) of one Gaussian's SH block lives at sh[(k*3 + ch) * st]: st = 1 for the reference's
 // (P,M,3) layout, st = P for the coefficient-major layout (E3_FLAG_SH_PLANAR, coalesced across lanes)
@@ -519,8 +516,10 @@ __device__ __forceinline__ void bin_store_runs(BinTables& T, int lane, bool mine
     if (mine) run_sorted[s] = make_uint2(out_base + inc - c, c);
 }
 
-// Two-pass form (the operator: the binning buffers are allocated between the passes, with the exact count): EMIT=false
-// counts the kept items per wave (-> inclusive scan -> total instance count I), EMIT=true replays the walk and writes.
+// Two passes: EMIT=false counts the kept items per wave (-> inclusive scan -> total instance count I), EMIT=true replays
+// the walk and writes.  (A single launch -- gather once, count, chain the counts across the workgroups with decoupled
+// look-back, emit from the tables still in LDS -- was measured slower: the chain serialises the workgroups,
+// profiles/EXPERIMENTS.md.)
 template <bool EMIT>
 __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift, int nviews, int ntiles,
                                                               const uint32_t* __restrict__ order,
@@ -561,95 +560,6 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     }
 }
 
-// Single-launch form (a forward whose binning buffers were sized BEFORE the count is known,
-// e3dgs_rasterize_forward_multi_capacity): the records are gathered ONCE -- that gather, 48 bytes at a random address per
-// splat, is what bounds a binning pass -- the wave walks its candidates to count them, the workgroups chain their counts
-// with decoupled look-back (descriptors as in scan_chained_kernel: {status, sum} in one 64-bit word, logical workgroup
-// ids from an atomic ticket so that a workgroup only ever waits for workgroups that have started), and the wave walks
-// the candidates again -- tables still in LDS -- to emit.  The last active workgroup publishes the instance count
-// (device word for the kernels behind, mapped host word for the caller).  A wave whose items would not fit the capacity
-// writes nothing: the count then exceeds the capacity and everything behind treats the forward as empty.
-__global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_fused_kernel(int P, int gshift, int nviews, int ntiles,
-                                                                    const uint32_t* __restrict__ order,
-                                                                    const uint32_t* __restrict__ nvis,
-                                                                    const uint2* __restrict__ rect, int packed_rect,
-                                                                    const float4* __restrict__ rec, int gx, int cull,
-                                                                    unsigned long long* desc /* nblocks + 1, zeroed */,
-                                                                    unsigned nblocks, void* __restrict__ keys, int keys16,
-                                                                    uint32_t* __restrict__ emit_gid,
-                                                                    uint2* __restrict__ run_sorted,
-                                                                    uint8_t* __restrict__ touched,
-                                                                    uint32_t* __restrict__ total_dev,
-                                                                    volatile int* total_host, uint32_t capacity) {
-    __shared__ BinTables tabs[BIN_WAVES];
-    __shared__ uint32_t s_bid, s_excl, s_cnt[BIN_WAVES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_bid = (uint32_t)atomicAdd(desc + nblocks, 1ull);
-    __syncthreads();
-    const uint32_t bid = s_bid;
-    const int nv = (int)__builtin_amdgcn_readfirstlane(*nvis);
-    const int per_block = BIN_WAVES << gshift;                   // splats per workgroup
-    const int first = (int)bid * per_block;
-    if (nv <= 0) {                                               // nothing visible at all: the count is 0
-        if (bid == 0 && threadIdx.x == 0) {
-            *total_dev = 0u;
-            if (total_host) { *total_host = 0; __threadfence_system(); }
-        }
-        return;
-    }
-    if (first >= nv) return;                                     // (workgroups behind the last splat: nobody looks back at them)
-    const int gw = (int)bid * BIN_WAVES + wave;
-    const int s = (gw << gshift) + lane;
-    const bool mine = lane < (1 << gshift) && s < nv;
-    BinTables& T = tabs[wave];
-    const uint32_t total = bin_load_tables(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull);
-    const uint32_t count = bin_walk<false>(T, lane, total, gx, cull, 0u, nullptr, 0, nullptr, nullptr);
-    if (lane == 0) s_cnt[wave] = count;
-    __syncthreads();
-    if (wave == 0) {
-        const uint32_t agg = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (lane == 0)
-            __hip_atomic_store(desc + bid, (bid == 0 ? SCD_PREFIX : SCD_AGG) | (unsigned long long)agg, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        int p = (int)bid - 1;                       // lane l looks at workgroup p - l
-        while (p >= 0) {
-            const int idx = p - lane;
-            const unsigned long long d = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                  : SCD_PREFIX;
-            const uint32_t st = (uint32_t)(d >> 62);
-            const unsigned long long ready = __ballot(st != 0u), pre = __ballot(st == 2u);
-            const int lead = (~ready) ? __builtin_ctzll(~ready) : 64;
-            const int firstpre = pre ? __builtin_ctzll(pre) : 64;
-            const int use = firstpre < lead ? firstpre + 1 : lead;
-            uint32_t c = lane < use ? (uint32_t)(d & SCD_MASK) : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            excl += c;
-            if (firstpre < lead) break;
-            p -= use;
-            if (use == 0) __builtin_amdgcn_s_sleep(1);
-        }
-        if (lane == 0) {
-            if (bid != 0)
-                __hip_atomic_store(desc + bid, SCD_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            s_excl = excl;
-            if (first + per_block >= nv) {          // the last workgroup with a splat: the grand total
-                *total_dev = excl + agg;
-                if (total_host) { *total_host = (int)(excl + agg); __threadfence_system(); }
-            }
-        }
-    }
-    __syncthreads();
-    uint32_t out_base = s_excl;
-    for (int w = 0; w < wave; ++w) out_base += s_cnt[w];
-    out_base = __builtin_amdgcn_readfirstlane(out_base);
-    if (out_base + count > capacity) return;                     // (would not fit: see above)
-    bin_walk<true>(T, lane, total, gx, cull, out_base, keys, keys16, emit_gid, touched);
-    bin_store_runs(T, lane, mine, s, out_base, run_sorted);
-}
-
 // After the stable tile sort the [start, end) of each tile comes out of the sort itself (scan_sort.hip: the last
 // pass of a two-pass sort derives the ranges from its scanned histogram).  The sort moved (tile id, emission index)
 // pairs; the compositing kernels translate emission index -> Gaussian id themselves (`emit_gid`, a small L2-resident
@@ -679,21 +589,9 @@ __device__ __forceinline__ uint2 normalise_empty_range(uint2* __restrict__ range
     return r;
 }
 
-// Longest-first deals tile rank r to wave slot r: the SIMD that gets rank s also gets ranks s + L, s + 2L, ... (L = one
-// wave per SIMD of the chip), always the heaviest of its layer.  Reversing every other layer ("snake") evens the sums
-// out, which matters when the launch is only one or two layers deep (small frames: all waves start at t = 0 and the
-// kernel takes as long as its most loaded SIMD).  snake = L, 0 = plain longest-first.
-__device__ __forceinline__ uint32_t snake_pos(uint32_t pos, uint32_t n, uint32_t snake) {
-    if (snake == 0u) return pos;
-    const uint32_t layer = pos / snake, first = layer * snake;
-    if ((layer & 1u) == 0u) return pos;
-    const uint32_t len = n - first < snake ? n - first : snake;
-    return first + (len - 1u - (pos - first));
-}
-
 __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ work,
-                                                          uint32_t* __restrict__ order, uint32_t snake) {
+                                                          uint32_t* __restrict__ order) {
     auto key = [&](int t) -> uint32_t { if (work) return work[t]; uint2 r = ranges[t]; return r.y - r.x; };
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
@@ -725,7 +623,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __r
     __syncthreads();
     for (int t = tid; t < ntiles; t += 1024) {
         uint32_t pos = atomicAdd(&hist[1023u - min(1023u, key(t) / width)], 1u);
-        order[snake_pos(pos, (uint32_t)ntiles, snake)] = (uint32_t)t;
+        order[pos] = (uint32_t)t;
     }
 }
 
@@ -735,7 +633,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, uint2* __r
 constexpr int ORDER_ITEMS = 32;
 __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, uint2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ work,
-                                                              uint32_t* __restrict__ order, uint32_t snake) {
+                                                              uint32_t* __restrict__ order) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t smax;
@@ -797,7 +695,7 @@ __global__ __launch_bounds__(1024) void tile_order_reg_kernel(int ntiles, uint2*
         const int t = tid + i * 1024;
         if (t < ntiles) {
             uint32_t pos = atomicAdd(&hist[key[i]], 1u);
-            order[snake_pos(pos, (uint32_t)ntiles, snake)] = (uint32_t)t;
+            order[pos] = (uint32_t)t;
         }
     }
 }
@@ -863,10 +761,6 @@ __global__ __launch_bounds__(1024) void tile_order_xcd_kernel(int ntiles, int ns
     }
 }
 
-static uint32_t lpt_snake() {
-    static const uint32_t v = [] { const char* e = getenv("E3DGS_LPT_SNAKE"); return e ? (uint32_t)atoi(e) : 0u; }();
-    return v;
-}
 static int xcd_block() {
     static const int v = [] { const char* e = getenv("E3DGS_XCD_BLOCK"); return e ? atoi(e) : 0; }();
     return v;
@@ -891,9 +785,9 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
         }
     }
     if (ntiles <= ORDER_ITEMS * 1024)
-        tile_order_reg_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order, lpt_snake());
+        tile_order_reg_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
     else
-        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order, lpt_snake());
+        tile_order_kernel<<<dim3(1), dim3(1024), 0, s>>>(ntiles, ranges, work, order);
     return ntiles;
 }
 
@@ -1120,7 +1014,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                           const ViewBatch& views, int P, int D, int M, int W, int H, const float* means3D,
                           const float* shs, const float* colors, const float* opac, const float* scales,
                           float scale_modifier, const float* rots, const float* cov_pre, int* radii, int debug,
-                          int flags, int* count_host, hipStream_t s, int skip_count) {
+                          int flags, int* count_host, hipStream_t s) {
     const ViewSet vs = make_view_set(views, W, H, scale_modifier);
     const int nv = vs.n;
     const int ntiles = vs.v[0].gx * vs.v[0].gy;
@@ -1152,7 +1046,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                                                             : preprocess_kernel<4, false>);
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                            geom.offsets, bin_scan_desc, (int)bin_desc_words(Q));
+                                            geom.offsets, bin_scan_desc, (int)scan_desc_words(Q));
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
@@ -1166,7 +1060,6 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0 || keys_sorted != geom.key0)
             return e3_fail(hipErrorUnknown, "internal: depth order not in ord0 / key0");
-        if (skip_count) return 0;       // (pre-sized binning buffers: bin_fused_kernel counts and emits in `finish`)
         const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
         const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
@@ -1196,8 +1089,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
 // word as usual, repeats the call with larger buffers.
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc, int count_on_device,
-                           int* count_host_mapped) {
+                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc, int count_on_device) {
     const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
     const int tiles_per_view = gx * gy;
     const int ntiles = tiles_per_view * nviews;
@@ -1225,18 +1117,10 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         const uint32_t* count_dev = count_on_device ? geom.offsets + nwaves : nullptr;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
-        if (count_on_device == 2)
-            // one launch: count, chain the counts across the workgroups, emit (records gathered once); the count goes to
-            // geom.offsets[nwaves] for the kernels behind and to the caller's mapped host word
-            bin_fused_kernel<<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>(
-                (int)Q, gshift, nviews, tiles_per_view, geom.ord0, geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
-                g_tile_cull, reinterpret_cast<unsigned long long*>(geom.scratch + sort_scratch_words(Q)), bb, k0, keys16,
-                bin.emit_gid, geom.run, bin.touched, geom.offsets + nwaves, count_host_mapped, I);
-        else
-            bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
-                                                                        geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec,
-                                                                        gx, g_tile_cull, geom.offsets, nullptr, k0, keys16,
-                                                                        bin.emit_gid, geom.run, bin.touched, count_dev, I);
+        bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
+                                                                    geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
+                                                                    g_tile_cull, geom.offsets, nullptr, k0, keys16,
+                                                                    bin.emit_gid, geom.run, bin.touched, count_dev, I);
         }
         KERNEL_OK("bin emit");
         uint32_t* vs;
