@@ -99,7 +99,7 @@ def lib():
     L.e3dgs_event_loss_scratch_bytes.restype = C.c_size_t
     L.e3dgs_event_loss_scratch_bytes.argtypes = [C.c_int, C.c_int]
     L.e3dgs_event_loss.restype = C.c_int
-    L.e3dgs_event_loss.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 4 + [_cp, _vp]
+    L.e3dgs_event_loss.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 5 + [_cp, _vp]
     L.e3dgs_ssim_scratch_bytes.restype = C.c_size_t
     L.e3dgs_ssim_scratch_bytes.argtypes = [C.c_int] * 3
     L.e3dgs_ssim.restype = C.c_int

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_reduce_kernel(
 // scalars (float[8]): 0 loss, 1 dL/dc, 2 rho, 3 L1 event, 4 L1 intensity, 5 L1 blur, 6 kE, 7 kI
 __global__ __launch_bounds__(EV_THREADS) void event_finalize_kernel(int nblocks, size_t HW, const double* __restrict__ partials,
                                                                     const float* __restrict__ c_ptr, int has_blur,
-                                                                    float* __restrict__ scalars) {
+                                                                    float* __restrict__ scalars, float* __restrict__ dc_out) {
     // one workgroup (a single wave walked the ~2 000 partial rows in 12 us of dependent loads); fixed order: deterministic
     __shared__ double sfin[EV_NSUM][EV_THREADS / WAVE];
     double acc[EV_NSUM] = {0, 0, 0, 0, 0};
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_finalize_kernel(int nblocks,
         if (has_blur) { loss = 0.5 * loss + 0.5 * L1B; outer = 0.5; }
         scalars[0] = (float)loss;
         scalars[1] = (float)(-outer * 0.9 * rho * (acc[2] / n) / c);
+        if (dc_out) *dc_out = scalars[1];      // (e.g. the threshold's slot of a flat gradient buffer: no copy kernel)
         scalars[2] = (float)rho; scalars[3] = (float)L1E; scalars[4] = (float)L1I; scalars[5] = (float)L1B;
         scalars[6] = (float)(outer * 0.9 * rho / n);
         scalars[7] = (float)(outer * 0.1 * (1.0 - rho) / (3.0 * n));
@@ -421,14 +422,15 @@ size_t e3_event_scratch_bytes(int W, int H) { return (size_t)ev_blocks((size_t)W
 
 int e3_event_loss_impl(int W, int H, const float* image, const float* now, const float* next, const float* gt_int,
                        const float* gt_now, const float* gt_next, const float* gt_blur, const float* c, float gt_c,
-                       float* d_image, float* d_now, float* d_next, float* scalars, char* scratch, hipStream_t s) {
+                       float* d_image, float* d_now, float* d_next, float* scalars, char* scratch, hipStream_t s,
+                       float* dc_out) {
     size_t HW = (size_t)W * H;
     if (HW == 0) return 0;
     int nb = ev_blocks(HW);
     double* partials = reinterpret_cast<double*>(scratch);
     event_reduce_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
                                                               gt_c, partials);
-    event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars);
+    event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars, dc_out);
     event_grad_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
                                                             gt_c, scalars, d_image, d_now, d_next);
     hipError_t e = hipGetLastError();

@@ -51,7 +51,7 @@ size_t e3_knn_scratch_bytes(int);
 int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
 size_t e3_event_scratch_bytes(int, int);
 int e3_event_loss_impl(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
-                       const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t);
+                       const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t, float*);
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_segments_impl(size_t, float*, const float*, float*, float*, int, const size_t*, const float*, const float*, float,
@@ -444,10 +444,10 @@ size_t e3dgs_event_loss_scratch_bytes(int width, int height) { return e3_event_s
 int e3dgs_event_loss(int width, int height, const float* image, const float* img_now, const float* img_next,
                      const float* gt_int, const float* gt_now, const float* gt_next, const float* gt_blur,
                      const float* c, float gt_c, float* d_image, float* d_now, float* d_next, float* scalars_out,
-                     char* scratch, void* stream) {
+                     float* dc_out, char* scratch, void* stream) {
     g_err[0] = 0;
     return e3_event_loss_impl(width, height, image, img_now, img_next, gt_int, gt_now, gt_next, gt_blur, c, gt_c,
-                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream);
+                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream, dc_out);
 }
 
 size_t e3dgs_ssim_scratch_bytes(int channels, int height, int width) { return e3_ssim_scratch_bytes(channels, height, width); }

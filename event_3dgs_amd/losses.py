@@ -25,7 +25,7 @@ class _EventLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = L.e3dgs_event_loss(W, H, _lib.ptr(image_c), _lib.ptr(now_c), _lib.ptr(next_c), _lib.ptr(gi),
                                     _lib.ptr(gn), _lib.ptr(gx), _lib.ptr(gb), _lib.ptr(c_dev), float(gt_c),
-                                    _lib.ptr(d_image), _lib.ptr(d_now), _lib.ptr(d_next), _lib.ptr(scalars),
+                                    _lib.ptr(d_image), _lib.ptr(d_now), _lib.ptr(d_next), _lib.ptr(scalars), None,
                                     _lib.ptr(scratch), _lib.current_stream())
         _lib.check(rc, "e3dgs_event_loss")
         ctx.save_for_backward(d_image, d_now, d_next, scalars)
@@ -40,10 +40,11 @@ class _EventLoss(torch.autograd.Function):
                 None)
 
 
-def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17, out=None):
+def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17, out=None, dc_out=None):
     """Direct call of e3dgs_event_loss (no autograd).  Returns (scalars[8], d_image, d_now, d_next):
     scalars[0] = loss, [1] = dL/dc, [2] = rho, [3..5] = L1 event / intensity / blur.  `out` may carry
-    preallocated (scalars, d_image, d_now, d_next, scratch) tensors to reuse across steps."""
+    preallocated (scalars, d_image, d_now, d_next, scratch) tensors to reuse across steps; `dc_out`: a one-element
+    device tensor that also receives dL/dc (the threshold's slot of a flat gradient buffer)."""
     L = _lib.lib()
     dev = image.device
     _, H, W = image.shape
@@ -59,7 +60,7 @@ def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur
         rc = L.e3dgs_event_loss(W, H, _lib.ptr(image), _lib.ptr(img_now), _lib.ptr(img_next), _lib.ptr(gt_int),
                                 _lib.ptr(gt_now), _lib.ptr(gt_next), _lib.ptr(gt_blur), _lib.ptr(c), float(gt_c),
                                 _lib.ptr(d_image), _lib.ptr(d_now), _lib.ptr(d_next), _lib.ptr(scalars),
-                                _lib.ptr(scratch), _lib.current_stream())
+                                _lib.ptr(dc_out), _lib.ptr(scratch), _lib.current_stream())
     _lib.check(rc, "e3dgs_event_loss")
     return scalars, d_image, d_now, d_next
 

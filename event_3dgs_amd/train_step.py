@@ -344,7 +344,7 @@ class EventTrainer:
         scalars = self.compute_gradients(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur,
                                          sh_via_colour=self.sh_via_colour and not self.overlap_features)
         self.apply_update(sync_grads)
-        return scalars.clone()        # compute_gradients' result lives in a buffer the next step overwrites
+        return scalars                # (one of two alternating buffers: valid until the step after the next one)
 
     def apply_update(self, sync_grads=True, skip=()):
         """Gradient averaging over the ranks (if any) + Adam (train.py:210-212,330-332) for the iteration whose gradients
@@ -523,7 +523,6 @@ class EventTrainer:
                 break
         else:
             raise RuntimeError("the instance count kept outgrowing the binning capacity")
-        self.c_grad.copy_(scalars[1:2])
         self.last_radii = raw["radii"][0]
         self.last_scalars = scalars
         return scalars
@@ -534,12 +533,16 @@ class EventTrainer:
         imgs = raw["color"]
         key = ("event",) + tuple(imgs.shape)
         if self._loss_bufs is None or self._loss_bufs[0] != key:
-            self._loss_bufs = (key, torch.empty(8, dtype=torch.float32, device=self.device), torch.empty_like(imgs),
+            # (two scalar blocks used alternately: the block an iteration returns stays intact during the next one)
+            self._loss_bufs = (key, torch.empty(2, 8, dtype=torch.float32, device=self.device), torch.empty_like(imgs),
                                torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(imgs.shape[3], imgs.shape[2]),
                                            dtype=torch.uint8, device=self.device))
-        _, sc, dpix, scratch = self._loss_bufs
+        _, sc2, dpix, scratch = self._loss_bufs
+        self._loss_flip = 1 - getattr(self, "_loss_flip", 0)
+        sc = sc2[self._loss_flip]
+        # (dL/dc goes straight into the threshold's slot of the flat gradient buffer: no copy kernel)
         scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[1], imgs[2], self.c, gt_int, gt_now, gt_next, gt_blur,
-                                                 out=(sc, dpix[0], dpix[1], dpix[2], scratch))     # train.py:165-203
+                                                 out=(sc, dpix[0], dpix[1], dpix[2], scratch), dc_out=self.c_grad)     # train.py:165-203
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])

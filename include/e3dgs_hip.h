@@ -397,6 +397,8 @@ int e3dgs_event_loss(
     float gt_c,             /* 0.17 in the reference */
     float* d_image, float* d_now, float* d_next, /* (3,H,W) grads, overwritten */
     float* scalars_out,     /* (8) device */
+    float* dc_out,          /* NULL, or a device word that also receives dL/dc (e.g. the threshold's slot of a flat
+                               gradient buffer: saves the caller a copy kernel per iteration) */
     char* scratch,
     void* stream);
 

@@ -101,19 +101,34 @@ def collect(tag, head):
                 f.write(f"{r['Name'].split('(')[0][:64]:64s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.1f} "
                         f"min_us={float(r['MinNs'])/1e3:9.1f} tot_ms={float(r['TotalDurationNs'])/1e6:8.2f} "
                         f"{100*float(r['TotalDurationNs'])/tot:5.1f}%\n")
-    # per-dispatch durations, max-size launches only (= the 3-view launches of the benchmark iteration)
+    # per-dispatch durations of ONE training iteration: the dispatches between two consecutive render_bwd_kernel launches
+    # (an interior window of the timed steps; the ground-truth renders in front and the statistics renders behind the
+    # training loop launch the per-Gaussian kernels with the same grids and must not be counted)
     durations = {}
     for f in files:
         if f.endswith("kernel_trace.csv"):
-            by = collections.defaultdict(list)
-            for r in csv.DictReader(open(f)):
-                g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))
-                by[kname(r)].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-            for k, v in by.items():
-                gmax = max(g for g, _ in v)
-                d = [t for g, t in v if g == gmax]
-                durations[k] = {"avg_us": round(sum(d) / len(d), 2), "launches": len(d), "grid": gmax}
-    summary["kernel_us_largest_launch"] = durations
+            rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+            marks = [i for i, r in enumerate(rows) if kname(r) == "render_bwd_kernel"]
+            windows = [rows[marks[j] + 1:marks[j + 1] + 1] for j in range(1, len(marks) - 1)]       # interior iterations
+            if not windows:
+                continue
+            per = collections.defaultdict(list)             # kernel -> [(launches, total us)] per window
+            for w in windows:
+                acc = collections.defaultdict(lambda: [0, 0.0])
+                for r in w:
+                    a = acc[kname(r)]
+                    a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                for k, a in acc.items():
+                    per[k].append(tuple(a))
+            for k, v in per.items():
+                if len(v) * 2 < len(windows):
+                    continue                                 # not part of every iteration
+                n_l = sorted(x[0] for x in v)[len(v) // 2]
+                us = [x[1] for x in v if x[0] == n_l]
+                durations[k] = {"launches_per_iteration": n_l, "us_per_iteration": round(sum(us) / len(us), 2)}
+            summary["iterations_in_window_stats"] = len(windows)
+            summary["iteration_us_sum_of_kernels"] = round(sum(d["us_per_iteration"] for d in durations.values()), 1)
+    summary["kernels_per_iteration"] = durations
     # ---- 2./3. HBM-side traffic of every kernel
     fetch = max_per_kernel(rocprof(out, "fetch", ["--pmc", "FETCH_SIZE"]), "counter_collection.csv", "FETCH_SIZE")
     write = max_per_kernel(rocprof(out, "write", ["--pmc", "WRITE_SIZE"]), "counter_collection.csv", "WRITE_SIZE")
@@ -129,16 +144,18 @@ def collect(tag, head):
     # bytes per ITERATION and bench.py stage: per kernel, bytes of its largest launch x its launches per iteration (the
     # exclusive chained scans serve both sorts -- four launches per iteration belong to the depth sort, two to the tile
     # sort; their few MB are booked at the size of the largest one)
-    n_iter = max(durations.get("render_bwd_kernel", {}).get("launches", 0), 1)
     stage = {}
     for name, prefixes in STAGES.items():
-        ks = [k for k in traffic if any(k.startswith(p) for p in prefixes)]
-        b = sum(traffic[k]["hbm_bytes_per_launch"] * durations.get(k, {}).get("launches", n_iter) / n_iter for k in ks)
-        scan = traffic.get("void scan_chained_kernel<false>", {}).get("hbm_bytes_per_launch", 0)
-        b += {"sort_depth": 4, "sort_tile": 2}.get(name, 0) * scan
-        stage[name] = {"bytes_per_iteration": int(b), "kernels": ks}
+        ks = [k for k in traffic if any(k.startswith(p) for p in prefixes) and k in durations]
+        b = sum(traffic[k]["hbm_bytes_per_launch"] * durations[k]["launches_per_iteration"] for k in ks)
+        us = sum(durations[k]["us_per_iteration"] for k in ks)
+        scan = "void scan_chained_kernel<false>"
+        if scan in durations and name in ("sort_depth", "sort_tile"):
+            share = {"sort_depth": 4, "sort_tile": 2}[name] / max(durations[scan]["launches_per_iteration"], 1)
+            b += traffic.get(scan, {}).get("hbm_bytes_per_launch", 0) * durations[scan]["launches_per_iteration"] * share
+            us += durations[scan]["us_per_iteration"] * share
+        stage[name] = {"bytes_per_iteration": int(b), "kernel_us_per_iteration": round(us, 1), "kernels": ks}
     summary["stages"] = stage
-    summary["iterations_profiled"] = n_iter
     # ---- 4. instruction mix of the compositing kernels
     mix = collections.defaultdict(dict)
     for i, ctrs in enumerate(SQ_PASSES):
