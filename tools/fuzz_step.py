@@ -61,7 +61,10 @@ def check(seed):
     # visible at the 1e-3 level, with hundreds it is not.
     # On a black background ln(Y + 1e-8) amplifies any difference at the dark pixels by up to 1e8 (the reference's loss
     # is that ill-conditioned there), so only gross errors are flagged for bg = 0.
-    loose = N < 500 or bgv == 0.0
+    # L1's gradient is sign(x): on a frame of a few thousand pixels, three pixel-channels whose |image - gt| is below the
+    # 1e-7 by which the two paths' images differ flip their sign and move every gradient by 2 % (seed 817: 21 x 115, images
+    # equal to 1.2e-7, no radius or threshold flip) -- small frames are compared loosely too.
+    loose = N < 500 or bgv == 0.0 or W * H < 6000
     sa0, lb0 = float(sa[0].detach()), float(lb.detach())
     if not math.isfinite(sa0) or abs(sa0 - lb0) > (2e-3 if loose else 2e-4) * max(abs(lb0), 1e-6):
         problems.append("loss %.7g vs %.7g" % (sa0, lb0))
