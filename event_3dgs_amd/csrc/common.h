@@ -184,6 +184,8 @@ struct GeomState {
     uint32_t* offsets; // inclusive scan of `tiles`
     uint32_t* scratch; // sort/scan scratch
     uint32_t* total;   // [1] instance count (device copy)
+    float4* binrec;    // 2 x float4 per DEPTH-SORTED position: the bin record the count pass derived (centre, conic,
+                       // threshold, candidate box), read back -- coalesced -- by the emission pass
     uint32_t* nvis;    // [1] splats the projection kept = length of the depth-sorted order (key0 / ord0): the depth sort
                        // drops the culled ones in its first pass, and every kernel behind it reads its count here
     static size_t required(size_t P) {
@@ -207,6 +209,7 @@ struct GeomState {
         g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_desc_words(n) + 64);
         g.total = carve<uint32_t>(p, 64);
         g.nvis = g.total + 16;
+        g.binrec = carve<float4>(p, 2 * n);
         return g;
     }
 };

@@ -371,12 +371,27 @@ struct BinTables {
 
 // Gathers the records of the wave's splats (depth-sorted positions s of `order`), derives the candidate rectangles and
 // fills the wave's tables.  Returns the number of candidate (splat, tile) items of the wave (wave-uniform).
+// MODE 0: gather and derive.  MODE 1 (count pass): also store the derived 32-byte bin record at the splat's SORTED position
+// (`binrec`, coalesced).  MODE 2 (emission pass): load that record instead of gathering -- the gather of a 48-byte record
+// at a random address per splat (1.25 lines of 128 bytes) is what bounds a binning pass, and the emission pass repeats
+// the count pass's walk over exactly the same splats.
+template <int MODE>
 __device__ __forceinline__ uint32_t bin_load_tables(BinTables& T, int lane, bool mine, int s, int nviews, int ntiles,
                                                     const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
-                                                    int packed_rect, const float4* __restrict__ rec, int cull) {
+                                                    int packed_rect, const float4* __restrict__ rec, int cull,
+                                                    float4* __restrict__ binrec) {
     uint32_t n = 0, g = 0;
     float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
-    if (mine) {
+    if (MODE == 2) {
+        if (mine) {
+            g = order[s];
+            a = binrec[2 * (size_t)s];
+            b = binrec[2 * (size_t)s + 1];
+            const uint32_t wh = __float_as_uint(b.w);
+            n = (wh & 0xFFFFu) * (wh >> 16);
+            b.w = __uint_as_float(wh & 0xFFFFu);
+        }
+    } else if (mine) {
         g = order[s];
         // ONE gather of the 48-byte record delivers the rectangle too (8 bits per bound in its spare word, grids up to
         // 255 x 255 tiles; the 16-bit array otherwise): the rectangle array used to cost a second 128-byte line per
@@ -432,6 +447,10 @@ __device__ __forceinline__ uint32_t bin_load_tables(BinTables& T, int lane, bool
                 }
             }
             b = make_float4(t.x, thr, __uint_as_float(xy0), __uint_as_float(w));
+        }
+        if (MODE == 1) {
+            binrec[2 * (size_t)s] = a;
+            binrec[2 * (size_t)s + 1] = make_float4(b.x, b.y, b.z, __uint_as_float(n ? (w | (h << 16)) : 0u));
         }
     }
     uint32_t incl = n;
@@ -532,7 +551,8 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
                                                               uint32_t* __restrict__ emit_gid,
                                                               uint2* __restrict__ run_sorted,
                                                               uint8_t* __restrict__ touched,
-                                                              const uint32_t* __restrict__ total_dev, uint32_t capacity) {
+                                                              const uint32_t* __restrict__ total_dev, uint32_t capacity,
+                                                              float4* __restrict__ binrec /* or null: both passes gather */) {
     __shared__ BinTables tabs[BIN_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * BIN_WAVES + wave;
@@ -550,7 +570,9 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     }
     const bool mine = lane < (1 << gshift) && s < nv;
     BinTables& T = tabs[wave];
-    const uint32_t total = bin_load_tables(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull);
+    uint32_t total;
+    if (!binrec) total = bin_load_tables<0>(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull, nullptr);
+    else total = bin_load_tables<EMIT ? 2 : 1>(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull, binrec);
     const uint32_t out_base = EMIT ? __builtin_amdgcn_readfirstlane(wave_offsets[gw]) : 0u;
     const uint32_t count = bin_walk<EMIT>(T, lane, total, gx, cull, out_base, keys, keys16, emit_gid, touched);
     if (!EMIT) {
@@ -761,6 +783,10 @@ __global__ __launch_bounds__(1024) void tile_order_xcd_kernel(int ntiles, int ns
     }
 }
 
+static bool bin_handoff() {      // E3DGS_BIN_HANDOFF=0: both binning passes gather the splat records (A/B switch)
+    static const bool v = [] { const char* e = getenv("E3DGS_BIN_HANDOFF"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static int xcd_block() {
     static const int v = [] { const char* e = getenv("E3DGS_XCD_BLOCK"); return e ? atoi(e) : 0; }();
     return v;
@@ -1068,7 +1094,8 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, geom.nvis,
                                                                      geom.rect, vs.v[0].gx <= 255 && vs.v[0].gy <= 255,
                                                                      geom.rec, vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
-                                                                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0u);
+                                                                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0u,
+                                                                     bin_handoff() ? geom.binrec : nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
         const int rc = launch_scan_chained_u32(geom.tiles, geom.offsets + 1, (size_t)nwaves, bin_scan_desc, true, s,
                                                (flags & E3_FLAG_COUNT_MAPPED) ? count_host : nullptr);
@@ -1120,7 +1147,8 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
                                                                     geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
                                                                     g_tile_cull, geom.offsets, nullptr, k0, keys16,
-                                                                    bin.emit_gid, geom.run, bin.touched, count_dev, I);
+                                                                    bin.emit_gid, geom.run, bin.touched, count_dev, I,
+                                                                    bin_handoff() ? geom.binrec : nullptr);
         }
         KERNEL_OK("bin emit");
         uint32_t* vs;
