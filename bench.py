@@ -240,9 +240,11 @@ def main():
         if name in stages:
             stages[name]["ms_per_iter"] = round(ms / n_iter_prof, 4) if name != dom_name or not timed[dom_name][1] else \
                 round(timed[dom_name][0] / max(timed[dom_name][1], 1), 4)
+    for st_ in stages.values():
+        st_.setdefault("ms_per_iter", st_["avg_ms"])                 # (the optimizer: one event pair per iteration)
     if prof and not prof_stale:
         for name, rec in prof.get("stages", {}).items():
-            if name in stages and rec.get("bytes_per_iteration"):
+            if name in stages and rec.get("bytes_per_iteration") and stages[name].get("ms_per_iter"):
                 stages[name]["pmc_GB_per_iter"] = round(rec["bytes_per_iteration"] / 1e9, 4)
                 stages[name]["pmc_GBps"] = round(rec["bytes_per_iteration"] / 1e9 / (stages[name]["ms_per_iter"] / 1e3), 1)
     dominant = dom_name if dom_name in stages else None
