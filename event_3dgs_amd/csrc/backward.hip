@@ -971,8 +971,11 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int P, int nranks, i
 // streaming pass that reads 3 colour-gradient floats per (Gaussian, view) instead of writing and re-reading 48
 // gradients.  blockIdx.y selects four coefficients (12 elements): a workgroup streams 36 planes of the
 // coefficient-major arrays (all 144 at once ran at 3.9 TB/s: too many concurrent DRAM streams), the moments and
-// parameters are requested before the gradient is computed, and the colour gradients re-read by the four y-slices come
+// parameters are requested before the gradient is computed, and the colour gradients re-read by the y-slices come
 // from L2 / Infinity Cache.  Same arithmetic as sh_grad_views_kernel + adam_segments_kernel: bit-identical results.
+#ifndef E3_SH_SLICE
+#define E3_SH_SLICE 2      // SH coefficients (x 3 channels) per workgroup slice: 18 streams per thread (1 / 2 / 4 / 8: 0.329 / 0.303 / 0.318 / 0.388 ms for the optimizer stage)
+#endif
 struct ShAdam { float* m; float* v; float ss_dc, ss_rest, bc2s, b1, b2, eps; };
 __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
                                                             const float* __restrict__ means,
@@ -980,16 +983,17 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
                                                             float scale, float* __restrict__ sh, int planar, ShAdam ad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const int k0 = 4 * (int)blockIdx.y;                  // this slice: coefficients k0 .. k0 + 3
+    constexpr int CS = E3_SH_SLICE, NE = 3 * CS;
+    const int k0 = CS * (int)blockIdx.y;                 // this slice: coefficients k0 .. k0 + CS - 1
     const size_t st = planar ? (size_t)P : (size_t)1;
     const size_t e0 = (planar ? (size_t)i : (size_t)i * M * 3) + (size_t)(3 * k0) * st;
-    float m0[12], v0[12], p0[12];
+    float m0[NE], v0[NE], p0[NE];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) { m0[j] = ad.m[e0 + j * st]; v0[j] = ad.v[e0 + j * st]; p0[j] = sh[e0 + j * st]; }
+    for (int j = 0; j < NE; ++j) { m0[j] = ad.m[e0 + j * st]; v0[j] = ad.v[e0 + j * st]; p0[j] = sh[e0 + j * st]; }
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-    float acc[4][3];
+    float acc[CS][3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    for (int k = 0; k < CS; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
     const int nk = (D + 1) * (D + 1);
 #pragma unroll 1
     for (int r = 0; r < nranks; ++r) {
@@ -1004,7 +1008,7 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
             const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
             const float x = ox / len, y = oy / len, z = oz / len;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < CS; ++kk) {
                 if (k0 + kk < nk) {                                         // (uniform per workgroup)
                     float Y, Yx, Yy, Yz;
                     sh_basis(k0 + kk, x, y, z, Y, Yx, Yy, Yz);
@@ -1014,7 +1018,7 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
         }
     }
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
+    for (int j = 0; j < NE; ++j) {
         const float g = (k0 + j / 3 < nk) ? acc[j / 3][j % 3] * scale : 0.0f;     // inactive degrees: zero gradient, moments decay
         const float mi = m0[j] + (1.0f - ad.b1) * (g - m0[j]);
         const float vi = v0[j] * ad.b2 + (1.0f - ad.b2) * g * g;
@@ -1031,7 +1035,7 @@ int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
     ShAdam ad;
     ad.m = exp_avg; ad.v = exp_avg_sq; ad.ss_dc = (float)((double)lr_dc / bc1); ad.ss_rest = (float)((double)lr_rest / bc1);
     ad.bc2s = (float)sqrt(bc2); ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
-    sh_adam_views_kernel<<<dim3((P + 255) / 256, M / 4), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
+    sh_adam_views_kernel<<<dim3((P + 255) / 256, M / E3_SH_SLICE), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
                                                                            rank_stride, scale, sh,
                                                                            (flags & E3_FLAG_SH_PLANAR) != 0, ad);
     hipError_t e = hipGetLastError();

@@ -399,7 +399,7 @@ int e3dgs_sh_adam_from_colour(int P, int nranks, int views_per_rank, int D, int 
     g_err[0] = 0;
     if (P < 0 || nranks < 1 || views_per_rank < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || step < 1)
         return e3_fail(hipErrorInvalidValue, "bad sizes");
-    if (M % 4 != 0 || M > 64) return e3_fail(hipErrorInvalidValue, "M must be a multiple of 4 (the optimizer kernel works on four coefficients per slice)");
+    if (M % 2 != 0 || M > 64) return e3_fail(hipErrorInvalidValue, "M must be even (the optimizer kernel works on two coefficients per slice)");
     if (P > 0 && (!means3D || !packed || !sh || !exp_avg || !exp_avg_sq)) return e3_fail(hipErrorInvalidValue, "null pointer");
     if (rank_stride < (size_t)views_per_rank * ((size_t)P * 3 + 3))
         return e3_fail(hipErrorInvalidValue, "rank_stride smaller than one rank block");
