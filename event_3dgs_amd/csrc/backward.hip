@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int P, int nranks, i
 // The same rebuild fused with the optimizer step of the SH coefficients: the gradient never reaches memory -- it goes
 // straight into torch.optim.Adam's update (f_dc / f_rest learning rates, scene/gaussian_model.py:156-157).  One
 // streaming pass that reads 3 colour-gradient floats per (Gaussian, view) instead of writing and re-reading 48
-// gradients.  blockIdx.y selects four coefficients (12 elements): a workgroup streams 36 planes of the
+// gradients.  blockIdx.y selects E3_SH_SLICE coefficients (2: 6 elements): a workgroup streams 18 planes of the
 // coefficient-major arrays (all 144 at once ran at 3.9 TB/s: too many concurrent DRAM streams), the moments and
 // parameters are requested before the gradient is computed, and the colour gradients re-read by the y-slices come
 // from L2 / Infinity Cache.  Same arithmetic as sh_grad_views_kernel + adam_segments_kernel: bit-identical results.
