@@ -338,9 +338,11 @@ class EventTrainer:
 
     def step(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
         """One event iteration (train.py:97-332 without densification).  Returns the device scalars tensor of
-        the loss kernel ([0] = loss).  The three renders are ONE multi-view pass of the rasteriser (every kernel
-        of the pipeline runs once over the three cameras), forward and backward; one host wait per iteration
-        (the instance count)."""
+        the loss kernel ([0] = loss; one of two alternating buffers -- valid until the step after the next one).  The
+        three renders are ONE multi-view pass of the rasteriser (every kernel of the pipeline runs once over the three
+        cameras), forward and backward.  Nothing waits for the host: forward, loss and backward are enqueued back to back
+        with binning buffers sized from earlier instance counts; the host reads this iteration's count once the backward
+        is enqueued and only then enqueues the optimizer step (_count_fits)."""
         scalars = self.compute_gradients(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur,
                                          sh_via_colour=self.sh_via_colour and not self.overlap_features)
         self.apply_update(sync_grads)
