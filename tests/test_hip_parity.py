@@ -598,11 +598,12 @@ def test_backward_is_deterministic():
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("nviews,W,H", [(3, 150, 100), (2, 64, 48), (4, 96, 80)])
+@pytest.mark.parametrize("nviews,W,H", [(3, 150, 100), (2, 64, 48), (4, 96, 80), (3, 3840, 2160)])
 def test_multi_view_pass_against_oracle(nviews, W, H):
     """e3dgs_rasterize_forward_multi / _backward_multi (the three renders of an event iteration in one pass)
     against the C oracle run once per camera: every image and radii array bit-exact, summed gradients to
-    GRAD_TOL (what loss.backward() accumulates at train.py:211)."""
+    GRAD_TOL (what loss.backward() accumulates at train.py:211).  Three 4K frames are 97 200 tiles: tile ids beyond 16
+    bits, i.e. 32-bit keys and the three-pass tile sort whose ranges come from `tile_ranges_kernel`."""
     from event_3dgs_amd import rasterizer
     from event_3dgs_amd.cameras import orbit_camera
     from oracle import c_oracle
