@@ -442,8 +442,10 @@ def measure_dropin(params, cams, gts, bg, dev, L, iters=8):
     lum = lambda im: (0.4124 * im[0] + 0.35758 * im[1] + 0.1804 * im[2]).unsqueeze(0)      # utils/loss_utils.py:24-28
     ev = lambda a, b, cc: (torch.log(lum(b) + 1e-8) - torch.log(lum(a) + 1e-8)) / cc       # :234-249
 
+    python_sh = [True]
+
     def step():
-        imgs = [render(cam, pc, pipe, bg)["render"] for cam in cams]
+        imgs = [render(cam, pc, pipe, bg, force_python_sh=python_sh[0])["render"] for cam in cams]
         img_diff, gt = ev(imgs[1], imgs[2], c), ev(gts[1], gts[2], 0.17)
         loss1, loss2 = torch.abs(img_diff - gt).mean(), torch.abs(imgs[0] - gts[0]).mean()          # train.py:165-203
         mask = (gt != 0).to(imgs[0].dtype)
@@ -477,7 +479,19 @@ def measure_dropin(params, cams, gts, bg, dev, L, iters=8):
         L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
         ras += ms.value
     L.e3dgs_profile_enable(0)
-    return {"ms": round(1e3 * wall, 3), "per_s": round(1.0 / wall, 2), "host_enqueue_ms": round(1e3 * sorted(host)[1], 3),
+    # the same iteration with ONE line of the reference removed (gaussian_renderer/__init__.py:71, which forces the torch
+    # SH branch): SH evaluated inside the rasteriser, forward and backward, as upstream 3DGS does
+    python_sh[0] = False
+    pipe.convert_SHs_python = False
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    wall_sh = (time.perf_counter() - t0) / iters
+    return {"ms": round(1e3 * wall, 3), "ms_with_sh_in_the_rasteriser": round(1e3 * wall_sh, 3), "per_s": round(1.0 / wall, 2), "host_enqueue_ms": round(1e3 * sorted(host)[1], 3),
             "rasteriser_kernels_ms": round(ras / 2, 3), "torch_side_ms": round(1e3 * wall - ras / 2, 3),
             "native_extension": rasterizer.native_ext() is not None,
             "what": "3 x render() (torch SH + activations, GaussianRasterizer via _C_native) + torch loss "
