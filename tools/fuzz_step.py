@@ -74,7 +74,9 @@ def check(seed):
             problems.append("non-finite grad " + name)
             continue
         sc = float(np.linalg.norm(gb))
-        err = rel_l2(ga, gb) if sc > 1e-9 else float(np.abs(ga).max())
+        # (a group whose whole gradient is below 1e-6 is compared absolutely: seed 4149 -- one Gaussian with a saturated
+        # opacity, sigmoid = 1.0f in the kernel and 1 - 2^-24 in torch, gradient 0 vs -4e-8)
+        err = rel_l2(ga, gb) if sc > 1e-6 else float(np.abs(ga - gb).max())
         if err > (3e-2 if loose else 3e-3):
             problems.append("grad %s err %.3g (|ref| %.3g)" % (name, err, sc))
     cg, cr = float(a.c_grad), float(b.c_grad)
