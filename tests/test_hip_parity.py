@@ -337,6 +337,20 @@ def test_randomised_configurations_against_oracle(first):
         assert not problems, (desc, problems)
 
 
+def test_randomised_medium_size_configurations_against_oracle():
+    """tools/fuzz_medium.py: 20 k .. 400 k Gaussians, frames up to 2600 x 1500, trained- and init-like scenes, cameras inside
+    and outside the cloud -- the sizes at which the scans chain over hundreds of workgroups, the depth sort drops culled
+    keys across many blocks and the tile sort's segment-aligned last pass has real segments (up to 19 M instances).
+    Radii, image, final_T, n_contrib bit-exact on a window of two tile rows; gradients per Gaussian."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_medium
+    for seed in (1, 4, 7, 11, 13, 20):
+        desc, problems = fuzz_medium.check(seed)
+        assert not problems, (desc, problems)
+
+
 @pytest.mark.parametrize("W,H", [(14, 14), (16, 16), (7, 30)])
 def test_frames_of_one_or_two_tiles(W, H):
     """A frame that is a single 16x16 tile needs zero tile-id bits: the sorted list must still be materialised
