@@ -1119,7 +1119,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);
         if (me != hipSuccess) return e3_fail(me, "hipMemsetAsync(gsum)");
     }
-    if (nv == 1) {
+    if (nv == 1 && !dL_dcolour_views) {
         // instantiation: accumulate or overwrite x SH degree x (P, M, 3) rows movable as float4 (16-byte aligned rows of the
         // reference layout, overwrite mode)
         const bool acc = (flags & E3_FLAG_ACCUMULATE) != 0;
@@ -1142,7 +1142,8 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
             dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     }
     else {
-        // several views: one pass, every gradient element written once (capi.hip checked the argument subset)
+        // several views (or one whose colour gradient is handed out instead of the SH gradient): one pass, every
+        // gradient element written once (capi.hip checked the argument subset)
         MultiViews mv;
         mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.gsum = gsum;
         geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(

@@ -364,14 +364,13 @@ int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rend
     if (rc) return rc;
     if (P > 0 && (!shs || !scales || !rotations)) return e3_fail(hipErrorInvalidValue, "shs + scales + rotations are required");
     if (D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
-    // nviews == 1 runs the general single-view kernel, so pass 2 to apply the multi-view argument rules always
+    // nviews == 1 runs the general single-view kernel (unless dL_dcolour_views is taken), so pass 2 to apply the
+    // multi-view argument rules always
     // dL_dsh may be NULL when the caller takes the per-view colour gradients instead (e3dgs_sh_grad_from_colour)
     float dummy_sh = 0.0f;
     rc = check_backward_args(2, P, shs, nullptr, opacities, nullptr, grad_acc, dL_dopacity, nullptr, dL_dmean3D,
                              nullptr, (dL_dsh || !dL_dcolour_views) ? dL_dsh : &dummy_sh, dL_dscale, dL_drot, flags);
     if (rc) return rc;
-    if (dL_dcolour_views && nviews < 2)
-        return e3_fail(hipErrorInvalidValue, "dL_dcolour_views needs the multi-view per-Gaussian kernel (nviews >= 2)");
     return e3_backward_impl(vb, P, D, M, num_rendered, background, width, height, means3D, shs, nullptr, opacities,
                             scales, scale_modifier, rotations, nullptr, radii, geom_buffer, binning_buffer, image_buffer,
                             dL_dpix, grad_acc, dL_dmean2D, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_dsh, dL_dscale,

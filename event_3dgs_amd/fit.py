@@ -74,7 +74,8 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
             scalars = tr.compute_gradients(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image,
                                            bg, gt_blur=blur, sh_via_colour=tr.sh_via_colour and not tr.overlap_features)
         else:
-            scalars = tr.compute_gradients_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim)
+            scalars = tr.compute_gradients_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim,
+                                                 sh_via_colour=tr.sh_via_colour and not tr.overlap_features)
         scalars = scalars.clone()
         upd, dens, size_thr, reset = densify.densification_schedule(
             iteration, densify_until_iter, densify_from_iter, densification_interval, opacity_reset_interval,

@@ -529,6 +529,27 @@ class EventTrainer:
         self.last_scalars = scalars
         return scalars
 
+    def _colour_gradients_instead_of_sh(self, out, settings):
+        """The backward hands out the per-view colour gradients (3 floats per Gaussian and view) instead of the 48-float SH
+        gradient, which is rebuilt after the exchange / inside the SH optimizer kernel.  _packed = [nv x P x 3 colour
+        gradients | nv x 3 camera centres]."""
+        nv, P = len(settings), self.N
+        if self._packed is None or self._packed.numel() != nv * P * 3 + nv * 3:
+            self._packed = torch.empty(nv * P * 3 + nv * 3, dtype=torch.float32, device=self.device)
+            self._gathered = torch.empty(self.world, self._packed.numel(), dtype=torch.float32, device=self.device)
+            self._packed_cams = None
+        self._packed_views = nv
+        out["sh"] = None
+        out["colour_views"] = self._packed[:nv * P * 3].view(nv, P, 3)
+        tail = self._packed[nv * P * 3:].view(nv, 3)
+        # (same camera-centre tensors as last iteration, unmodified: already there.  The entry keeps the tensors alive
+        # and is matched by identity: a stale hit would rebuild the SH gradient with last iteration's directions)
+        cams = tuple(st.campos for st in settings)
+        if self._packed_cams is None or not self._same_tensors(self._packed_cams, cams):
+            for k, t in enumerate(cams):
+                tail[k].copy_(t)
+            self._packed_cams = (cams, tuple(t._version for t in cams))
+
     def _event_forward_backward(self, settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour):
         # ---- the three renders (train.py:144,159,161)
         raw = self._forward_views(settings)
@@ -549,24 +570,7 @@ class EventTrainer:
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.factorize_sh or sh_via_colour:
-            # the kernel hands out the per-view colour gradients instead of the SH gradient (rebuilt after the exchange /
-            # inside the SH optimizer kernel)
-            nv, P = 3, self.N
-            if self._packed is None or self._packed.numel() != nv * P * 3 + nv * 3:
-                self._packed = torch.empty(nv * P * 3 + nv * 3, dtype=torch.float32, device=self.device)
-                self._gathered = torch.empty(self.world, self._packed.numel(), dtype=torch.float32, device=self.device)
-                self._packed_cams = None
-            self._packed_views = nv
-            out["sh"] = None
-            out["colour_views"] = self._packed[:nv * P * 3].view(nv, P, 3)
-            tail = self._packed[nv * P * 3:].view(nv, 3)
-            # (same camera-centre tensors as last iteration, unmodified: already there.  The entry keeps the tensors alive
-            # and is matched by identity: a stale hit would rebuild the SH gradient with last iteration's directions)
-            cams = tuple(st.campos for st in settings)
-            if self._packed_cams is None or not self._same_tensors(self._packed_cams, cams):
-                for k, t in enumerate(cams):
-                    tail[k].copy_(t)
-                self._packed_cams = (cams, tuple(t._version for t in cams))
+            self._colour_gradients_instead_of_sh(out, settings)
         if self.track_stats:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out)
@@ -782,14 +786,17 @@ class EventTrainer:
         Adam.  No autograd graph; the SSIM kernel returns its own gradient.  Returns the loss as a device scalar."""
         if mode not in ("gray", "rgb"):
             raise ValueError("mode must be 'gray' or 'rgb'")
-        loss = self.compute_gradients_image(cam, gt_image, bg, mode, lambda_dssim)
+        loss = self.compute_gradients_image(cam, gt_image, bg, mode, lambda_dssim,
+                                            sh_via_colour=self.sh_via_colour and not self.overlap_features)
         self.apply_update(sync_grads, skip=("c",))     # optimizer_c only steps on event iterations (train.py:210-212)
         return loss.clone()
 
-    def compute_gradients_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):
+    def compute_gradients_image(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2, sh_via_colour=False):
+        """sh_via_colour (what step_image() uses on one rank): as in compute_gradients() -- the SH segment of the gradient
+        buffer is NOT written; apply_update() rebuilds the SH gradient inside the SH optimizer kernel."""
         settings = [self._settings(cam, bg)]
         for _attempt in range(4):
-            loss, raw = self._image_forward_backward(settings, gt_image, mode, lambda_dssim)
+            loss, raw = self._image_forward_backward(settings, gt_image, mode, lambda_dssim, sh_via_colour)
             if self._count_fits(raw):
                 break
         else:
@@ -799,7 +806,7 @@ class EventTrainer:
         self.last_scalars = loss
         return loss
 
-    def _image_forward_backward(self, settings, gt_image, mode, lambda_dssim):
+    def _image_forward_backward(self, settings, gt_image, mode, lambda_dssim, sh_via_colour=False):
         raw = self._forward_views(settings)
         img = raw["color"][0]
         gt = gt_image if gt_image.dtype == torch.float32 else gt_image.float()
@@ -820,7 +827,9 @@ class EventTrainer:
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.track_stats:
             out["means2D"] = self.viewspace_grad
-        self._packed_views = 0                     # single render: the SH gradient itself is exchanged
+        self._packed_views = 0
+        if self.factorize_sh or sh_via_colour:     # as in the event iteration, with one view: 3 floats per Gaussian are
+            self._colour_gradients_instead_of_sh(out, settings)      # exchanged / kept instead of the 48 of the SH gradient
         rasterizer.backward_multi(raw, dpix, out)
         return loss, raw
 

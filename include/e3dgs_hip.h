@@ -283,7 +283,7 @@ int e3dgs_rasterize_backward_multi(
     float* dL_dsh,                    /* may be NULL if dL_dcolour_views is given */
     float* dL_dscale, float* dL_drot,
     float* dL_dcolour_views,          /* (nviews,P,3) or NULL: per-view dL/dcolour with the SH clamp mask applied
-                                         (zero where the view does not see the Gaussian); needs nviews >= 2 */
+                                         (zero where the view does not see the Gaussian) */
     int debug, int flags, void* stream);
 
 /*

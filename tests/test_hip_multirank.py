@@ -245,8 +245,12 @@ def _psnr_after(iters):
                                  train)["psnr"] if iters == 0 else None
     if iters == 0:
         return p0
+    import random
+    # (the single-rank loop draws its cameras with `rng`, by default the global random.randint as train.py:116 does:
+    # seeded here, or the single-rank PSNRs move by +-0.2 dB from run to run and the envelope below turns flaky)
     tr = fit.fit_event_scene(init, train, events, bg, DEV, iterations=iters, cameras_extent=4.4,
-                             densify_from_iter=10 ** 9, start_sh_degree=3, seed=5, white_background=True)
+                             densify_from_iter=10 ** 9, start_sh_degree=3, seed=5, white_background=True,
+                             rng=random.Random(5).randint)
     return scene_io.evaluate_views(lambda cam: tr.render_raw(cam, bg)["color"], train)["psnr"]
 
 

@@ -104,10 +104,20 @@ def check_image(seed):
     gp["xyz"] = params["xyz"] + 0.01 * torch.randn(params["xyz"].shape, generator=torch.Generator().manual_seed(1)).to(DEV)
     gt = (torch.round(EventTrainer(gp, DEV, active_sh_degree=deg).render_raw(cam, bg)["color"].clamp(0, 1) * 255) / 255).contiguous()
     a, b = EventTrainer(params, DEV, active_sh_degree=deg), EventTrainer(params, DEV, active_sh_degree=deg)
-    la = a.step_image(cam, gt, bg, mode=mode, lambda_dssim=lam)
+    a2 = EventTrainer(params, DEV, active_sh_degree=deg)
+    # a: gradients in memory (single-view per-Gaussian kernel), then the generic optimizer; a2: step_image() as training
+    # runs it (multi-view per-Gaussian kernel with one view + SH gradient rebuilt inside the SH optimizer kernel): same
+    # mathematics through different kernels -- the moments agree to rounding
+    la = a.compute_gradients_image(cam, gt, bg, mode=mode, lambda_dssim=lam).clone()
+    a.apply_update(skip=("c",))
+    a2.step_image(cam, gt, bg, mode=mode, lambda_dssim=lam)
     lb = b.step_image_autograd(cam, gt, bg, mode=mode, lambda_dssim=lam)
     torch.cuda.synchronize()
     problems = []
+    for nm, x, y in (("exp_avg", a.exp_avg, a2.exp_avg), ("exp_avg_sq", a.exp_avg_sq, a2.exp_avg_sq)):
+        e = rel_l2(x.cpu().numpy(), y.cpu().numpy())
+        if not e <= 2e-5:
+            problems.append("step_image() vs compute_gradients_image() + apply_update(): %s rel. L2 %.3g" % (nm, e))
     loose = N < 500
     la0, lb0 = float(la.detach()), float(lb.detach())
     # 1 - SSIM of two nearly equal images is a difference of fp32 numbers close to 1: 1e-6 absolute on the loss
