@@ -548,7 +548,14 @@ int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v
 // C1 = 0.01^2, C2 = 0.03^2, mean over the map.  `to_gray` applies rgb_to_grayscale (:18-23) to both inputs
 // first (ssim_gray :368-385).  Forward writes the three partials dm/dmu1, dm/ds11, dm/ds12 per pixel; the
 // backward pass blurs them (the window is symmetric) and applies the chain rule of mu1, E[x^2], E[xy].
-constexpr int SS_T = 16, SS_R = 5, SS_IN = SS_T + 2 * SS_R;   // 16x16 outputs from a 26x26 input patch
+// Work decomposition: a workgroup produces a 32x32 output tile from a 42x42 input patch (1.7x read amplification, served
+// by L2).  Both separable passes are register-tiled: a thread of the horizontal pass slides the window over 18 inputs
+// for a run of 8 outputs (36 LDS reads and 54 products instead of 176 and 264), a thread of the vertical pass over 14 rows
+// for 4 outputs.  Every output still accumulates its 11 taps in ascending order (same rounding as the untiled form).
+// Row pitches 43 / 33 keep both passes free of LDS bank conflicts for the lane -> (row, run) maps used below.
+constexpr int SS_R = 5, SS_TX = 32, SS_TY = 32, SS_INX = SS_TX + 2 * SS_R, SS_INY = SS_TY + 2 * SS_R;
+constexpr int SS_SP = SS_INX + 1, SS_HP = SS_TX + 1, SS_RUN_H = 8, SS_RUN_V = 4;
+static_assert(SS_INY * (SS_TX / SS_RUN_H) <= 256 && SS_TX * (SS_TY / SS_RUN_V) == 256, "one pass per thread");
 struct SsimWin { float w[11]; };      // the 11 taps travel as a kernel argument: no per-device / per-process state
 
 __device__ __forceinline__ float ss_load(const float* __restrict__ img, int C, int to_gray, size_t HW, int ch, int x, int y,
@@ -562,53 +569,112 @@ __device__ __forceinline__ float ss_load(const float* __restrict__ img, int C, i
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWin win, int C, int H, int W, int to_gray, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ partial3,
                                                        double* __restrict__ block_sums) {
-    __shared__ float s1[SS_IN][SS_IN + 1], s2[SS_IN][SS_IN + 1];
-    __shared__ float h[5][SS_IN][SS_T + 1];
+    // the input patches are dead once the horizontal pass has read them: its results go into the same LDS (one more
+    // barrier, 28 instead of 42 KB per workgroup)
+    __shared__ float lds[5 * SS_INY * SS_HP];
+    static_assert(2 * SS_INY * SS_SP <= 5 * SS_INY * SS_HP, "patches fit under the horizontal results");
+    float (*s1)[SS_SP] = reinterpret_cast<float (*)[SS_SP]>(lds);
+    float (*s2)[SS_SP] = reinterpret_cast<float (*)[SS_SP]>(lds + SS_INY * SS_SP);
+    float (*h)[SS_INY][SS_HP] = reinterpret_cast<float (*)[SS_INY][SS_HP]>(lds);
     __shared__ double wred[4];
     const int ch = blockIdx.z;
-    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int x0 = blockIdx.x * SS_TX, y0 = blockIdx.y * SS_TY;
     const size_t HW = (size_t)H * W;
-    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
-        int ly = i / SS_IN, lx = i % SS_IN;
-        s1[ly][lx] = ss_load(img1, C, to_gray, HW, ch, x0 + lx - SS_R, y0 + ly - SS_R, W, H);
-        s2[ly][lx] = ss_load(img2, C, to_gray, HW, ch, x0 + lx - SS_R, y0 + ly - SS_R, W, H);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < SS_IN * SS_T; i += 256) {          // horizontal pass
-        int ly = i / SS_T, lx = i % SS_T;
-        float a = 0, b = 0, aa = 0, bb = 0, ab = 0;
+    // patch loads: unconditional (clamped address, value selected afterwards) and fully unrolled, so that all of a
+    // thread's requests are in flight together -- a load under `if (inside)` waits for its own round trip
+    constexpr int NLOAD = (SS_INY * SS_INX + 255) / 256;
+    float v1[NLOAD], v2[NLOAD];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            float w = win.w[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
-            a = FMA(w, u, a); b = FMA(w, v, b); aa = FMA(w, u * u, aa); bb = FMA(w, v * v, bb); ab = FMA(w, u * v, ab);
+    for (int it = 0; it < NLOAD; ++it) {
+        const int i = min((int)threadIdx.x + it * 256, SS_INY * SS_INX - 1);
+        const int ly = i / SS_INX, lx = i - ly * SS_INX;
+        const int x = x0 + lx - SS_R, y = y0 + ly - SS_R;
+        const bool in = x >= 0 && y >= 0 && x < W && y < H;
+        const size_t p = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        float a, b;
+        if (to_gray) {
+            a = FMA(0.114f, img1[2 * HW + p], FMA(0.587f, img1[HW + p], 0.299f * img1[p]));
+            b = FMA(0.114f, img2[2 * HW + p], FMA(0.587f, img2[HW + p], 0.299f * img2[p]));
+        } else {
+            a = img1[ch * HW + p]; b = img2[ch * HW + p];
         }
-        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+        v1[it] = in ? a : 0.0f; v2[it] = in ? b : 0.0f;                 // zero padding
+    }
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < SS_INY * SS_INX) { const int ly = i / SS_INX, lx = i - ly * SS_INX; s1[ly][lx] = v1[it]; s2[ly][lx] = v2[it]; }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+    const bool hz = threadIdx.x < SS_INY * (SS_TX / SS_RUN_H);       // horizontal pass: (row, run of 8 columns)
+    const int row = hz ? threadIdx.x >> 2 : 0, c0 = (threadIdx.x & 3) * SS_RUN_H;
+    float acc[SS_RUN_H][5];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {                                    // vertical pass
-        float w = win.w[k];
-        mu1 = FMA(w, h[0][ly + k][lx], mu1); mu2 = FMA(w, h[1][ly + k][lx], mu2);
-        e11 = FMA(w, h[2][ly + k][lx], e11); e22 = FMA(w, h[3][ly + k][lx], e22); e12 = FMA(w, h[4][ly + k][lx], e12);
+    for (int o = 0; o < SS_RUN_H; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = acc[o][4] = 0.0f;
+    if (hz) {
+#pragma unroll
+        for (int j = 0; j < SS_RUN_H + 10; ++j) {
+            const float u = s1[row][c0 + j], v = s2[row][c0 + j];
+            const float uu = u * u, vv = v * v, uv = u * v;
+#pragma unroll
+            for (int o = 0; o < SS_RUN_H; ++o) {
+                const int k = j - o;
+                if (k >= 0 && k < 11) {
+                    const float w = win.w[k];
+                    acc[o][0] = FMA(w, u, acc[o][0]); acc[o][1] = FMA(w, v, acc[o][1]); acc[o][2] = FMA(w, uu, acc[o][2]);
+                    acc[o][3] = FMA(w, vv, acc[o][3]); acc[o][4] = FMA(w, uv, acc[o][4]);
+                }
+            }
+        }
     }
-    const int x = x0 + lx, y = y0 + ly;
+    __syncthreads();                                                  // every patch value has been read
+    if (hz) {
+#pragma unroll
+        for (int o = 0; o < SS_RUN_H; ++o)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) h[q][row][c0 + o] = acc[o][q];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * SS_RUN_V;     // vertical pass: (column, run of 4 rows)
+    float out[SS_RUN_V][5];
+#pragma unroll
+    for (int o = 0; o < SS_RUN_V; ++o) out[o][0] = out[o][1] = out[o][2] = out[o][3] = out[o][4] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SS_RUN_V + 10; ++j) {
+        float hv[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) hv[q] = h[q][r0 + j][lx];
+#pragma unroll
+        for (int o = 0; o < SS_RUN_V; ++o) {
+            const int k = j - o;
+            if (k >= 0 && k < 11) {
+                const float w = win.w[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) out[o][q] = FMA(w, hv[q], out[o][q]);
+            }
+        }
+    }
+    const int x = x0 + lx;
     double v = 0.0;
-    if (x < W && y < H) {
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
-        float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
-        float inv = 1.0f / (B1 * B2);
-        float m = A1 * A2 * inv;
-        v = (double)m;
-        if (partial3) {
-            size_t p = (size_t)ch * HW + (size_t)y * W + x;
-            size_t CHW = (size_t)gridDim.z * HW;
-            float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -m / B1, dB2 = -m / B2;
-            partial3[p] = dA1 * 2.0f * mu2 - dA2 * 2.0f * mu2 + dB1 * 2.0f * mu1 - dB2 * 2.0f * mu1;   // dm/dmu1
-            partial3[CHW + p] = dB2;                                                                    // dm/dE[x^2]
-            partial3[2 * CHW + p] = 2.0f * dA2;                                                          // dm/dE[xy]
+#pragma unroll
+    for (int o = 0; o < SS_RUN_V; ++o) {
+        const int y = y0 + r0 + o;
+        if (x < W && y < H) {
+            const float mu1 = out[o][0], mu2 = out[o][1], e11 = out[o][2], e22 = out[o][3], e12 = out[o][4];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+            float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+            float inv = 1.0f / (B1 * B2);
+            float m = A1 * A2 * inv;
+            v += (double)m;
+            if (partial3) {
+                size_t p = (size_t)ch * HW + (size_t)y * W + x;
+                size_t CHW = (size_t)gridDim.z * HW;
+                float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -m / B1, dB2 = -m / B2;
+                partial3[p] = dA1 * 2.0f * mu2 - dA2 * 2.0f * mu2 + dB1 * 2.0f * mu1 - dB2 * 2.0f * mu1;   // dm/dmu1
+                partial3[CHW + p] = dB2;                                                                    // dm/dE[x^2]
+                partial3[2 * CHW + p] = 2.0f * dA2;                                                          // dm/dE[xy]
+            }
         }
     }
 #pragma unroll
@@ -616,7 +682,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(SsimWin win, int C, int H
     if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0)
-        block_sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = wred[0] + wred[1] + wred[2] + wred[3];
+        block_sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (wred[0] + wred[1]) + (wred[2] + wred[3]);
 }
 
 __global__ __launch_bounds__(WAVE) void ssim_finalize_kernel(int nblocks, double count, const double* __restrict__ sums,
@@ -634,52 +700,92 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWin win, int C, int H
                                                        double* __restrict__ l1_sums) {
     // l1_sums != NULL (e3dgs_image_loss): d_img1 = scale * dSSIM/dimg + l1_scale * sign(img1 - img2) (per channel, or
     // on the gray values with the channel weights), and sum |img1 - img2| of the block goes to l1_sums[block]
-    __shared__ float sp[3][SS_IN][SS_IN + 1];
-    __shared__ float h[3][SS_IN][SS_T + 1];
+    __shared__ float lds[3 * SS_INY * SS_SP];                    // patches, then (same LDS) the horizontal results
+    float (*sp)[SS_INY][SS_SP] = reinterpret_cast<float (*)[SS_INY][SS_SP]>(lds);
+    float (*h)[SS_INY][SS_HP] = reinterpret_cast<float (*)[SS_INY][SS_HP]>(lds);
     __shared__ double wred[4];
     const int ch = blockIdx.z;
-    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int x0 = blockIdx.x * SS_TX, y0 = blockIdx.y * SS_TY;
     const size_t HW = (size_t)H * W, CHW = (size_t)gridDim.z * HW;
-    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
-        int ly = i / SS_IN, lx = i % SS_IN;
-        int x = x0 + lx - SS_R, y = y0 + ly - SS_R;
-        bool in = x >= 0 && y >= 0 && x < W && y < H;
-        size_t p = (size_t)ch * HW + (size_t)(in ? y : 0) * W + (in ? x : 0);
+    constexpr int NLOAD = (SS_INY * SS_INX + 255) / 256;      // (unconditional, unrolled loads: see ssim_fwd_kernel)
+    float pv[NLOAD][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sp[q][ly][lx] = in ? partial3[q * CHW + p] : 0.0f;
+    for (int it = 0; it < NLOAD; ++it) {
+        const int i = min((int)threadIdx.x + it * 256, SS_INY * SS_INX - 1);
+        const int ly = i / SS_INX, lx = i - ly * SS_INX;
+        const int x = x0 + lx - SS_R, y = y0 + ly - SS_R;
+        const bool in = x >= 0 && y >= 0 && x < W && y < H;
+        const size_t p = (size_t)ch * HW + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const float t = partial3[q * CHW + p]; pv[it][q] = in ? t : 0.0f; }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < SS_IN * SS_T; i += 256) {
-        int ly = i / SS_T, lx = i % SS_T;
-        float a = 0, b = 0, c = 0;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            float w = win.w[k];
-            a = FMA(w, sp[0][ly][lx + k], a); b = FMA(w, sp[1][ly][lx + k], b); c = FMA(w, sp[2][ly][lx + k], c);
+    for (int it = 0; it < NLOAD; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < SS_INY * SS_INX) {
+            const int ly = i / SS_INX, lx = i - ly * SS_INX;
+            sp[0][ly][lx] = pv[it][0]; sp[1][ly][lx] = pv[it][1]; sp[2][ly][lx] = pv[it][2];
         }
-        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    float g0 = 0, g1 = 0, g2 = 0;
+    const bool hz = threadIdx.x < SS_INY * (SS_TX / SS_RUN_H);       // horizontal pass: (row, run of 8 columns)
+    const int row = hz ? threadIdx.x >> 2 : 0, c0 = (threadIdx.x & 3) * SS_RUN_H;
+    float acc[SS_RUN_H][3];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        float w = win.w[k];
-        g0 = FMA(w, h[0][ly + k][lx], g0); g1 = FMA(w, h[1][ly + k][lx], g1); g2 = FMA(w, h[2][ly + k][lx], g2);
+    for (int o = 0; o < SS_RUN_H; ++o) acc[o][0] = acc[o][1] = acc[o][2] = 0.0f;
+    if (hz) {
+#pragma unroll
+        for (int j = 0; j < SS_RUN_H + 10; ++j) {
+            const float a = sp[0][row][c0 + j], b = sp[1][row][c0 + j], c = sp[2][row][c0 + j];
+#pragma unroll
+            for (int o = 0; o < SS_RUN_H; ++o) {
+                const int k = j - o;
+                if (k >= 0 && k < 11) {
+                    const float w = win.w[k];
+                    acc[o][0] = FMA(w, a, acc[o][0]); acc[o][1] = FMA(w, b, acc[o][1]); acc[o][2] = FMA(w, c, acc[o][2]);
+                }
+            }
+        }
     }
-    const int x = x0 + lx, y = y0 + ly;
+    __syncthreads();                                                  // every patch value has been read
+    if (hz) {
+#pragma unroll
+        for (int o = 0; o < SS_RUN_H; ++o) { h[0][row][c0 + o] = acc[o][0]; h[1][row][c0 + o] = acc[o][1]; h[2][row][c0 + o] = acc[o][2]; }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * SS_RUN_V;     // vertical pass: (column, run of 4 rows)
+    float out[SS_RUN_V][3];
+#pragma unroll
+    for (int o = 0; o < SS_RUN_V; ++o) out[o][0] = out[o][1] = out[o][2] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SS_RUN_V + 10; ++j) {
+        const float h0 = h[0][r0 + j][lx], h1 = h[1][r0 + j][lx], h2 = h[2][r0 + j][lx];
+#pragma unroll
+        for (int o = 0; o < SS_RUN_V; ++o) {
+            const int k = j - o;
+            if (k >= 0 && k < 11) {
+                const float w = win.w[k];
+                out[o][0] = FMA(w, h0, out[o][0]); out[o][1] = FMA(w, h1, out[o][1]); out[o][2] = FMA(w, h2, out[o][2]);
+            }
+        }
+    }
+    const int x = x0 + lx;
     double absdiff = 0.0;
-    if (x < W && y < H) {
-        float u = ss_load(img1, C, to_gray, HW, ch, x, y, W, H), v = ss_load(img2, C, to_gray, HW, ch, x, y, W, H);
-        float g = scale * (g0 + 2.0f * u * g1 + v * g2);
-        if (l1_sums) {
-            const float e = u - v;
-            absdiff = (double)fabsf(e);
-            g += l1_scale * (float)((e > 0.0f) - (e < 0.0f));
+#pragma unroll
+    for (int o = 0; o < SS_RUN_V; ++o) {
+        const int y = y0 + r0 + o;
+        if (x < W && y < H) {
+            float u = ss_load(img1, C, to_gray, HW, ch, x, y, W, H), v = ss_load(img2, C, to_gray, HW, ch, x, y, W, H);
+            float g = scale * (out[o][0] + 2.0f * u * out[o][1] + v * out[o][2]);
+            if (l1_sums) {
+                const float e = u - v;
+                absdiff += (double)fabsf(e);
+                g += l1_scale * (float)((e > 0.0f) - (e < 0.0f));
+            }
+            size_t p = (size_t)y * W + x;
+            if (to_gray) { d_img1[p] = 0.299f * g; d_img1[HW + p] = 0.587f * g; d_img1[2 * HW + p] = 0.114f * g; }
+            else d_img1[ch * HW + p] = g;
         }
-        size_t p = (size_t)y * W + x;
-        if (to_gray) { d_img1[p] = 0.299f * g; d_img1[HW + p] = 0.587f * g; d_img1[2 * HW + p] = 0.114f * g; }
-        else d_img1[ch * HW + p] = g;
     }
     if (l1_sums) {
 #pragma unroll
@@ -721,7 +827,7 @@ static SsimWin ssim_window() {
 }
 
 size_t e3_ssim_scratch_bytes(int C, int H, int W) {
-    size_t nb = (size_t)((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T) * C;
+    size_t nb = (size_t)((W + SS_TX - 1) / SS_TX) * ((H + SS_TY - 1) / SS_TY) * C;
     return nb * sizeof(double) + 3 * (size_t)C * H * W * sizeof(float) + 512;
 }
 
@@ -730,7 +836,7 @@ int e3_ssim_impl(int C, int H, int W, int to_gray, const float* img1, const floa
     if (to_gray && C != 3) return e3_fail(hipErrorInvalidValue, "to_gray needs 3-channel inputs");
     const SsimWin win = ssim_window();
     const int Ceff = to_gray ? 1 : C;
-    dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, Ceff);
+    dim3 grid((W + SS_TX - 1) / SS_TX, (H + SS_TY - 1) / SS_TY, Ceff);
     size_t nb = (size_t)grid.x * grid.y * grid.z;
     double* sums = reinterpret_cast<double*>(scratch);
     float* partial3 = reinterpret_cast<float*>(scratch + align_up(nb * sizeof(double), 256));
@@ -745,7 +851,7 @@ int e3_ssim_impl(int C, int H, int W, int to_gray, const float* img1, const floa
 
 // (1 - lambda) L1 + lambda (1 - SSIM) and its image gradient in three launches (the --gray and RGB iterations).
 size_t e3_image_loss_scratch_bytes(int C, int H, int W) {
-    size_t nb = (size_t)((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T) * C;
+    size_t nb = (size_t)((W + SS_TX - 1) / SS_TX) * ((H + SS_TY - 1) / SS_TY) * C;
     return e3_ssim_scratch_bytes(C, H, W) + nb * sizeof(double) + 256;
 }
 int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, const float* img, const float* gt,
@@ -754,7 +860,7 @@ int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, con
     if (!d_img || !scalars) return e3_fail(hipErrorInvalidValue, "scalars and d_img are required");
     const SsimWin win = ssim_window();
     const int Ceff = to_gray ? 1 : C;
-    dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, Ceff);
+    dim3 grid((W + SS_TX - 1) / SS_TX, (H + SS_TY - 1) / SS_TY, Ceff);
     const size_t nb = (size_t)grid.x * grid.y * grid.z;
     double* sums = reinterpret_cast<double*>(scratch);
     float* partial3 = reinterpret_cast<float*>(scratch + align_up(nb * sizeof(double), 256));
