@@ -148,6 +148,12 @@ def main():
     for _ in range(warm):
         loss = one_step()
     torch.cuda.synchronize()
+    # Python's cyclic garbage collector is kept out of the measurements (as timeit does): a generation-2 pass of this
+    # process takes 30-60 ms -- measured: it landed inside a 20-step window in two runs of three and turned 2.0 ms per
+    # step into 4 -- and nothing the iteration allocates needs it (no reference cycles; tensors are freed by refcount).
+    import gc
+    gc.collect()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -323,6 +329,30 @@ def main():
         contrast = {"ms": round(cms, 3), "per_s": round(1e3 / cms, 1), "renders": 2,
                     "what": "renders #2,#3 fwd + log-contrast L1 (train.py:159-178) + backward of both; no optimizer"}
 
+    # ---- the iteration as the reference's DATASETS shape it: the event camera `index` is read with the training camera's
+    # extrinsics (scene/dataset_readers.py:157), so render #1 (train.py:144) and render #2 (:159) are the same view.
+    # EventTrainer renders it once (compute_gradients: shared pose).  The headline above keeps three DISTINCT cameras
+    # (three renders of work); this is the same step with cam_now at cam_int's pose.  After the timed region.
+    shared_pose = None
+    if world == 1 and not args.no_substep:
+        cam_now_same = orbit_camera(k0, K, W, H, device=dev)           # a second camera object, the pose of cam_int
+        gt_same = trainer.render_raw(cam_now_same, bg)["color"].clone()
+        sp_step = lambda: trainer.step(cam_int, cam_now_same, cam_next, gts[0], gt_same, gts[2], bg, gt_blur=gt_blur)
+        before = trainer.shared_pose_iterations
+        for _ in range(3):
+            sp_step()
+        torch.cuda.synchronize()
+        tsp = time.perf_counter()
+        reps = max(5, min(args.steps, 20))
+        for _ in range(reps):
+            sp_step()
+        torch.cuda.synchronize()
+        sms = 1e3 * (time.perf_counter() - tsp) / reps
+        shared_pose = {"ms": round(sms, 3), "per_s": round(1e3 / sms, 1), "renders": 2,
+                       "taken": trainer.shared_pose_iterations - before == reps + 3,
+                       "what": "the full event iteration (loss on three images, backward, Adam) when render #1 and render #2 "
+                               "share a pose, as in the reference's datasets: that view is rendered once"}
+
     # ---- several ranks: what the exchange costs, so that one JSON line diagnoses an 8-GPU run.  After the timed region:
     #   exposed_comm_ms  = step time - time of the same step without any exchange (sync_grads=False: local Adam)
     #   allreduce_ms / allgather_ms = the two collectives of the default schedule alone, on their real buffers
@@ -407,7 +437,7 @@ def main():
                        "sh_exchange_on_side_stream": bool(trainer.overlap_features), "dp_schedule": dp_schedule,
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "contrast_only_substep": contrast,
-            "dropin_autograd_step": dropin, "cpu_baseline": cpu_baseline,
+            "dropin_autograd_step": dropin, "shared_pose_iteration": shared_pose, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
             # ranks the communicator itself reports (1: no process group) and whether the factorised / overlapped
             # exchange had to be replaced by the plain schedule (a failing exchange must not hide in a slower number)

@@ -329,8 +329,12 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     size_t HW, const float* __restrict__ image, const float* __restrict__ now, const float* __restrict__ next,
     const float* __restrict__ gt_int, const float* __restrict__ gt_now, const float* __restrict__ gt_next,
     const float* __restrict__ gt_blur, const float* __restrict__ c_ptr, float gt_c,
-    const float* __restrict__ scalars, float* __restrict__ d_image, float* __restrict__ d_now,
+    const float* __restrict__ scalars, float* d_image, float* d_now /* may alias d_image: the SUM is stored */,
     float* __restrict__ d_next) {
+    // d_now == d_image: render #1 and render #2 are the same render (the reference's event camera `index` carries the
+    // pose of its training camera `index`: scene/dataset_readers.py:157 reads both with the same extrinsics), so the
+    // caller rendered it once and wants dL/d(that image) = intensity part + contrast part
+    const bool shared = d_now == d_image;
     const float c = c_ptr[0];
     const float kE = scalars[6], kI = scalars[7];
     const float kB = 0.5f / (3.0f * (float)HW);
@@ -392,8 +396,13 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 reinterpret_cast<float4*>(d_next + ch * HW)[q] = make_float4(on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
-                reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
-                reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
+                if (shared) {
+                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1],
+                                                                                  oi[ch][2] + ow[ch][2], oi[ch][3] + ow[ch][3]);
+                } else {
+                    reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
+                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
+                }
             }
         }
     } else {
@@ -408,7 +417,9 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
             pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                d_next[ch * HW + p] = dn[ch]; d_now[ch * HW + p] = dw[ch]; d_image[ch * HW + p] = di[ch];
+                d_next[ch * HW + p] = dn[ch];
+                if (shared) d_image[ch * HW + p] = di[ch] + dw[ch];
+                else { d_now[ch * HW + p] = dw[ch]; d_image[ch * HW + p] = di[ch]; }
             }
         }
     }

@@ -68,18 +68,19 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
         else:
             index = sample_index(len(train_cameras), mode, rng)
         cam = train_cameras[index]
+        upd, dens, size_thr, reset = densify.densification_schedule(
+            iteration, densify_until_iter, densify_from_iter, densification_interval, opacity_reset_interval,
+            white_background)
         if mode == "event":
             now, nxt = event_cameras[index], event_cameras[index + 1]
             blur = blurry_cameras[index].original_image if blurry_cameras else None         # train.py:197-203
             scalars = tr.compute_gradients(cam, now, nxt, cam.original_image, now.original_image, nxt.original_image,
-                                           bg, gt_blur=blur, sh_via_colour=tr.sh_via_colour and not tr.overlap_features)
+                                           bg, gt_blur=blur, sh_via_colour=tr.sh_via_colour and not tr.overlap_features,
+                                           viewspace_grad=upd)       # (statistics iterations need render #1's own gradient)
         else:
             scalars = tr.compute_gradients_image(cam, cam.original_image, bg, mode=mode, lambda_dssim=lambda_dssim,
                                                  sh_via_colour=tr.sh_via_colour and not tr.overlap_features)
         scalars = scalars.clone()
-        upd, dens, size_thr, reset = densify.densification_schedule(
-            iteration, densify_until_iter, densify_from_iter, densification_interval, opacity_reset_interval,
-            white_background)
         skip = set() if mode == "event" else {"c"}
         if dens or iteration == iterations:
             skip.add("gaussians")

@@ -132,6 +132,10 @@ class EventTrainer:
         # count that did not fit costs a repeated forward / backward, never a wrong update.  E3DGS_NO_HOST_WAIT=0
         # restores begin -> wait -> finish.
         self.no_host_wait = os.environ.get("E3DGS_NO_HOST_WAIT", "1") != "0"
+        # render #1 == render #2 of an event iteration (same pose) rendered once: see compute_gradients()
+        self.share_coincident_views = os.environ.get("E3DGS_SHARE_VIEWS", "1") != "0"
+        self.shared_pose_iterations = 0
+        self._coincide = {}
         self._capacity = {}            # (N, views, H, W) -> instances the binning buffers are sized for
         self.count_retries = 0         # iterations repeated because the count exceeded the capacity
         self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
@@ -500,11 +504,19 @@ class EventTrainer:
             return False
         return True
 
-    def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sh_via_colour=False):
+    def compute_gradients(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sh_via_colour=False,
+                          viewspace_grad=True):
         """Forward (three renders), event loss and backward of one iteration: fills the flat gradient buffer.
         sh_via_colour (what step() uses on one rank): the SH segment of the gradient buffer is NOT written; the backward
         leaves the per-view colour gradients instead and apply_update() rebuilds the SH gradient inside the fused
         SH-optimizer kernel.
+        Shared pose (share_coincident_views, on by default): when cam_int and cam_now are the same view -- the
+        reference's datasets are built that way: the event cameras are read with the training cameras' extrinsics
+        (scene/dataset_readers.py:157), so train.py:144 and :159 render the same image twice -- it is rendered ONCE: its
+        image feeds the intensity and the contrast term and its backward receives the sum of the two pixel gradients
+        (the backward is linear in them).  Same loss, same image bits, gradients equal to summation order, two thirds of
+        the work.  Not taken when the screen-space gradient of render #1 ALONE is needed (densification statistics,
+        train.py:145,317-320): viewspace_grad=False says it is not (fit.fit_event_scene passes the schedule's answer).
         The returned scalars tensor, `last_scalars` and `last_radii` are VIEWS of persistent buffers that the next
         iteration overwrites (step() / step_image() return clones)."""
         v = self.views
@@ -519,8 +531,14 @@ class EventTrainer:
                                  "exchange: construct EventTrainer(..., factorize_sh=False) on every rank (or set "
                                  "E3DGS_FACTORIZE_SH=0) for datasets that mix resolutions")
             return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
+        need_vs = self.track_stats and viewspace_grad
+        shared = self.share_coincident_views and not need_vs and self._views_coincide(cam_int, cam_now, settings)
+        if shared:
+            settings = [settings[0], settings[2]]
+        self.shared_pose_iterations += int(shared)
         for _attempt in range(4):
-            scalars, raw = self._event_forward_backward(settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour)
+            scalars, raw = self._event_forward_backward(settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour,
+                                                        shared=shared, viewspace=need_vs)
             if self._count_fits(raw):
                 break
         else:
@@ -529,29 +547,55 @@ class EventTrainer:
         self.last_scalars = scalars
         return scalars
 
-    def _colour_gradients_instead_of_sh(self, out, settings):
+    def _views_coincide(self, cam_a, cam_b, settings):
+        """True when the two cameras are the same view (frame size, field of view, matrices, centre -- compared by value
+        ONCE per camera pair: the answer is cached on the pair, matched by identity like _camera_tensors)."""
+        if cam_a is cam_b:
+            return True
+        sa, sb = settings[0], settings[1]
+        if (sa.image_height, sa.image_width, sa.tanfovx, sa.tanfovy) != (sb.image_height, sb.image_width, sb.tanfovx, sb.tanfovy):
+            return False
+        tensors = (sa.viewmatrix, sa.projmatrix, sa.campos, sb.viewmatrix, sb.projmatrix, sb.campos)
+        hit = self._coincide.get((id(cam_a), id(cam_b)))
+        if hit is not None and hit[0] is cam_a and hit[1] is cam_b and self._same_tensors(hit[2], tensors):
+            return hit[3]
+        same = bool(torch.equal(sa.viewmatrix, sb.viewmatrix) and torch.equal(sa.projmatrix, sb.projmatrix)
+                    and torch.equal(sa.campos, sb.campos))          # (a host wait, once per camera pair)
+        if len(self._coincide) > 4096:
+            self._coincide.clear()
+        self._coincide[(id(cam_a), id(cam_b))] = (cam_a, cam_b, (tensors, tuple(t._version for t in tensors)), same)
+        return same
+
+    def _colour_gradients_instead_of_sh(self, out, settings, pad_to=None):
         """The backward hands out the per-view colour gradients (3 floats per Gaussian and view) instead of the 48-float SH
         gradient, which is rebuilt after the exchange / inside the SH optimizer kernel.  _packed = [nv x P x 3 colour
-        gradients | nv x 3 camera centres]."""
-        nv, P = len(settings), self.N
+        gradients | nv x 3 camera centres].  pad_to: the block keeps that many views (the extra ones carry zero
+        gradients, which the rebuild skips) -- every rank's block of the all-gather has the same size even when this
+        rank rendered a shared-pose iteration with two views."""
+        n_real, P = len(settings), self.N
+        nv = max(n_real, pad_to or 0)
         if self._packed is None or self._packed.numel() != nv * P * 3 + nv * 3:
             self._packed = torch.empty(nv * P * 3 + nv * 3, dtype=torch.float32, device=self.device)
             self._gathered = torch.empty(self.world, self._packed.numel(), dtype=torch.float32, device=self.device)
             self._packed_cams = None
         self._packed_views = nv
         out["sh"] = None
-        out["colour_views"] = self._packed[:nv * P * 3].view(nv, P, 3)
+        out["colour_views"] = self._packed[:n_real * P * 3].view(n_real, P, 3)
+        if nv > n_real:
+            self._packed[n_real * P * 3:nv * P * 3].zero_()
         tail = self._packed[nv * P * 3:].view(nv, 3)
         # (same camera-centre tensors as last iteration, unmodified: already there.  The entry keeps the tensors alive
         # and is matched by identity: a stale hit would rebuild the SH gradient with last iteration's directions)
-        cams = tuple(st.campos for st in settings)
+        cams = tuple(st.campos for st in settings) + (settings[-1].campos,) * (nv - n_real)
         if self._packed_cams is None or not self._same_tensors(self._packed_cams, cams):
             for k, t in enumerate(cams):
                 tail[k].copy_(t)
             self._packed_cams = (cams, tuple(t._version for t in cams))
 
-    def _event_forward_backward(self, settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour):
-        # ---- the three renders (train.py:144,159,161)
+    def _event_forward_backward(self, settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour, shared=False,
+                                viewspace=True):
+        # ---- the three renders (train.py:144,159,161); shared: render #1 and render #2 are the same render (two views:
+        # [shared, next]) -- its image feeds both loss terms and receives the sum of their gradients
         raw = self._forward_views(settings)
         imgs = raw["color"]
         key = ("event",) + tuple(imgs.shape)
@@ -564,14 +608,16 @@ class EventTrainer:
         self._loss_flip = 1 - getattr(self, "_loss_flip", 0)
         sc = sc2[self._loss_flip]
         # (dL/dc goes straight into the threshold's slot of the flat gradient buffer: no copy kernel)
-        scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[1], imgs[2], self.c, gt_int, gt_now, gt_next, gt_blur,
-                                                 out=(sc, dpix[0], dpix[1], dpix[2], scratch), dc_out=self.c_grad)     # train.py:165-203
+        i_now, i_next = (0, 1) if shared else (1, 2)
+        scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[i_now], imgs[i_next], self.c, gt_int, gt_now, gt_next, gt_blur,
+                                                 out=(sc, dpix[0], dpix[i_now], dpix[i_next], scratch),
+                                                 dc_out=self.c_grad)                                                   # train.py:165-203
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.factorize_sh or sh_via_colour:
-            self._colour_gradients_instead_of_sh(out, settings)
-        if self.track_stats:
+            self._colour_gradients_instead_of_sh(out, settings, pad_to=3 if self.world > 1 else None)
+        if self.track_stats and viewspace:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out)
         return scalars, raw

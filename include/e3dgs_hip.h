@@ -382,6 +382,11 @@ int e3dgs_dist_knn3(int P, const float* points /* (P,3) */, float* out /* (P) */
  * Two launches: a reduction pass (partials -> scalars[8] on device) and a
  * gradient pass.  scalars_out[0]=loss, [1]=dL/dc, [2]=rho, [3]=L1 event,
  * [4]=L1 intensity, [5]=L1 blur.  `scratch` needs e3dgs_event_loss_scratch_bytes(W,H).
+ *
+ * Shared pose: the reference reads its event cameras with the training cameras' extrinsics
+ * (scene/dataset_readers.py:157), so render #1 (train.py:144) and render #2 (:159) of an iteration are the same
+ * render.  A caller that rendered it once passes the same pointer as `image` and `img_now` and the same pointer as
+ * d_image and d_now: the SUM of the two gradients is stored there.
  */
 size_t e3dgs_event_loss_scratch_bytes(int width, int height);
 int e3dgs_event_loss(

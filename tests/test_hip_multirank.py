@@ -163,6 +163,55 @@ def test_two_rank_fit_with_densification_keeps_replicas_identical(tmp_path):
         assert torch.equal(r0[k], r1[k]), k
 
 
+def _shared_pose_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams, gts, bg = _inputs(rank)
+    if rank == 0:             # this rank's event camera `now` carries the pose of its training camera (a real dataset)
+        cams = [cams[0], orbit_camera(0, 16, W, H, device=DEV, daz=0.0), cams[2]]
+    tr = EventTrainer(params, DEV)
+    assert tr.factorize_sh
+    for _ in range(STEPS):
+        tr.step(*cams, *gts, bg)
+    tr.sync_features()
+    torch.cuda.synchronize()
+    assert tr.shared_pose_iterations == (STEPS if rank == 0 else 0)
+    torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu()}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_of_them_with_a_shared_pose_triplet(tmp_path):
+    """Rank 0 renders two views (its renders #1 and #2 share a pose), rank 1 three: the blocks of the colour-gradient
+    all-gather keep one size (rank 0 pads a zero third view), the replicas stay bit-identical and track the emulation
+    with three separate renders on both ranks."""
+    out = str(tmp_path / "sp")
+    mp.spawn(_shared_pose_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in ("flat", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), k
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    pa, ca, ga, bg = _inputs(0)
+    pb, cb, gb, _ = _inputs(1)
+    ca = [ca[0], orbit_camera(0, 16, W, H, device=DEV, daz=0.0), ca[2]]
+    ta, tb = EventTrainer(pa, DEV, overlap_features=False), EventTrainer(pb, DEV, overlap_features=False)
+    ta.share_coincident_views = False
+    for _ in range(STEPS):
+        ta.compute_gradients(*ca, *ga, bg)
+        tb.compute_gradients(*cb, *gb, bg)
+        mean = (ta.flat_grad + tb.flat_grad).div_(2)
+        ta.flat_grad.copy_(mean); tb.flat_grad.copy_(mean)
+        ta.apply_update(); tb.apply_update()
+    torch.cuda.synchronize()
+    m_ref, m_got = ta.exp_avg.cpu(), r0["m"]
+    assert float((m_got - m_ref).norm() / m_ref.norm()) < 1e-4
+    assert float((r0["flat"] - ta.flat.cpu()).abs().max()) <= 0.05
+
+
 def _image_worker(rank, world, port, out, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -933,3 +933,53 @@ def test_checkpoint_resume_continues_the_adam_bias_correction():
         t.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
     torch.cuda.synchronize()
     assert torch.equal(a.flat, b.flat)
+
+
+def test_shared_pose_iteration_equals_three_renders():
+    """The reference's datasets give the event camera `index` the pose of the training camera `index`
+    (scene/dataset_readers.py:157 reads both with the same extrinsics), so renders #1 and #2 of an event iteration
+    (train.py:144,159) are the same render.  EventTrainer renders it once and sends the sum of the two pixel gradients
+    through its backward: same loss bits, gradients and update equal to summation order; not taken when the densification
+    statistics need the screen-space gradient of render #1 alone."""
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams = _scene()
+    W, H = cams[0].image_width, cams[0].image_height
+    same = orbit_camera(0, 16, W, H, device=DEV, daz=0.0)            # another camera object, the pose of cams[0]
+    assert same is not cams[0]
+    bg = torch.tensor([0.2, 0.2, 0.2], device=DEV)
+    gts = _gts(params, cams, bg)
+    blur = (0.5 * (gts[0] + gts[2])).contiguous()
+    for gt_blur in (None, blur):
+        a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
+        b.share_coincident_views = False
+        sa = a.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur).clone()
+        sb = b.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur).clone()
+        torch.cuda.synchronize()
+        assert a.shared_pose_iterations == 1 and b.shared_pose_iterations == 0
+        assert torch.equal(sa[:6], sb[:6])                              # loss, dL/dc, rho, the three L1 terms: same bits
+        assert float(a.c_grad) == float(b.c_grad)
+        for name in ("xyz", "features", "opacity", "scaling", "rotation"):
+            ga, gb = a.grads[name].cpu().numpy(), b.grads[name].cpu().numpy()
+            assert np.abs(gb).max() > 0
+            assert rel_l2(ga, gb) <= 1e-5, (name, rel_l2(ga, gb))
+        # the whole step, as training runs it (SH gradient rebuilt from TWO views' colour gradients)
+        a2, b2 = EventTrainer(params, DEV), EventTrainer(params, DEV)
+        b2.share_coincident_views = False
+        for _ in range(3):
+            a2.step(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+            b2.step(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+        torch.cuda.synchronize()
+        assert a2.shared_pose_iterations == 3
+        assert rel_l2(a2.exp_avg.cpu().numpy(), b2.exp_avg.cpu().numpy()) <= 1e-4
+        assert float((a2.flat - b2.flat).abs().max()) <= 0.05
+    # distinct poses: three renders
+    c = EventTrainer(params, DEV)
+    c.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
+    assert c.shared_pose_iterations == 0
+    # densification statistics wanted: render #1's own screen-space gradient -> three renders; not wanted -> two
+    d = EventTrainer(params, DEV, track_densification_stats=True)
+    d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg)
+    assert d.shared_pose_iterations == 0 and float(d.viewspace_grad.abs().sum()) > 0
+    d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, viewspace_grad=False)
+    assert d.shared_pose_iterations == 1
