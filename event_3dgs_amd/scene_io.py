@@ -50,8 +50,10 @@ def _load_views(views, folder, resolution, device):
             mask = rgb[3:4, ...]
         image = gt.clamp(0.0, 1.0).to(torch.float32)
         image = image * (mask if mask is not None else torch.ones((1, image.shape[1], image.shape[2])))   # cameras.py:43-46
+        # (PILtoTorch permutes HWC -> CHW: the reference keeps that strided view, torch ops do not mind; the fused loss
+        # kernels read plain (3, H, W) planes, so the frame is laid out once, here)
         cams.append(Camera(v["R"], v["T"], v["FovX"], v["FovY"], image.shape[2], image.shape[1], device=device,
-                           image=image.to(device)))
+                           image=image.contiguous().to(device)))
         cams[-1].image_name, cams[-1].uid = v["image_name"], len(cams) - 1
     return cams
 

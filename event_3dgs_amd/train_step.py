@@ -520,6 +520,11 @@ class EventTrainer:
         The returned scalars tensor, `last_scalars` and `last_radii` are VIEWS of persistent buffers that the next
         iteration overwrites (step() / step_image() return clones)."""
         v = self.views
+        # ground-truth frames as plain fp32 (3, H, W) planes (a no-op for frames that already are: cameras of the
+        # reference hold whatever strides PILtoTorch's permute left, utils/general_utils.py:21-27)
+        plane = lambda t: None if t is None else (t if (t.dtype == torch.float32 and t.is_contiguous())
+                                                  else t.to(torch.float32).contiguous())
+        gt_int, gt_now, gt_next, gt_blur = plane(gt_int), plane(gt_now), plane(gt_next), plane(gt_blur)
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
         sizes = {(int(s.image_height), int(s.image_width)) for s in settings}
         if len(sizes) != 1:

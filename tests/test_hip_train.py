@@ -983,3 +983,49 @@ def test_shared_pose_iteration_equals_three_renders():
     assert d.shared_pose_iterations == 0 and float(d.viewspace_grad.abs().sum()) > 0
     d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, viewspace_grad=False)
     assert d.shared_pose_iterations == 1
+
+
+def test_scene_directory_to_shared_pose_training(tmp_path):
+    """A scene directory in the reference's layout (sparse/0 + images + images_event: the golden COLMAP model with random
+    frames) -> load_colmap_scene -> create_from_pcd -> fit_event_scene.  The loader gives event camera `index` the pose
+    of training camera `index` (as scene/dataset_readers.py:157 does), so once the densification statistics are no
+    longer collected (iteration >= densify_until_iter) every event iteration renders two views instead of three."""
+    import shutil
+    from PIL import Image
+    from event_3dgs_amd import fit, scene_io
+    from simple_knn._C import distCUDA2
+    cd = os.path.join(GOLDEN, "colmap_tiny")
+    root = str(tmp_path / "scene")
+    os.makedirs(os.path.join(root, "sparse/0"))
+    for f in ("cameras.bin", "images.bin", "points3D.bin"):
+        shutil.copy(os.path.join(cd, f), os.path.join(root, "sparse/0", f))
+    from event_3dgs_amd import io_formats as IO
+    rs = np.random.RandomState(0)
+    for d in ("images", "images_event", "renders"):
+        os.makedirs(os.path.join(root, d))
+        for im in IO.read_images_binary(os.path.join(cd, "images.bin")).values():
+            Image.fromarray(rs.randint(0, 256, (48, 64, 3), dtype=np.uint8)).save(os.path.join(root, d, im.name))
+    sc = scene_io.load_colmap_scene(root, gray=True, event=True, device=DEV)
+    params = scene_io.create_from_pcd(sc.point_cloud, sc.cameras_extent, distCUDA2, device=DEV)
+    shared_after = []
+    tr = fit.fit_event_scene(params, sc.train_cameras, sc.event_cameras, torch.zeros(3, device=DEV), DEV, iterations=10,
+                             cameras_extent=sc.cameras_extent, densify_until_iter=6, densify_from_iter=2,
+                             densification_interval=2, rng=lambda a, b: 2,
+                             on_iteration=lambda it, t, s: shared_after.append(t.shared_pose_iterations))
+    torch.cuda.synchronize()
+    # iterations 1..5 collect statistics (render #1's own screen-space gradient: three renders); 6..10 share
+    assert shared_after == [0, 0, 0, 0, 0, 1, 2, 3, 4, 5], shared_after
+    assert torch.isfinite(tr.flat).all()
+    # the one-render modes and the evaluation protocol on the same loaded cameras (frames with PILtoTorch's strides
+    # are laid out as planes on the way in)
+    strided = sc.train_cameras[2].original_image.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    assert not strided.is_contiguous()
+    sc.train_cameras[2].original_image = strided
+    sc.event_cameras[2].original_image = sc.event_cameras[2].original_image.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    for mode in ("gray", "rgb", "event"):
+        t2 = fit.fit_event_scene(params, sc.train_cameras, sc.event_cameras, torch.zeros(3, device=DEV), DEV, iterations=3,
+                                 cameras_extent=sc.cameras_extent, rng=lambda a, b: 2, mode=mode)
+        assert torch.isfinite(t2.flat).all(), mode
+    res = scene_io.evaluate_views(lambda cam: tr.render_raw(cam, torch.zeros(3, device=DEV))["color"], sc.test_cameras,
+                                  index_list=(1, 3))
+    assert np.isfinite(res["psnr"]) and np.isfinite(res["ssim"])

@@ -146,6 +146,12 @@ def test_scene_directory_loader(tmp_path):
     # -r -1 caps the width at 1600 (utils/camera_utils.py:26-36): 1920x1080 -> 1600x900
     assert (sc.train_cameras[0].image_width, sc.train_cameras[0].image_height) == (1600, 900)
     assert sc.event_cameras[0].original_image.shape == (3, 48, 64)
+    # the event cameras are read with the training cameras' extrinsics / intrinsics (scene/dataset_readers.py:157): the
+    # event camera `index` is the training camera `index` seen again -- what EventTrainer's shared-pose iteration uses
+    for tc, ec in zip(sc.train_cameras, sc.event_cameras):
+        assert tc is not ec and tc.image_name == ec.image_name
+        assert torch.equal(tc.world_view_transform, ec.world_view_transform) and torch.equal(tc.camera_center, ec.camera_center)
+        assert (tc.FoVx, tc.FoVy) == (ec.FoVx, ec.FoVy)
     assert float(sc.event_cameras[0].original_image.max()) <= 1.0
     assert os.path.exists(sc.ply_path) and np.all(sc.point_cloud.colors == 0.5)          # --gray initial colours
     assert scene_io.target_resolution(1920, 1080, 1) == (1920, 1080)
