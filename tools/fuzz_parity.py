@@ -83,6 +83,28 @@ def run_hip(c):
     return img.detach().cpu().numpy(), radii.cpu().numpy(), grads, gw.numpy()
 
 
+def fp64_gradients(c, gw):
+    """Gradients of the same case from the PyTorch oracle in float64 (autograd): name -> array."""
+    kw = oracle_kwargs(c["act"], c["cam"], c["bg"], c["use_sh"], c["use_cov"], c["sh_degree"], c["scale_modifier"])
+    names = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "colors_precomp": "colors",
+             "cov3D_precomp": "cov3D", "scales": "scales", "rotations": "rotations"}
+    t64, leaves = {}, {}
+    for k, v in kw.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float32:
+            t64[k] = torch.from_numpy(v.astype(np.float64))
+            if k in names:
+                leaves[k] = t64[k].requires_grad_(True)
+        else:
+            t64[k] = v
+    m2 = torch.zeros(c["N"], 3, dtype=torch.float64, requires_grad=True)
+    img = torch_oracle.rasterize(**t64, means2D=m2)[0]
+    (img * torch.from_numpy(gw.astype(np.float64))).sum().backward()
+    out = {names[k]: t.grad.numpy() for k, t in leaves.items() if t.grad is not None}
+    if m2.grad is not None:
+        out["means2D"] = m2.grad.numpy()
+    return out
+
+
 def check(seed):
     c = make_case(seed)
     img, radii, grads, gw = run_hip(c)
@@ -96,6 +118,7 @@ def check(seed):
     if not np.isfinite(img).all():
         problems.append("non-finite image")
     gb = f.backward(gw)
+    fp64 = None
     for k, g in grads.items():
         ref = gb.get(k)
         if ref is None:
@@ -106,6 +129,19 @@ def check(seed):
             continue
         scale = float(np.linalg.norm(ref))
         err = rel_l2(g, ref) if scale > 1e-12 else float(np.abs(g).max())
+        if err > GRAD_TOL and c["N"] <= 64:
+            # A gradient that (nearly) cancels -- one Gaussian whose colour equals the background: seed 20660, |dL/do| =
+            # 5e-6 beside |dL/dmean| = 6 -- is ill-conditioned in fp32 for ANY formulation: the fp64 PyTorch oracle
+            # arbitrates, with the C oracle's own distance to it as the yardstick.
+            if fp64 is None:
+                fp64 = fp64_gradients(c, gw)
+            r64 = fp64.get(k)
+            if r64 is not None:
+                n64 = float(np.linalg.norm(r64)) + 1e-300
+                e_hip, e_c = float(np.linalg.norm(g - r64.reshape(g.shape))) / n64, float(np.linalg.norm(ref - r64.reshape(g.shape))) / n64
+                if e_hip <= max(GRAD_TOL, 2.0 * e_c):
+                    continue
+                err = e_hip
         if err > GRAD_TOL:
             problems.append("grad %s err %.3g (|ref| %.3g)" % (k, err, scale))
     desc = "seed %d: N=%d %dx%d boost %.2f r=%.1f sh=%s(%d) cov=%s mod=%.1f visible=%d I=%d" % (

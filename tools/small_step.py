@@ -12,7 +12,8 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 800
 kind = sys.argv[4] if len(sys.argv) > 4 else "trained"
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 30
-params = synth.make_scene(N, kind, seed=0, device=dev)
+from simple_knn._C import distCUDA2
+params = synth.make_scene(N, kind, seed=0, device=dev, dist2_fn=distCUDA2)
 cams = [orbit_camera(0, 64, W, H, device=dev, daz=d) for d in (0.0, 0.005, 0.015)]
 bg = torch.zeros(3, device=dev)
 gt = EventTrainer(params, dev)
