@@ -36,7 +36,10 @@ gt_tr = EventTrainer(gt_params, dev)
 q8 = lambda t: (torch.round(t.clamp(0, 1) * 255) / 255).contiguous()
 train, events = [], []
 for k in range(K):
-    for lst, daz in ((train, 0.0), (events, 0.003)):
+    # SOAK_SHARED=1: the event camera k carries the pose of the training camera k, as in the reference's datasets
+    # (scene/dataset_readers.py:157) -- the event pair is then (view k, view k + 1) and EventTrainer renders two views per
+    # iteration once the densification statistics are no longer collected
+    for lst, daz in ((train, 0.0), (events, 0.0 if os.environ.get("SOAK_SHARED") == "1" else 0.003)):
         c = orbit_camera(k, K, SIZE, SIZE, device=dev, daz=daz)
         c.original_image = q8(gt_tr.render_raw(c, bg)["color"])
         lst.append(c)
@@ -78,7 +81,8 @@ out = dict(iterations=ITERS, size=SIZE, background=BG, mode=MODE, gt_gaussians=N
            iters_per_s=round((ITERS - 10) / elapsed, 1), psnr_before=round(float(before["psnr"]), 2),
            psnr_after=round(float(after["psnr"]), 2), ssim_before=round(float(before["ssim"]), 4),
            ssim_after=round(float(after["ssim"]), 4), nonfinite_checks=log["nonfinite"],
-           gaussians_every_100=log["n"], loss_every_100=log["loss"], sh_degree=tr.active_sh_degree)
+           gaussians_every_100=log["n"], loss_every_100=log["loss"], sh_degree=tr.active_sh_degree,
+           shared_pose_iterations=tr.shared_pose_iterations)
 line = json.dumps(out)
 print(line)
 if os.path.isdir("gpurun_out"):
