@@ -977,6 +977,21 @@ def test_shared_pose_iteration_equals_three_renders():
     c = EventTrainer(params, DEV)
     c.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg)
     assert c.shared_pose_iterations == 0
+    # a camera moved in place afterwards (pose refinement) is noticed: the cached answer is tied to the tensors' versions
+    e = EventTrainer(params, DEV)
+    moved = orbit_camera(0, 16, W, H, device=DEV, daz=0.0)
+    e.compute_gradients(cams[0], moved, cams[2], gts[0], gts[1], gts[2], bg)
+    assert e.shared_pose_iterations == 1
+    other = orbit_camera(0, 16, W, H, device=DEV, daz=0.004)
+    for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+        getattr(moved, name).copy_(getattr(other, name))
+    e.compute_gradients(cams[0], moved, cams[2], gts[0], gts[1], gts[2], bg)
+    assert e.shared_pose_iterations == 1
+    f3 = EventTrainer(params, DEV)
+    f3.compute_gradients(cams[0], other, cams[2], gts[0], gts[1], gts[2], bg)
+    torch.cuda.synchronize()
+    for name in ("xyz", "features", "opacity"):
+        assert torch.equal(e.grads[name], f3.grads[name]), name          # really rendered at the new pose
     # densification statistics wanted: render #1's own screen-space gradient -> three renders; not wanted -> two
     d = EventTrainer(params, DEV, track_densification_stats=True)
     d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg)
