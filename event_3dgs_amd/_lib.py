@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 NOTIFY_FN = C.CFUNCTYPE(None, C.c_void_p)
@@ -75,6 +75,10 @@ def lib():
     L.e3dgs_rasterize_backward_multi.argtypes = (
         [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
         + [_ip] + [_cp] * 3 + [_fp] * 9 + [C.c_int, C.c_int, _vp])
+    L.e3dgs_rasterize_backward_multi_stats.restype = C.c_int
+    L.e3dgs_rasterize_backward_multi_stats.argtypes = (
+        [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
+        + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, C.c_int, _vp])
     L.e3dgs_sh_grad_from_colour.restype = C.c_int
     L.e3dgs_sh_grad_from_colour.argtypes = [C.c_int] * 5 + [_fp, _fp, C.c_size_t, C.c_float, _fp, C.c_int, _vp]
     L.e3dgs_sh_adam_from_colour.restype = C.c_int
@@ -176,7 +180,7 @@ ACC_STRIDE = 12
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
     "e3dgs_rasterize_backward", "e3dgs_rasterize_forward_multi", "e3dgs_rasterize_forward_multi_begin",
-    "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi",
+    "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi", "e3dgs_rasterize_backward_multi_stats",
     "e3dgs_sh_grad_from_colour", "e3dgs_sh_adam_from_colour",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",

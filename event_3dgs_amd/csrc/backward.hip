@@ -20,12 +20,21 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 #ifndef E3_BWD_WAVES
 #define E3_BWD_WAVES 6
 #endif
-__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(
+// STATS (shared-pose iterations that also collect densification statistics, EventTrainer.compute_gradients): view 0 is
+// the render that train.py:144 and :159 both produce; its backward carries the SUM of the two loss terms' pixel
+// gradients, while the statistics (train.py:145,317-320) want the screen-space mean gradient under the intensity term's
+// pixel gradient `dL_dpix2` ALONE.  The backward is linear in the pixel gradient, so the tiles of view 0 run a second
+// dL/dalpha chain on dL_dpix2 next to the first -- sharing G, alpha, T and the keep decisions -- and store its two
+// screen-space sums per instance in `part2` (2 floats at the instance's slot).  The default instantiation is unchanged.
+template <bool STATS>
+__global__ __launch_bounds__(BWD_WAVES * WAVE, STATS ? 5 : E3_BWD_WAVES) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
-    float* __restrict__ part /* (I,9) per-instance records at their SLOTS, packed: mx my A B C o c0 c1 c2 */) {
+    float* __restrict__ part /* (I,9) per-instance records at their SLOTS, packed: mx my A B C o c0 c1 c2 */,
+    const float* __restrict__ dL_dpix2 /* STATS: (3,H,W) second pixel gradient of view 0 */,
+    float* __restrict__ part2 /* STATS: (I,2) NDC-unit screen-space mean gradient under dL_dpix2, view-0 slots */) {
     // the 64 staged records of a round, 48 B each: one LDS address per entry, the three 16-B broadcasts are immediate
     // offsets of it (three separate arrays cost two more address adds per entry); 48-B stride keeps the staging stores
     // conflict-free (8 lanes x 16 B per LDS cycle land on 32 distinct banks)
@@ -38,8 +47,9 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
     // The LDS pipe is otherwise idle in this kernel.  Reduced sums are parked in sPart and committed every 16
     // entries by lanes 0..15 as three 16-byte stores into the instance's own record (no atomics: the per-Gaussian
     // sum over its instances happens in geom_bwd_kernel, in a fixed order -> deterministic gradients).
-    __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][9][68];        // per-entry transpose buffer: [value][lane], rows padded to 68
+    __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][STATS ? 11 : 9][68];   // per-entry transpose buffer: [value][lane], rows padded to 68
     __shared__ __attribute__((aligned(16))) float sPart[BWD_WAVES][16][16];     // [entry & 15][16 floats]: reduced sums parked until the commit
+    __shared__ float sPart2[STATS ? BWD_WAVES : 1][16][2];                      // STATS: the two extra sums of an entry
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4_t LdsF4;
@@ -72,6 +82,8 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
     //   Q_g = T_final (bg . dL/dC) + sum_{j>g} a_j T_j (c_j . dL/dC),
     // instead of the reference's accumulated colour / last colour / last alpha (7 registers -> 1).
     float pfy[4], T[4], Q[4], dp0[4], dp1[4], dp2[4];
+    float dq0[4], dq1[4], dq2[4], Q2[4];                       // STATS: the second chain's pixel gradient and running sum
+    const bool sv = STATS && view == 0;                        // (wave-uniform)
     uint32_t last[4];
     uint32_t maxc = 0;
 #pragma unroll
@@ -86,6 +98,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
         dp1[k] = inside ? dL_dpix[HW + pix] : 0.0f;
         dp2[k] = inside ? dL_dpix[2 * HW + pix] : 0.0f;
         Q[k] = T[k] * FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
+        if (STATS) {
+            dq0[k] = (sv && inside) ? dL_dpix2[pix] : 0.0f;
+            dq1[k] = (sv && inside) ? dL_dpix2[HW + pix] : 0.0f;
+            dq2[k] = (sv && inside) ? dL_dpix2[2 * HW + pix] : 0.0f;
+            Q2[k] = T[k] * FMA(bg0, dq0[k], FMA(bg1, dq1[k], bg2 * dq2[k]));
+        }
         maxc = last[k] > maxc ? last[k] : maxc;
     }
     maxc = wave_max_u32(maxc);
@@ -163,6 +181,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
                 // dx Uy (three multiplications per entry instead of five more operations per pixel), and o is applied
                 // to the reduced sums by the commit lanes.
                 float Uy = 0.0f, Uyy = 0.0f, So = 0.0f, Sc0 = 0.0f, Sc1 = 0.0f, Sc2 = 0.0f;
+                float So2 = 0.0f, Uy2 = 0.0f;               // STATS: sum u', sum u' dy of the second chain
                 unsigned long long any = 0ull;              // lanes that composited this entry at one of their pixels
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -216,6 +235,14 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
                             const float uy = u * dy;
                             So += u; Uy += uy;
                             Uyy = FMA(uy, dy, Uyy);
+                            if (STATS && sv) {                              // the same formulas on the second pixel gradient
+                                const float cd2 = FMA(b.z, dq0[k], FMA(b.w, dq1[k], c.x * dq2[k]));
+                                const float dL_dalpha2 = FMA(T[k], cd2, -(Q2[k] * inv_one_m));
+                                Q2[k] = FMA(w, cd2, Q2[k]);
+                                const float u2 = G * dL_dalpha2;
+                                const float uy2 = u2 * dy;
+                                So2 += u2; Uy2 += uy2;
+                            }
                         }
                     }
                 }
@@ -227,6 +254,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
                     r[0 * 68 + lane] = Sx;  r[1 * 68 + lane] = Uy;  r[2 * 68 + lane] = dx * Sx;
                     r[3 * 68 + lane] = dx * Uy; r[4 * 68 + lane] = Uyy; r[5 * 68 + lane] = So;
                     r[6 * 68 + lane] = Sc0; r[7 * 68 + lane] = Sc1; r[8 * 68 + lane] = Sc2;
+                    if (STATS && sv) { r[9 * 68 + lane] = dx * So2; r[10 * 68 + lane] = Uy2; }
                     wave_sync();
                     // lane (v, p) = (lane >> 3, lane & 7) adds the 8 floats [8p, 8p + 8) of value v (two ds_read_b128) and ONE
                     // float of the ninth value (Sc2): its 64 floats are spread over all lanes instead of a masked second
@@ -245,6 +273,17 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
                     if (rp == 0) {                           // slots 0..7 = Sx Sy Sxx Sxy Syy So Sc0 Sc1, 8..15 = partials of Sc2
                         float* pe = reinterpret_cast<float*>(part_base_ptr + (size_t)(j & 15) * 16);
                         pe[rv] = s; pe[8 + rv] = s8;
+                    }
+                    if (STATS && sv) {                       // rows 9, 10 (Sx', Sy'): the same 8-float reads + three DPP adds
+                        const int rr = 9 + (rv & 1);
+                        const float4 t0 = *reinterpret_cast<const float4*>(r + rr * 68 + 8 * rp);
+                        const float4 t1 = *reinterpret_cast<const float4*>(r + rr * 68 + 8 * rp + 4);
+                        float t = ((t0.x + t0.y) + (t0.z + t0.w)) + ((t1.x + t1.y) + (t1.z + t1.w));
+                        t += dpp_f<DPP_QUAD_XOR1>(t);
+                        t += dpp_f<DPP_QUAD_XOR2>(t);
+                        t += dpp_bc_f<DPP_ROW_SHL4>(t);
+                        asm volatile("" : "+v"(t));
+                        if (rp == 0 && rv < 2) sPart2[wave][j & 15][rv] = t;
                     }
                     wave_sync();
                 }
@@ -271,6 +310,12 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
                     g[0] = F3{-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy, -0.5f * p0.z};
                     g[1] = F3{-p0.w, -0.5f * p1.x, p1.y};
                     g[2] = F3{p1.z, p1.w, p2};
+                    if (STATS && sv) {                       // the same mean2D formula on the second chain's sums
+                        const float sx = hit ? sPart2[wave][lane][0] * eb.y : 0.0f, sy = hit ? sPart2[wave][lane][1] * eb.y : 0.0f;
+                        float* g2 = part2 + 2 * (size_t)__float_as_uint(sRec[wave][e].c.w);
+                        g2[0] = -(ea.z * sx + ea.w * sy) * ddelx_dx;
+                        g2[1] = -(eb.x * sy + ea.w * sx) * ddely_dy;
+                    }
                 }
                 wave_sync();
             }
@@ -285,6 +330,7 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_ker
         F3* g = reinterpret_cast<F3*>(part + E3_REC_FLOATS * (size_t)perm[e]);
         const F3 z3 = F3{0.0f, 0.0f, 0.0f};
         g[0] = z3; g[1] = z3; g[2] = z3;
+        if (STATS && sv) { part2[2 * (size_t)perm[e]] = 0.0f; part2[2 * (size_t)perm[e] + 1] = 0.0f; }
     }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;
@@ -541,6 +587,31 @@ __global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const 
     }
 }
 
+// STATS (render_bwd_kernel<true>): per-splat sums of the second chain's two floats per instance, for the splats of view
+// 0 only, into the free components .y / .z of the splat's third sum vector (run_reduce_kernel wrote (c2, 0, 0, 0)
+// there: this kernel runs after it).  One thread per kept splat, its run added in slot order (fixed order).
+__global__ __launch_bounds__(256) void run_reduce_stats_kernel(const uint32_t* __restrict__ order,
+                                                               const uint2* __restrict__ run_sorted,
+                                                               const float* __restrict__ part2, float4* __restrict__ gsum,
+                                                               const uint32_t* __restrict__ nvis,
+                                                               const uint8_t* __restrict__ touched, uint32_t nviews,
+                                                               const uint32_t* __restrict__ count_dev, uint32_t capacity) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= *nvis) return;
+    if (count_dev && *count_dev > capacity) return;
+    const size_t q = order[j];
+    if (q % nviews != 0) return;                     // splat q = Gaussian * nviews + view
+    const uint2 rn = run_sorted[j];
+    float sx = 0.0f, sy = 0.0f;
+    for (uint32_t r = rn.x; r < rn.x + rn.y; ++r) {
+        if (touched[r] == 0) continue;
+        sx += part2[2 * (size_t)r]; sy += part2[2 * (size_t)r + 1];
+    }
+    float4 v = gsum[3 * q + 2];
+    v.y = sx; v.z = sy;
+    gsum[3 * q + 2] = v;
+}
+
 __device__ __forceinline__ void load_sums(const float4* __restrict__ gsum, size_t q, float g12[9]) {
     const float4 s0 = gsum[3 * q], s1 = gsum[3 * q + 1];
     const float s2 = gsum[3 * q + 2].x;
@@ -747,6 +818,7 @@ struct MultiViews {
     const int* radii;          // (n, P)
     const uint32_t* clamped;   // per splat q = i * n + v
     const float4* gsum;        // per splat: summed gradient records (run_reduce_kernel)
+    int stats;                 // view 0's screen-space output comes from the second chain's sums (gsum[3q+2].y/.z)
 };
 
 // real SH basis function k and its gradient w.r.t. the unit direction (same constants as sh_backward)
@@ -839,7 +911,10 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             for (int k = 0; k < 6; ++k) gcov[k] += gcv[k];
             gmean[0] += gmv[0]; gmean[1] += gmv[1]; gmean[2] += gmv[2];
             gopac += g12[5];
-            if (v == 0) { m2x = g12[0]; m2y = g12[1]; }
+            if (v == 0) {
+                if (mv.stats) { const float4 s2 = mv.gsum[3 * q + 2]; m2x = s2.y; m2y = s2.z; }
+                else { m2x = g12[0]; m2y = g12[1]; }
+            }
             const uint32_t cl = mv.clamped[q];
             o_g0 = (cl & 1u) ? 0.0f : g12[6];
             o_g1 = (cl & 2u) ? 0.0f : g12[7];
@@ -1071,7 +1146,8 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                      const int* radii, const char* geom_buffer, const char* binning_buffer,
                      const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                     float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s, float* dL_dcolour_views) {
+                     float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s, float* dL_dcolour_views,
+                     const float* dL_dpix_stats) {
     (void)colors;
     if (P <= 0) return 0;
     const ViewSet vs = make_view_set(views, W, H, scale_modifier);
@@ -1089,9 +1165,17 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
         const int nslots = launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, img.work, img.order_bwd, s);
-        render_bwd_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-            g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-            background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc);
+        // (STATS: the second chain's records sit in the slack between the packed 9-float records and the per-splat sums:
+        // the caller provides E3_ACC_STRIDE = 12 floats per instance)
+        float* part2 = grad_acc + E3_REC_FLOATS * (size_t)num_rendered;
+        if (dL_dpix_stats)
+            render_bwd_kernel<true><<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+                g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, dL_dpix_stats, part2);
+        else
+            render_bwd_kernel<false><<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+                g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, nullptr, nullptr);
     }
     KERNEL_OK("render_bwd_kernel");
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;
@@ -1119,6 +1203,10 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         hipError_t me = hipMemsetAsync(gsum, 0, Q * 3 * sizeof(float4), s);
         if (me != hipSuccess) return e3_fail(me, "hipMemsetAsync(gsum)");
     }
+    if (dL_dpix_stats && num_rendered > 0)
+        run_reduce_stats_kernel<<<dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s>>>(
+            geom.ord0, geom.run, grad_acc + E3_REC_FLOATS * (size_t)num_rendered, gsum, geom.nvis, bin.touched, (uint32_t)nv,
+            count_dev, (uint32_t)num_rendered);
     if (nv == 1 && !dL_dcolour_views) {
         // instantiation: accumulate or overwrite x SH degree x (P, M, 3) rows movable as float4 (16-byte aligned rows of the
         // reference layout, overwrite mode)
@@ -1146,6 +1234,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         // gradient element written once (capi.hip checked the argument subset)
         MultiViews mv;
         mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.gsum = gsum;
+        mv.stats = (dL_dpix_stats && num_rendered > 0) ? 1 : 0;
         geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
             dL_dscale, dL_drot, dL_dcolour_views);

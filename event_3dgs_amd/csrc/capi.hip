@@ -70,7 +70,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 11; }
+int e3dgs_abi_version(void) { return 12; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -348,16 +348,16 @@ int e3dgs_rasterize_forward_multi_capacity(e3dgs_alloc_fn geom_alloc, void* geom
                                   P > 0 ? 1 : 0);
 }
 
-int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,
-                                   int width, int height, const float* means3D, const float* shs,
-                                   const float* opacities, const float* scales, float scale_modifier,
-                                   const float* rotations, const float* const* viewmatrix,
-                                   const float* const* projmatrix, const float* const* cam_pos, const float* tan_fovx,
-                                   const float* tan_fovy, const int* radii, const char* geom_buffer,
-                                   const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
-                                   float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
-                                   float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug,
-                                   int flags, void* stream) {
+static int backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,
+                          int width, int height, const float* means3D, const float* shs,
+                          const float* opacities, const float* scales, float scale_modifier,
+                          const float* rotations, const float* const* viewmatrix,
+                          const float* const* projmatrix, const float* const* cam_pos, const float* tan_fovx,
+                          const float* tan_fovy, const int* radii, const char* geom_buffer,
+                          const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
+                          float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
+                          float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug,
+                          int flags, void* stream, const float* dL_dpix_view0_stats) {
     g_err[0] = 0;
     ViewBatch vb;
     int rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
@@ -371,10 +371,48 @@ int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rend
     rc = check_backward_args(2, P, shs, nullptr, opacities, nullptr, grad_acc, dL_dopacity, nullptr, dL_dmean3D,
                              nullptr, (dL_dsh || !dL_dcolour_views) ? dL_dsh : &dummy_sh, dL_dscale, dL_drot, flags);
     if (rc) return rc;
+    if (dL_dpix_view0_stats && nviews < 2 && !dL_dcolour_views)
+        return e3_fail(hipErrorInvalidValue, "dL_dpix_view0_stats needs the multi-view per-Gaussian kernel (nviews >= 2 or dL_dcolour_views)");
+    if (dL_dpix_view0_stats && !dL_dmean2D)
+        return e3_fail(hipErrorInvalidValue, "dL_dpix_view0_stats without dL_dmean2D: nothing would read the second chain");
     return e3_backward_impl(vb, P, D, M, num_rendered, background, width, height, means3D, shs, nullptr, opacities,
                             scales, scale_modifier, rotations, nullptr, radii, geom_buffer, binning_buffer, image_buffer,
                             dL_dpix, grad_acc, dL_dmean2D, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_dsh, dL_dscale,
-                            dL_drot, debug, flags, (hipStream_t)stream, dL_dcolour_views);
+                            dL_drot, debug, flags, (hipStream_t)stream, dL_dcolour_views, dL_dpix_view0_stats);
+}
+
+int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,
+                                   int width, int height, const float* means3D, const float* shs,
+                                   const float* opacities, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* const* viewmatrix,
+                                   const float* const* projmatrix, const float* const* cam_pos, const float* tan_fovx,
+                                   const float* tan_fovy, const int* radii, const char* geom_buffer,
+                                   const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
+                                   float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
+                                   float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug,
+                                   int flags, void* stream) {
+    return backward_multi(nviews, P, D, M, num_rendered, background, width, height, means3D, shs, opacities, scales,
+                          scale_modifier, rotations, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+                          geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D, dL_dopacity,
+                          dL_dmean3D, dL_dsh, dL_dscale, dL_drot, dL_dcolour_views, debug, flags, stream, nullptr);
+}
+
+int e3dgs_rasterize_backward_multi_stats(int nviews, int P, int D, int M, int num_rendered, const float* background,
+                                         int width, int height, const float* means3D, const float* shs,
+                                         const float* opacities, const float* scales, float scale_modifier,
+                                         const float* rotations, const float* const* viewmatrix,
+                                         const float* const* projmatrix, const float* const* cam_pos,
+                                         const float* tan_fovx, const float* tan_fovy, const int* radii,
+                                         const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                                         const float* dL_dpix, const float* dL_dpix_view0_stats, float* grad_acc,
+                                         float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D, float* dL_dsh,
+                                         float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug, int flags,
+                                         void* stream) {
+    return backward_multi(nviews, P, D, M, num_rendered, background, width, height, means3D, shs, opacities, scales,
+                          scale_modifier, rotations, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+                          geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D, dL_dopacity,
+                          dL_dmean3D, dL_dsh, dL_dscale, dL_drot, dL_dcolour_views, debug, flags, stream,
+                          dL_dpix_view0_stats);
 }
 
 int e3dgs_sh_grad_from_colour(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,

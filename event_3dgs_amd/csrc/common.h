@@ -352,7 +352,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                      const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                      float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s,
-                     float* dL_dcolour_views = nullptr);
+                     float* dL_dcolour_views = nullptr, const float* dL_dpix_stats = nullptr);
 int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* dL_dsh, int flags, hipStream_t s);
 

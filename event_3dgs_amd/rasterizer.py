@@ -616,11 +616,14 @@ def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flag
     return forward_multi_finish(pend)
 
 
-def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
+def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None, stats_grad_view0=None):
     """e3dgs_rasterize_backward_multi for a forward_multi result.  grad_out_color is (n,3,H,W); `out` maps
     means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are fully overwritten
     with the gradient summed over the views.  Optional `colour_views` (n,P,3): the per-view clamp-masked colour
-    gradients (then `sh` may be omitted; see sh_grad_from_colour)."""
+    gradients (then `sh` may be omitted; see sh_grad_from_colour).
+    stats_grad_view0 (3,H,W): e3dgs_rasterize_backward_multi_stats -- out["means2D"] is the screen-space gradient view 0
+    has under THAT pixel gradient, everything else follows grad_out_color (shared-pose iterations that collect
+    densification statistics)."""
     L = _lib.lib()
     rs = raw["settings"]
     sl = raw["settings_list"]
@@ -646,15 +649,21 @@ def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None):
         grad_acc = torch.empty(int(raw["num_rendered"]) + len(sl) * P, _lib.ACC_STRIDE, dtype=torch.float32,
                                device=dev)
     arrays, keep = _view_arrays(sl)
-    with torch.cuda.device(dev):
-        rc = L.e3dgs_rasterize_backward_multi(
-            len(sl), P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(raw["bg"]), W, H, _lib.ptr(means3D),
+    head = (len(sl), P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(raw["bg"]), W, H, _lib.ptr(means3D),
             _lib.ptr(sh), _lib.ptr(raw.get("opacities")), _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots),
-            *arrays, _lib.ptr(raw["radii"]), _lib.ptr(raw["geom"]), _lib.ptr(raw["binning"]), _lib.ptr(raw["image"]),
-            _lib.ptr(g), _lib.ptr(grad_acc), _lib.ptr(out.get("means2D")), _lib.ptr(out.get("opacities")),
+            *arrays, _lib.ptr(raw["radii"]), _lib.ptr(raw["geom"]), _lib.ptr(raw["binning"]), _lib.ptr(raw["image"]))
+    tail = (_lib.ptr(grad_acc), _lib.ptr(out.get("means2D")), _lib.ptr(out.get("opacities")),
             _lib.ptr(out.get("means3D")), _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")),
             _lib.ptr(out.get("rots")), _lib.ptr(out.get("colour_views")), int(bool(rs.debug)), int(flags),
             _lib.current_stream())
+    with torch.cuda.device(dev):
+        if stats_grad_view0 is None:
+            rc = L.e3dgs_rasterize_backward_multi(*head, _lib.ptr(g), *tail)
+        else:
+            g2 = stats_grad_view0
+            if not (g2.is_cuda and g2.dtype == torch.float32 and g2.is_contiguous() and tuple(g2.shape) == (3, H, W)):
+                raise ValueError("stats_grad_view0 must be a contiguous fp32 (3,H,W) GPU tensor")
+            rc = L.e3dgs_rasterize_backward_multi_stats(*head, _lib.ptr(g), _lib.ptr(g2), *tail)
     _lib.check(rc, "e3dgs_rasterize_backward_multi")
 
 

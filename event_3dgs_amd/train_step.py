@@ -136,6 +136,7 @@ class EventTrainer:
         self.share_coincident_views = os.environ.get("E3DGS_SHARE_VIEWS", "1") != "0"
         self.shared_pose_iterations = 0
         self._coincide = {}
+        self._dstat = None             # render #1's own pixel gradient on shared-pose iterations that collect statistics
         self._capacity = {}            # (N, views, H, W) -> instances the binning buffers are sized for
         self.count_retries = 0         # iterations repeated because the count exceeded the capacity
         self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
@@ -515,8 +516,10 @@ class EventTrainer:
         (scene/dataset_readers.py:157), so train.py:144 and :159 render the same image twice -- it is rendered ONCE: its
         image feeds the intensity and the contrast term and its backward receives the sum of the two pixel gradients
         (the backward is linear in them).  Same loss, same image bits, gradients equal to summation order, two thirds of
-        the work.  Not taken when the screen-space gradient of render #1 ALONE is needed (densification statistics,
-        train.py:145,317-320): viewspace_grad=False says it is not (fit.fit_event_scene passes the schedule's answer).
+        the work.  When the densification statistics are collected (track_densification_stats, train.py:145,317-320) they
+        need the screen-space gradient of render #1 ALONE: the shared view's tiles then run a second dL/dalpha chain on
+        render #1's own pixel gradient (e3dgs_rasterize_backward_multi_stats); viewspace_grad=False says the statistics
+        are not updated this iteration (fit.fit_event_scene passes the schedule's answer) and saves that chain.
         The returned scalars tensor, `last_scalars` and `last_radii` are VIEWS of persistent buffers that the next
         iteration overwrites (step() / step_image() return clones)."""
         v = self.views
@@ -537,7 +540,7 @@ class EventTrainer:
                                  "E3DGS_FACTORIZE_SH=0) for datasets that mix resolutions")
             return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
         need_vs = self.track_stats and viewspace_grad
-        shared = self.share_coincident_views and not need_vs and self._views_coincide(cam_int, cam_now, settings)
+        shared = self.share_coincident_views and self._views_coincide(cam_int, cam_now, settings)
         if shared:
             settings = [settings[0], settings[2]]
         self.shared_pose_iterations += int(shared)
@@ -614,17 +617,28 @@ class EventTrainer:
         sc = sc2[self._loss_flip]
         # (dL/dc goes straight into the threshold's slot of the flat gradient buffer: no copy kernel)
         i_now, i_next = (0, 1) if shared else (1, 2)
+        want_vs = self.track_stats and viewspace
+        d_int = dpix[0]
+        if shared and want_vs:
+            # the statistics need render #1's OWN screen-space gradient: its pixel gradient is kept apart (d_int), the
+            # shared view's backward gets the sum, and a second dL/dalpha chain in the tiles of view 0 carries d_int
+            # (e3dgs_rasterize_backward_multi_stats)
+            if self._dstat is None or self._dstat.shape != dpix[0].shape:
+                self._dstat = torch.empty_like(dpix[0])
+            d_int = self._dstat
         scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[i_now], imgs[i_next], self.c, gt_int, gt_now, gt_next, gt_blur,
-                                                 out=(sc, dpix[0], dpix[i_now], dpix[i_next], scratch),
+                                                 out=(sc, d_int, dpix[i_now], dpix[i_next], scratch),
                                                  dc_out=self.c_grad)                                                   # train.py:165-203
+        if shared and want_vs:
+            dpix[0].add_(d_int)
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.factorize_sh or sh_via_colour:
             self._colour_gradients_instead_of_sh(out, settings, pad_to=3 if self.world > 1 else None)
-        if self.track_stats and viewspace:
+        if want_vs:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
-        rasterizer.backward_multi(raw, dpix, out)
+        rasterizer.backward_multi(raw, dpix, out, stats_grad_view0=d_int if (shared and want_vs) else None)
         return scalars, raw
 
     def _compute_gradients_separate(self, settings, gt_int, gt_now, gt_next, gt_blur):

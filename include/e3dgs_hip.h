@@ -287,6 +287,32 @@ int e3dgs_rasterize_backward_multi(
     int debug, int flags, void* stream);
 
 /*
+ * The same backward for an iteration whose view 0 stands for TWO renders of the reference (render #1 and render #2 of
+ * an event iteration share their pose: the event cameras are read with the training cameras' extrinsics,
+ * scene/dataset_readers.py:157).  dL_dpix[0] holds the SUM of the two renders' pixel gradients; the densification
+ * statistics (train.py:145,317-320) need the screen-space mean gradient of render #1 ALONE:
+ * dL_dpix_view0_stats (3,H,W) is that render's own pixel gradient, and dL_dmean2D receives the gradient it induces
+ * (a second dL/dalpha chain beside the first in the tiles of view 0; every other output is that of
+ * e3dgs_rasterize_backward_multi).  dL_dmean2D is required.
+ */
+int e3dgs_rasterize_backward_multi_stats(
+    int nviews, int P, int D, int M, int num_rendered,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations,
+    const float* const* viewmatrix, const float* const* projmatrix, const float* const* cam_pos,
+    const float* tan_fovx, const float* tan_fovy,
+    const int* radii,
+    const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    const float* dL_dpix,             /* (nviews,3,H,W) */
+    const float* dL_dpix_view0_stats, /* (3,H,W) */
+    float* grad_acc,
+    float* dL_dmean2D,                /* (P,3): view 0 under dL_dpix_view0_stats */
+    float* dL_dopacity, float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    float* dL_dcolour_views,
+    int debug, int flags, void* stream);
+
+/*
  * SH gradient from per-view colour gradients:  dL/dsh[k][ch] = scale * sum over all views of
  * Y_k(direction from the view's camera centre to the Gaussian) * dL/dcolour_view[ch].
  * New capability for view-parallel data parallelism (north_star: train.py's loop sharded by camera with an

@@ -992,19 +992,36 @@ def test_shared_pose_iteration_equals_three_renders():
     torch.cuda.synchronize()
     for name in ("xyz", "features", "opacity"):
         assert torch.equal(e.grads[name], f3.grads[name]), name          # really rendered at the new pose
-    # densification statistics wanted: render #1's own screen-space gradient -> three renders; not wanted -> two
-    d = EventTrainer(params, DEV, track_densification_stats=True)
-    d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg)
-    assert d.shared_pose_iterations == 0 and float(d.viewspace_grad.abs().sum()) > 0
+    # densification statistics wanted: render #1's OWN screen-space gradient (train.py:145,317-320) -- the shared view's
+    # tiles run a second dL/dalpha chain on render #1's pixel gradient (e3dgs_rasterize_backward_multi_stats): same
+    # statistics input as with three renders, and the same parameter gradients as without statistics
+    for gt_blur in (None, blur):
+        d = EventTrainer(params, DEV, track_densification_stats=True)
+        d3 = EventTrainer(params, DEV, track_densification_stats=True)
+        d3.share_coincident_views = False
+        sd = d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur).clone()
+        s3 = d3.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur).clone()
+        torch.cuda.synchronize()
+        assert d.shared_pose_iterations == 1 and d3.shared_pose_iterations == 0
+        assert torch.equal(sd[:6], s3[:6])
+        va, vb = d.viewspace_grad.cpu().numpy(), d3.viewspace_grad.cpu().numpy()
+        assert np.abs(vb).max() > 0 and np.all(va[:, 2] == 0)
+        assert rel_l2(va, vb) <= 1e-5, rel_l2(va, vb)
+        # ... and it is NOT the gradient of the summed pixel gradients
+        n = EventTrainer(params, DEV)
+        n.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+        for name in ("xyz", "features", "opacity", "scaling", "rotation"):
+            assert torch.equal(d.grads[name], n.grads[name]), name          # the first chain is untouched by the second
+            assert rel_l2(d.grads[name].cpu().numpy(), d3.grads[name].cpu().numpy()) <= 1e-5, name
     d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, viewspace_grad=False)
-    assert d.shared_pose_iterations == 1
+    assert d.shared_pose_iterations == 2
 
 
 def test_scene_directory_to_shared_pose_training(tmp_path):
     """A scene directory in the reference's layout (sparse/0 + images + images_event: the golden COLMAP model with random
     frames) -> load_colmap_scene -> create_from_pcd -> fit_event_scene.  The loader gives event camera `index` the pose
-    of training camera `index` (as scene/dataset_readers.py:157 does), so once the densification statistics are no
-    longer collected (iteration >= densify_until_iter) every event iteration renders two views instead of three."""
+    of training camera `index` (as scene/dataset_readers.py:157 does), so every event iteration renders two views instead
+    of three -- with the statistics chain while the densification statistics are collected."""
     import shutil
     from PIL import Image
     from event_3dgs_amd import fit, scene_io
@@ -1028,8 +1045,8 @@ def test_scene_directory_to_shared_pose_training(tmp_path):
                              densification_interval=2, rng=lambda a, b: 2,
                              on_iteration=lambda it, t, s: shared_after.append(t.shared_pose_iterations))
     torch.cuda.synchronize()
-    # iterations 1..5 collect statistics (render #1's own screen-space gradient: three renders); 6..10 share
-    assert shared_after == [0, 0, 0, 0, 0, 1, 2, 3, 4, 5], shared_after
+    # every iteration shares the pose; 1..5 also collect statistics (second chain for render #1's own screen-space gradient)
+    assert shared_after == list(range(1, 11)), shared_after
     assert torch.isfinite(tr.flat).all()
     # the one-render modes and the evaluation protocol on the same loaded cameras (frames with PILtoTorch's strides
     # are laid out as planes on the way in)
