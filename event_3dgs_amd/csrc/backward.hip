@@ -20,6 +20,9 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 #ifndef E3_BWD_WAVES
 #define E3_BWD_WAVES 6
 #endif
+#ifndef E3_BWD_STATS_WAVES
+#define E3_BWD_STATS_WAVES 5      // render_bwd_kernel<true> (second gradient chain: +16 VGPRs)
+#endif
 // STATS (shared-pose iterations that also collect densification statistics, EventTrainer.compute_gradients): view 0 is
 // the render that train.py:144 and :159 both produce; its backward carries the SUM of the two loss terms' pixel
 // gradients, while the statistics (train.py:145,317-320) want the screen-space mean gradient under the intensity term's
@@ -27,7 +30,7 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 // dL/dalpha chain on dL_dpix2 next to the first -- sharing G, alpha, T and the keep decisions -- and store its two
 // screen-space sums per instance in `part2` (2 floats at the instance's slot).  The default instantiation is unchanged.
 template <bool STATS>
-__global__ __launch_bounds__(BWD_WAVES * WAVE, STATS ? 5 : E3_BWD_WAVES) void render_bwd_kernel(
+__global__ __launch_bounds__(BWD_WAVES * WAVE, STATS ? E3_BWD_STATS_WAVES : E3_BWD_WAVES) void render_bwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
