@@ -137,6 +137,7 @@ class EventTrainer:
         self.shared_pose_iterations = 0
         self._coincide = {}
         self._dstat = None             # render #1's own pixel gradient on shared-pose iterations that collect statistics
+        self._instances_per_view = 0.0 # of the last forward whose count is known (_note_count)
         self._capacity = {}            # (N, views, H, W) -> instances the binning buffers are sized for
         self.count_retries = 0         # iterations repeated because the count exceeded the capacity
         self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
@@ -486,7 +487,11 @@ class EventTrainer:
         raw["capacity_key"] = key
         return raw
 
+    SHARE_STATS_MIN_INSTANCES = 500_000      # per view, and
+    SHARE_STATS_MIN_TILES = 4096             # tiles per view: below either, statistics iterations keep three renders
+
     def _note_count(self, key, count):
+        self._instances_per_view = count / max(int(key[1]), 1)
         if not self.no_host_wait:
             return
         cap = self._capacity.get(key)
@@ -541,6 +546,14 @@ class EventTrainer:
             return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
         need_vs = self.track_stats and viewspace_grad
         shared = self.share_coincident_views and self._views_coincide(cam_int, cam_now, settings)
+        if shared and need_vs:
+            # launches that do not fill the GPU several times over gain nothing: a third view composites beside the other
+            # two for almost nothing, while the second gradient chain lengthens the tiles that decide the launch's
+            # duration (800 x 800: 30 k Gaussians 0.53 ms with three renders, 0.55 ms shared + statistics, 200 k: 0.95 /
+            # 0.91; 1080p: 500 k 1.96 / 1.74, 1 M 2.52 / 2.25 -- tools/shared_pose_time.py)
+            tiles = ((settings[0].image_width + 15) // 16) * ((settings[0].image_height + 15) // 16)
+            if tiles < self.SHARE_STATS_MIN_TILES or self._instances_per_view < self.SHARE_STATS_MIN_INSTANCES:
+                shared = False
         if shared:
             settings = [settings[0], settings[2]]
         self.shared_pose_iterations += int(shared)

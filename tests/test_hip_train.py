@@ -997,6 +997,7 @@ def test_shared_pose_iteration_equals_three_renders():
     # statistics input as with three renders, and the same parameter gradients as without statistics
     for gt_blur in (None, blur):
         d = EventTrainer(params, DEV, track_densification_stats=True)
+        d.SHARE_STATS_MIN_INSTANCES = d.SHARE_STATS_MIN_TILES = 0      # (by default only launches that fill the GPU take this path)
         d3 = EventTrainer(params, DEV, track_densification_stats=True)
         d3.share_coincident_views = False
         sd = d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, gt_blur=gt_blur).clone()
@@ -1015,6 +1016,11 @@ def test_shared_pose_iteration_equals_three_renders():
             assert rel_l2(d.grads[name].cpu().numpy(), d3.grads[name].cpu().numpy()) <= 1e-5, name
     d.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg, viewspace_grad=False)
     assert d.shared_pose_iterations == 2
+    # default threshold: a launch this small keeps three renders on statistics iterations
+    small = EventTrainer(params, DEV, track_densification_stats=True)
+    small.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg)
+    small.compute_gradients(cams[0], same, cams[2], gts[0], gts[1], gts[2], bg)
+    assert small.shared_pose_iterations == 0 and 0 < small._instances_per_view < small.SHARE_STATS_MIN_INSTANCES
 
 
 def test_scene_directory_to_shared_pose_training(tmp_path):
@@ -1039,14 +1045,23 @@ def test_scene_directory_to_shared_pose_training(tmp_path):
             Image.fromarray(rs.randint(0, 256, (48, 64, 3), dtype=np.uint8)).save(os.path.join(root, d, im.name))
     sc = scene_io.load_colmap_scene(root, gray=True, event=True, device=DEV)
     params = scene_io.create_from_pcd(sc.point_cloud, sc.cameras_extent, distCUDA2, device=DEV)
-    shared_after = []
-    tr = fit.fit_event_scene(params, sc.train_cameras, sc.event_cameras, torch.zeros(3, device=DEV), DEV, iterations=10,
-                             cameras_extent=sc.cameras_extent, densify_until_iter=6, densify_from_iter=2,
-                             densification_interval=2, rng=lambda a, b: 2,
-                             on_iteration=lambda it, t, s: shared_after.append(t.shared_pose_iterations))
-    torch.cuda.synchronize()
-    # every iteration shares the pose; 1..5 also collect statistics (second chain for render #1's own screen-space gradient)
-    assert shared_after == list(range(1, 11)), shared_after
+    from event_3dgs_amd.train_step import EventTrainer
+    for threshold, expect in ((None, [0, 0, 0, 0, 0, 1, 2, 3, 4, 5]), (0, list(range(1, 11)))):
+        # iterations 1..5 collect statistics: three renders for a launch this small (default threshold), or -- threshold
+        # 0 -- the shared view with the second gradient chain; 6..10 share the pose in both runs
+        shared_after = []
+        keep = (EventTrainer.SHARE_STATS_MIN_INSTANCES, EventTrainer.SHARE_STATS_MIN_TILES)
+        if threshold is not None:
+            EventTrainer.SHARE_STATS_MIN_INSTANCES = EventTrainer.SHARE_STATS_MIN_TILES = threshold
+        try:
+            tr = fit.fit_event_scene(params, sc.train_cameras, sc.event_cameras, torch.zeros(3, device=DEV), DEV,
+                                     iterations=10, cameras_extent=sc.cameras_extent, densify_until_iter=6,
+                                     densify_from_iter=2, densification_interval=2, rng=lambda a, b: 2,
+                                     on_iteration=lambda it, t, s: shared_after.append(t.shared_pose_iterations))
+        finally:
+            EventTrainer.SHARE_STATS_MIN_INSTANCES, EventTrainer.SHARE_STATS_MIN_TILES = keep
+        torch.cuda.synchronize()
+        assert shared_after == expect, (threshold, shared_after)
     assert torch.isfinite(tr.flat).all()
     # the one-render modes and the evaluation protocol on the same loaded cameras (frames with PILtoTorch's strides
     # are laid out as planes on the way in)
