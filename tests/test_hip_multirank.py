@@ -172,13 +172,17 @@ def _shared_pose_worker(rank, world, port, out):
     params, cams, gts, bg = _inputs(rank)
     if rank == 0:             # this rank's event camera `now` carries the pose of its training camera (a real dataset)
         cams = [cams[0], orbit_camera(0, 16, W, H, device=DEV, daz=0.0), cams[2]]
-    tr = EventTrainer(params, DEV)
+    # (rank 0 also collects densification statistics: the shared view's tiles run the second gradient chain -- which must
+    # leave every exchanged gradient as it is)
+    tr = EventTrainer(params, DEV, track_densification_stats=(rank == 0))
+    tr.SHARE_STATS_MIN_INSTANCES = tr.SHARE_STATS_MIN_TILES = 0
     assert tr.factorize_sh
     for _ in range(STEPS):
         tr.step(*cams, *gts, bg)
     tr.sync_features()
     torch.cuda.synchronize()
     assert tr.shared_pose_iterations == (STEPS if rank == 0 else 0)
+    assert rank != 0 or float(tr.viewspace_grad.abs().sum()) > 0
     torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu()}, f"{out}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
