@@ -335,6 +335,9 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     // pose of its training camera `index`: scene/dataset_readers.py:157 reads both with the same extrinsics), so the
     // caller rendered it once and wants dL/d(that image) = intensity part + contrast part
     const bool shared = d_now == d_image;
+    // image == now with separate outputs: d_now receives the TOTAL gradient of that render (what its backward needs),
+    // d_image the intensity part alone (what the densification statistics need: e3dgs_rasterize_backward_multi_stats)
+    const bool total_in_now = !shared && image == now;
     const float c = c_ptr[0];
     const float kE = scalars[6], kI = scalars[7];
     const float kB = 0.5f / (3.0f * (float)HW);
@@ -400,6 +403,10 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
                     reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1],
                                                                                   oi[ch][2] + ow[ch][2], oi[ch][3] + ow[ch][3]);
                 } else {
+                    if (total_in_now) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ow[ch][u] = oi[ch][u] + ow[ch][u];
+                    }
                     reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
                     reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
                 }
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
             for (int ch = 0; ch < 3; ++ch) {
                 d_next[ch * HW + p] = dn[ch];
                 if (shared) d_image[ch * HW + p] = di[ch] + dw[ch];
-                else { d_now[ch * HW + p] = dw[ch]; d_image[ch * HW + p] = di[ch]; }
+                else { d_now[ch * HW + p] = total_in_now ? di[ch] + dw[ch] : dw[ch]; d_image[ch * HW + p] = di[ch]; }
             }
         }
     }

@@ -17,6 +17,10 @@ class _EventLoss(torch.autograd.Function):
         _, H, W = image.shape
         prep = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
         image_c, now_c, next_c = prep(image), prep(img_now), prep(img_next)
+        if now_c.data_ptr() == image_c.data_ptr():
+            # (the kernel reads "same input, separate outputs" as the shared-render convention of include/e3dgs_hip.h:
+            # d_now = total.  Autograd adds the two gradients of one tensor itself, so it gets two distinct inputs.)
+            now_c = now_c.clone()
         gi, gn, gx, gb = prep(gt_int), prep(gt_now), prep(gt_next), prep(gt_blur)
         c_dev = c.detach().to(torch.float32).reshape(1).contiguous()
         d_image, d_now, d_next = (torch.empty_like(image_c) for _ in range(3))
@@ -44,7 +48,9 @@ def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur
     """Direct call of e3dgs_event_loss (no autograd).  Returns (scalars[8], d_image, d_now, d_next):
     scalars[0] = loss, [1] = dL/dc, [2] = rho, [3..5] = L1 event / intensity / blur.  `out` may carry
     preallocated (scalars, d_image, d_now, d_next, scratch) tensors to reuse across steps; `dc_out`: a one-element
-    device tensor that also receives dL/dc (the threshold's slot of a flat gradient buffer)."""
+    device tensor that also receives dL/dc (the threshold's slot of a flat gradient buffer).
+    Shared render (image IS img_now): with d_now IS d_image the sum of the two gradients is stored; with separate
+    outputs d_now receives the sum and d_image the intensity term's part alone (include/e3dgs_hip.h)."""
     L = _lib.lib()
     dev = image.device
     _, H, W = image.shape

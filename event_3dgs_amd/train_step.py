@@ -642,8 +642,7 @@ class EventTrainer:
         scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[i_now], imgs[i_next], self.c, gt_int, gt_now, gt_next, gt_blur,
                                                  out=(sc, d_int, dpix[i_now], dpix[i_next], scratch),
                                                  dc_out=self.c_grad)                                                   # train.py:165-203
-        if shared and want_vs:
-            dpix[0].add_(d_int)
+        # (image and img_now are the same tensor, the outputs are not: the kernel stored the sum in dpix[0], d_int alone)
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])

@@ -412,7 +412,9 @@ int e3dgs_dist_knn3(int P, const float* points /* (P,3) */, float* out /* (P) */
  * Shared pose: the reference reads its event cameras with the training cameras' extrinsics
  * (scene/dataset_readers.py:157), so render #1 (train.py:144) and render #2 (:159) of an iteration are the same
  * render.  A caller that rendered it once passes the same pointer as `image` and `img_now` and the same pointer as
- * d_image and d_now: the SUM of the two gradients is stored there.
+ * d_image and d_now: the SUM of the two gradients is stored there.  With the same input pointer but separate outputs,
+ * d_now receives the sum (the shared render's total pixel gradient) and d_image the intensity term's part alone (the
+ * second argument of e3dgs_rasterize_backward_multi_stats).
  */
 size_t e3dgs_event_loss_scratch_bytes(int width, int height);
 int e3dgs_event_loss(

@@ -1076,3 +1076,30 @@ def test_scene_directory_to_shared_pose_training(tmp_path):
     res = scene_io.evaluate_views(lambda cam: tr.render_raw(cam, torch.zeros(3, device=DEV))["color"], sc.test_cameras,
                                   index_list=(1, 3))
     assert np.isfinite(res["psnr"]) and np.isfinite(res["ssim"])
+
+
+def test_event_loss_kernel_shared_render_conventions():
+    """e3dgs_event_loss when render #1 and render #2 are one image: aliased outputs -> the sum; separate outputs -> d_now =
+    the sum, d_image = the intensity term alone; the autograd wrapper still hands autograd two separate gradients."""
+    from event_3dgs_amd import losses
+    g = torch.Generator(device=DEV).manual_seed(3)
+    H, W = 37, 53
+    img, nxt, gi, gn, gx = (torch.rand(3, H, W, device=DEV, generator=g) * 0.8 + 0.1 for _ in range(5))
+    c = torch.tensor([0.21], device=DEV)
+    sc0, di0, dn0, dx0 = (t.clone() for t in losses.event_loss_raw(img, img.clone(), nxt, c, gi, gn, gx))
+    buf = lambda: torch.empty_like(img)
+    sh = buf()
+    sc1, _, _, dx1 = losses.event_loss_raw(img, img, nxt, c, gi, gn, gx,
+                                          out=(torch.empty(8, device=DEV), sh, sh, buf(), torch.empty(
+                                              _lib_scratch(W, H), dtype=torch.uint8, device=DEV)))
+    assert torch.equal(sc1[:6], sc0[:6]) and torch.equal(dx1, dx0) and torch.equal(sh, di0 + dn0)
+    sc2, di2, dn2, dx2 = losses.event_loss_raw(img, img, nxt, c, gi, gn, gx)
+    assert torch.equal(di2, di0) and torch.equal(dn2, di0 + dn0) and torch.equal(dx2, dx0)
+    leaf = img.clone().requires_grad_(True)
+    losses.event_iteration_loss(leaf, leaf, nxt, c, gi, gn, gx).backward()
+    assert torch.allclose(leaf.grad, di0 + dn0, rtol=0, atol=0)
+
+
+def _lib_scratch(W, H):
+    from event_3dgs_amd import _lib
+    return _lib.lib().e3dgs_event_loss_scratch_bytes(W, H)
