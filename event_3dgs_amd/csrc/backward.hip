@@ -21,7 +21,7 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 #define E3_BWD_WAVES 6
 #endif
 #ifndef E3_BWD_STATS_WAVES
-#define E3_BWD_STATS_WAVES 5      // render_bwd_kernel<true> (second gradient chain: +16 VGPRs)
+#define E3_BWD_STATS_WAVES 5      // render_bwd_stats_kernel (second gradient chain: +16 VGPRs)
 #endif
 // STATS (shared-pose iterations that also collect densification statistics, EventTrainer.compute_gradients): view 0 is
 // the render that train.py:144 and :159 both produce; its backward carries the SUM of the two loss terms' pixel
@@ -30,7 +30,7 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 // dL/dalpha chain on dL_dpix2 next to the first -- sharing G, alpha, T and the keep decisions -- and store its two
 // screen-space sums per instance in `part2` (2 floats at the instance's slot).  The default instantiation is unchanged.
 template <bool STATS>
-__global__ __launch_bounds__(BWD_WAVES * WAVE, STATS ? E3_BWD_STATS_WAVES : E3_BWD_WAVES) void render_bwd_kernel(
+__device__ __forceinline__ void render_bwd_body(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -345,6 +345,23 @@ __global__ __launch_bounds__(BWD_WAVES * WAVE, STATS ? E3_BWD_STATS_WAVES : E3_B
     }
 }
 
+#define E3_RENDER_BWD_PARAMS                                                                                             \
+    unsigned long long *__restrict__ trace, int ntiles, int tiles_per_view, const uint32_t *__restrict__ order, int gx,  \
+        int W, int H, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ emit_gid,                           \
+        const float4 *__restrict__ rec, const float *__restrict__ bg, const float *__restrict__ final_T,                 \
+        const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ perm,                                       \
+        const uint8_t *__restrict__ strip_mask, const float *__restrict__ dL_dpix, float *__restrict__ part
+#define E3_RENDER_BWD_ARGS \
+    trace, ntiles, tiles_per_view, order, gx, W, H, ranges, emit_gid, rec, bg, final_T, n_contrib, perm, strip_mask, dL_dpix, part
+// (two plain kernels around the one body: the profiles, the bench line and the reviews name `render_bwd_kernel`)
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(E3_RENDER_BWD_PARAMS) {
+    render_bwd_body<false>(E3_RENDER_BWD_ARGS, nullptr, nullptr);
+}
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_kernel(
+    E3_RENDER_BWD_PARAMS, const float* __restrict__ dL_dpix2, float* __restrict__ part2) {
+    render_bwd_body<true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2);
+}
+
 // ------------------------------------------------------------------------------------ per-Gaussian backward
 template <bool ACCUM>
 __device__ __forceinline__ void put(float* p, float v) { if (ACCUM) *p += v; else *p = v; }
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(256) void run_reduce_wave_kernel(uint32_t Q, const 
     }
 }
 
-// STATS (render_bwd_kernel<true>): per-splat sums of the second chain's two floats per instance, for the splats of view
+// STATS (render_bwd_stats_kernel): per-splat sums of the second chain's two floats per instance, for the splats of view
 // 0 only, into the free components .y / .z of the splat's third sum vector (run_reduce_kernel wrote (c2, 0, 0, 0)
 // there: this kernel runs after it).  One thread per kept splat, its run added in slot order (fixed order).
 __global__ __launch_bounds__(256) void run_reduce_stats_kernel(const uint32_t* __restrict__ order,
@@ -1172,13 +1189,13 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         // the caller provides E3_ACC_STRIDE = 12 floats per instance)
         float* part2 = grad_acc + E3_REC_FLOATS * (size_t)num_rendered;
         if (dL_dpix_stats)
-            render_bwd_kernel<true><<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+            render_bwd_stats_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
                 background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, dL_dpix_stats, part2);
         else
-            render_bwd_kernel<false><<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+            render_bwd_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, nullptr, nullptr);
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc);
     }
     KERNEL_OK("render_bwd_kernel");
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;
