@@ -56,3 +56,36 @@ def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback, sche
         assert isinstance(comm[key], float), key
     assert comm["nonsh_schedule"] == schedule and "NCCL_ALGO" in comm["env"] and "NCCL_PROTO" in comm["env"]
     assert comm["sh_exchange"] == ("allreduce" if force_fallback else "factorised")
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_carries_the_contract():
+    """`python bench.py` (N = 1; the tiny workload to keep the test short): one JSON line with the contract's keys, the
+    `roofline` object of the dominant kernel measured with HIP events in the timed region, the `cpu_baseline` of the
+    oracle, and the extra measurements that never enter `value`."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "6", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert out["metric"] == base["metric"] and out["unit"] == "iters/s"
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["warmup"] == 2 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - 1.0) < 1e-2          # value = iterations / s of the timed region
+    assert out["config"]["workload"] == "tiny" and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and "traffic" in rf
+    assert rf["kernel"] == "render_bwd_kernel" and rf["avg_launch_ms"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["unit"] == "iters/s" and cb["cores"] >= 1 and cb["kind"] in ("port", "reference")
+    assert isinstance(cb["sample"], str) and cb["sample"]
+    assert out["device_allocs_in_timed_region"] == 0
+    for key in ("contrast_only_substep", "shared_pose_iteration", "dropin_autograd_step"):
+        assert key in out
+    assert out["shared_pose_iteration"]["taken"] is True and out["shared_pose_iteration"]["renders"] == 2
