@@ -570,21 +570,24 @@ class EventTrainer:
 
     def _views_coincide(self, cam_a, cam_b, settings):
         """True when the two cameras are the same view (frame size, field of view, matrices, centre -- compared by value
-        ONCE per camera pair: the answer is cached on the pair, matched by identity like _camera_tensors)."""
+        ONCE per camera pair: the answer is cached on the pair's matrix tensors, matched by identity like _camera_tensors)."""
         if cam_a is cam_b:
             return True
         sa, sb = settings[0], settings[1]
         if (sa.image_height, sa.image_width, sa.tanfovx, sa.tanfovy) != (sb.image_height, sb.image_width, sb.tanfovx, sb.tanfovy):
             return False
         tensors = (sa.viewmatrix, sa.projmatrix, sa.campos, sb.viewmatrix, sb.projmatrix, sb.campos)
-        hit = self._coincide.get((id(cam_a), id(cam_b)))
-        if hit is not None and hit[0] is cam_a and hit[1] is cam_b and self._same_tensors(hit[2], tensors):
-            return hit[3]
+        # (the entry holds the six small matrix tensors -- never the cameras, which carry their frames -- and is matched by
+        # identity + in-place version, as in _camera_tensors)
+        key = tuple(id(t) for t in tensors)
+        hit = self._coincide.get(key)
+        if hit is not None and self._same_tensors(hit[0], tensors):
+            return hit[1]
         same = bool(torch.equal(sa.viewmatrix, sb.viewmatrix) and torch.equal(sa.projmatrix, sb.projmatrix)
                     and torch.equal(sa.campos, sb.campos))          # (a host wait, once per camera pair)
         if len(self._coincide) > 4096:
             self._coincide.clear()
-        self._coincide[(id(cam_a), id(cam_b))] = (cam_a, cam_b, (tensors, tuple(t._version for t in tensors)), same)
+        self._coincide[key] = ((tensors, tuple(t._version for t in tensors)), same)
         return same
 
     def _colour_gradients_instead_of_sh(self, out, settings, pad_to=None):
