@@ -1,5 +1,6 @@
 """Mirror of the reference's boundary wrapper `render()` (gaussian_renderer/__init__.py:20-104) and
-of its second caller `render_depth()` (:106-189) on the HIP operator -- same arguments, same dict, same behaviour:
+of the other two callers of the boundary, `render_depth()` (:106-189) and `render_point()` (:274-370, with its
+`project_points` / `generate_depth_map` helpers :194-273), on the HIP operator -- same arguments, same results:
 
   * a zero `(N,3)` screen-space tensor that receives the NDC-unit mean gradients (`viewspace_points`, :28-32);
   * `pipe.compute_cov3D_python` -> covariance built in torch and passed as `cov3D_precomp` (:60-66);
@@ -148,3 +149,40 @@ def render_depth(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ove
     distance = (pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_xyz.shape[0], 1)).norm(dim=1, keepdim=True)
     colors_precomp = torch.clamp_min(distance.repeat(1, 3) + 0.5, 0.0)
     return _rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, colors_precomp, None)
+
+
+def project_points(points_3d, full_proj_transform, epsilon=1e-4):
+    """gaussian_renderer/__init__.py:194-220: (N,3) world points -> (N,2) NDC through the row-vector full projection,
+    normalised by (w + 1e-4) -- the reference's own restatement of the rasteriser's projection (its eps is 1e-4)."""
+    ones = torch.ones(points_3d.shape[0], 1, dtype=points_3d.dtype, device=points_3d.device)
+    clip = torch.cat((points_3d, ones), dim=1) @ full_proj_transform.to(points_3d.dtype)
+    return clip[:, :2] / (clip[:, 3:4] + epsilon)
+
+
+def generate_depth_map(points_3d, camera_center, projection_matrix, image_size, radii=None):
+    """gaussian_renderer/__init__.py:221-273: nearest-point depth map -- every point goes to the pixel its centre falls in
+    (ndc2Pix, then int() truncation) and a pixel keeps the smallest distance to the camera centre; pixels no point hits
+    hold +inf.  The reference walks the points in a Python loop on the host; this is one scatter-min on the points'
+    device.  `radii` is accepted and unused, as upstream."""
+    with torch.no_grad():
+        width, height = int(image_size[0]), int(image_size[1])
+        pts = points_3d.detach()
+        dist = (pts - camera_center.to(pts.device)).norm(dim=1)
+        ndc = project_points(pts, projection_matrix.to(pts.device))
+        x = (((ndc[:, 0] + 1) * width - 1) * 0.5).to(torch.int64)        # .to(int64) truncates toward zero, like int()
+        y = (((ndc[:, 1] + 1) * height - 1) * 0.5).to(torch.int64)
+        ok = (x >= 0) & (x < width) & (y >= 0) & (y < height)
+        depth = torch.full((height * width,), float("inf"), dtype=torch.float32, device=pts.device)
+        depth.scatter_reduce_(0, (y * width + x)[ok], dist[ok].to(torch.float32), reduce="amin", include_self=True)
+        return depth.view(height, width)
+
+
+def render_point(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """gaussian_renderer/__init__.py:274-370 (render.py:305): one rasteriser call for the radii, then the nearest-point
+    depth map of the visible Gaussians (radius > 0) whose opacity exceeds 0.8."""
+    out = render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, force_python_sh=False)
+    with torch.no_grad():
+        keep = (out["radii"] > 0) & (pc.get_opacity.reshape(-1) > 0.8)
+        points = pc.get_xyz[keep]
+    return generate_depth_map(points, viewpoint_camera.camera_center, viewpoint_camera.full_proj_transform,
+                              [int(viewpoint_camera.image_width), int(viewpoint_camera.image_height)], out["radii"][keep])

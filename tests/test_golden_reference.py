@@ -187,6 +187,26 @@ def test_g10_projection_matches_reference_cpu_restatement(k):
         (np.abs(depth[both] - depth_ref[both]) > 1e-4 * depth_ref[both].max()).mean() <= 0.02
 
 
+@pytest.mark.parametrize("k", [0, 3])
+def test_g10_product_depth_map_of_render_point(k):
+    """event_3dgs_amd.renderer.project_points / generate_depth_map (the tail of render_point,
+    gaussian_renderer/__init__.py:194-273,354-369) against the reference's own outputs: NDC to rounding, the depth map
+    pixel for pixel (a point whose centre sits within rounding of a pixel border may land next door)."""
+    from event_3dgs_amd import renderer
+    g, c = G("projection.npz"), G("cameras.npz")
+    pts, ndc_ref, depth_ref = torch.tensor(g[f"points{k}"]), g[f"ndc{k}"], g[f"depth{k}"]
+    W, H = (int(v) for v in c[f"size{k}"])
+    proj, centre = torch.tensor(c[f"proj{k}"]), torch.tensor(c[f"center{k}"])
+    ndc = renderer.project_points(pts, proj).numpy()
+    assert np.abs(ndc - ndc_ref).max() <= 2e-6 * max(1.0, np.abs(ndc_ref).max())
+    depth = renderer.generate_depth_map(pts, centre, proj, (W, H), None).numpy()
+    assert depth.shape == depth_ref.shape == (H, W)
+    same_hit = np.isfinite(depth) == np.isfinite(depth_ref)
+    assert same_hit.mean() >= 1.0 - 4.0 / depth.size
+    both = np.isfinite(depth) & np.isfinite(depth_ref)
+    assert both.sum() > 100 and np.abs(depth[both] - depth_ref[both]).max() <= 1e-5 * depth_ref[both].max()
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_g1_product_eval_sh_in_render_mirror(deg):
     """event_3dgs_amd.renderer.eval_sh (the torch SH branch render() is forced into at

@@ -586,6 +586,24 @@ def test_render_mirror_matches_fused_path_and_oracle():
     f = c_oracle.Forward(**oracle_kwargs(act, cam_cpu, tuple(bg.tolist()), False, False))
     d = np.abs(dep["render"].detach().cpu().numpy() - f.out_color)
     assert float(d.mean()) <= 1e-5 and float((d > 1e-3).mean()) <= 1e-4
+    # render_point (gaussian_renderer/__init__.py:274-370): nearest-point depth map of the visible, opaque Gaussians -- on
+    # the device, against the same reduction done point by point on the host with the oracle's radii
+    gv = renderer.GaussianView(params)
+    pm = renderer.render_point(cam, gv, renderer.PipelineParams(), bg)
+    assert pm.shape == (H, W) and pm.is_cuda
+    keep = (f.radii > 0) & (act["opacities"].reshape(-1).numpy() > 0.8)
+    pts = act["means3D"].numpy()[keep]
+    ndc = renderer.project_points(torch.from_numpy(pts), cam_cpu.full_proj_transform).numpy()
+    ref = np.full((H, W), np.inf, np.float32)
+    dist = np.linalg.norm(pts - cam_cpu.camera_center.numpy()[None], axis=1)
+    for i in range(pts.shape[0]):
+        x, y = int(((ndc[i, 0] + 1) * W - 1) * 0.5), int(((ndc[i, 1] + 1) * H - 1) * 0.5)
+        if 0 <= x < W and 0 <= y < H:
+            ref[y, x] = min(ref[y, x], dist[i])
+    got = pm.cpu().numpy()
+    assert keep.sum() > 50 and (np.isfinite(got) == np.isfinite(ref)).mean() >= 1.0 - 4.0 / got.size
+    both = np.isfinite(got) & np.isfinite(ref)
+    assert both.sum() > 20 and np.abs(got[both] - ref[both]).max() <= 1e-5 * ref[both].max()
 
 
 def test_densify_stats_kernel_equals_torch_form():
