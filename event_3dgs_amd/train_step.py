@@ -348,7 +348,8 @@ class EventTrainer:
         three renders are ONE multi-view pass of the rasteriser (every kernel of the pipeline runs once over the three
         cameras), forward and backward.  Nothing waits for the host: forward, loss and backward are enqueued back to back
         with binning buffers sized from earlier instance counts; the host reads this iteration's count once the backward
-        is enqueued and only then enqueues the optimizer step (_count_fits)."""
+        is enqueued and only then enqueues the optimizer step (_count_fits).  When cam_int and cam_now are the same view
+        (the reference's datasets: compute_gradients) that view is rendered once -- two views per iteration."""
         scalars = self.compute_gradients(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur,
                                          sh_via_colour=self.sh_via_colour and not self.overlap_features)
         self.apply_update(sync_grads)
