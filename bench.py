@@ -554,13 +554,15 @@ def self_launch(n):
 
 
 def _oracle_inputs(trainer):
-    """The trained parameters on the host, activated with torch on the CPU (what both CPU legs and the parity leg use)."""
+    """The trained parameters on the host, activated by the ORACLE's statement of the activations (gso_activate:
+    scene/gaussian_model.py:33-41 with the deterministic exp) -- what both CPU legs and the parity leg use, and what the
+    timed PREACT kernels compute themselves from the raw parameters."""
     import numpy as np
-    import torch
-    v = {k: t.detach().cpu() for k, t in trainer.views.items()}
-    return dict(means=v["xyz"].numpy(), scales=torch.exp(v["scaling"]).numpy(),
-                rots=torch.nn.functional.normalize(v["rotation"]).numpy(), opac=torch.sigmoid(v["opacity"]).numpy(),
-                shs=np.ascontiguousarray(v["features"].t().reshape(-1, 16, 3).numpy()))   # (48,N) planar -> (N,16,3)
+    from oracle import c_oracle
+    v = {k: t.detach().cpu().numpy() for k, t in trainer.views.items()}
+    scales, rots, opac = c_oracle.activate(v["scaling"], v["rotation"], v["opacity"])
+    return dict(means=v["xyz"], scales=scales, rots=rots, opac=opac, raw_rots=v["rotation"],
+                shs=np.ascontiguousarray(v["features"].T.reshape(-1, 16, 3)))   # (48,N) planar -> (N,16,3)
 
 
 def _pick_threads():
@@ -649,51 +651,47 @@ def run_torch_cpu_baseline(inp, cams, bg, W, H, rows, budget_s=90.0):
 def run_c_oracle_baseline(trainer, inp, cams, bg, W, H, rows):
     """C oracle (single thread) on a bounded sample of the same workload: full preprocess + binning of
     all Gaussians for the three views, compositing fwd+bwd restricted to `rows` tile rows around the image
-    centre, extrapolated linearly in tile instances to the whole image.  The same leg checks the HIP operator
-    against the oracle on the sampled rows: image (bit for bit expected) and, per Gaussian, the gradients of a
-    pixel gradient that is non-zero on those rows only."""
+    centre, extrapolated linearly in tile instances to the whole image.  The same leg checks THE PATH THAT WAS TIMED --
+    one multi-view pass on the raw parameters with in-kernel activations and coefficient-major SH
+    (rasterizer.forward_multi / backward_multi with EventTrainer.FWD_FLAGS) -- against the oracle on the sampled rows:
+    radii, image (bit for bit expected) and, per Gaussian, the gradients w.r.t. the raw parameters of a pixel gradient
+    that is non-zero on those rows only."""
     import numpy as np
     import torch
     from event_3dgs_amd import rasterizer
     from oracle import c_oracle
-    from oracle.metrics import per_gaussian_err, rel_l2
+    from oracle.metrics import rel_l2
     means, scales, rots, opac, shs = (inp[k] for k in ("means", "scales", "rots", "opac", "shs"))
     dev = trainer.device
+    P = means.shape[0]
     gy = (H + 15) // 16
     r0 = max(0, gy // 2 - rows // 2)
     y0, y1 = r0 * 16, min(H, (r0 + rows) * 16)
     total = 0.0
-    detail, diffs, gerr = [], [], {}
-    gw = np.zeros((3, H, W), np.float32)
-    gw[:, y0:y1] = np.random.default_rng(7).standard_normal((3, y1 - y0, W)).astype(np.float32)
-    gw_dev = torch.from_numpy(gw).to(dev)
-    dev_in = [torch.from_numpy(x).to(dev) for x in (means, shs, opac, scales, rots)]
-    for cam in cams:
+    detail, diffs, radii_bad = [], [], []
+    gw = np.zeros((len(cams), 3, H, W), np.float32)
+    rng = np.random.default_rng(7)
+    for k in range(len(cams)):
+        gw[k, :, y0:y1] = rng.standard_normal((3, y1 - y0, W)).astype(np.float32)
+    # ---- the timed path: ONE multi-view pass on the raw parameters
+    v = trainer.views
+    settings = [trainer._settings(c, bg) for c in cams]
+    hip = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
+                                   flags=trainer.FWD_FLAGS)
+    acc = {k: 0.0 for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    for k, cam in enumerate(cams):
         f = c_oracle.Forward(means3D=means, opacities=opac, viewmatrix=cam.world_view_transform.contiguous().cpu().numpy(),
                              projmatrix=cam.full_proj_transform.cpu().numpy(),
                              campos=cam.camera_center.contiguous().cpu().numpy(), bg=bg.cpu().numpy(), width=W,
                              height=H, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), shs=shs,
                              sh_degree=3, scales=scales, rotations=rots, tile_rows=(r0, r0 + rows))
         t1 = time.perf_counter()
-        gb = f.backward(gw)                      # timed alone: windowed compositing backward + per-Gaussian backward
+        gb = f.backward(gw[k])                   # timed alone: windowed compositing backward + per-Gaussian backward
         t2 = time.perf_counter()
-        # ---- parity on the sampled rows: the operator path on EXACTLY the oracle's inputs (torch-CPU activations)
-        hip = rasterizer.forward_raw(dev_in[0], dev_in[1], None, dev_in[2], dev_in[3], dev_in[4], None,
-                                     trainer._settings(cam, bg))
-        diffs.append(float(np.abs(hip["color"][:, y0:y1].cpu().numpy() - f.out_color[:, y0:y1]).max()))
-        P = means.shape[0]
-        e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
-        out = dict(means2D=e(P, 3), opacities=e(P, 1), means3D=e(P, 3), sh=e(P, 16, 3), scales=e(P, 3), rots=e(P, 4))
-        rasterizer.backward_raw(hip, gw_dev, out)
-        pairs = dict(means3D=(out["means3D"], gb["means3D"]), means2D=(out["means2D"], gb["means2D"]),
-                     opacities=(out["opacities"], gb["opacities"]), shs=(out["sh"], gb["shs"]),
-                     scales=(out["scales"], gb["scales"]), rotations=(out["rots"], gb["rotations"]))
-        for name, (a, b) in pairs.items():
-            a = a.cpu().numpy()
-            cur = gerr.setdefault(name, [0.0, 0.0])
-            cur[0] = max(cur[0], rel_l2(a.reshape(P, -1), np.asarray(b).reshape(P, -1)))
-            cur[1] = max(cur[1], per_gaussian_err(a, np.asarray(b).reshape(a.shape)))
-        del hip, out
+        diffs.append(float(np.abs(hip["color"][k][:, y0:y1].cpu().numpy() - f.out_color[:, y0:y1]).max()))
+        radii_bad.append(int((hip["radii"][k].cpu().numpy() != f.radii).sum()))
+        for name in acc:
+            acc[name] = acc[name] + np.asarray(gb[name], np.float64)
         tm = f.timings            # preprocess, binning, composite seconds
         ranges = f.ranges.reshape(gy, -1, 2)
         inst_rows = int((ranges[r0:r0 + rows, :, 1] - ranges[r0:r0 + rows, :, 0]).sum())
@@ -703,18 +701,40 @@ def run_c_oracle_baseline(trainer, inp, cams, bg, W, H, rows):
         detail.append({"pre_s": round(tm[0], 3), "bin_s": round(tm[1], 3), "comp_fwd_s": round(tm[2], 3),
                        "bwd_s": round(t2 - t1, 3), "row_instances": inst_rows, "extrap": round(scale, 2)})
         f.close()
+    # oracle gradients w.r.t. the RAW parameters (chain rule of gso_activate), HIP gradients of the multi-view backward
+    gs, gq, go = c_oracle.activate_backward(inp["raw_rots"], scales, rots, opac, acc["scales"], acc["rotations"],
+                                            acc["opacities"])
+    ref = {"xyz": acc["means3D"], "scaling": gs, "rotation": gq, "opacity": go,
+           "features": np.ascontiguousarray(np.asarray(acc["shs"]).reshape(P, 48).T)}
+    e = lambda like: torch.full_like(like, float("nan"))
+    out = dict(means3D=e(v["xyz"]), sh=e(v["features"]), opacities=e(v["opacity"]), scales=e(v["scaling"]),
+               rots=e(v["rotation"]))
+    rasterizer.backward_multi(hip, torch.from_numpy(gw).to(dev), out)
+    got = {"xyz": out["means3D"], "scaling": out["scales"], "rotation": out["rots"], "opacity": out["opacities"],
+           "features": out["sh"]}
+    gerr = {}
+    for name, t in got.items():
+        a = t.cpu().numpy().astype(np.float64)
+        b = np.asarray(ref[name], np.float64).reshape(a.shape)
+        if name == "features":
+            a, b = a.T, b.T
+        a2, b2 = a.reshape(P, -1), b.reshape(P, -1)
+        per = np.abs(a2 - b2).max(axis=1) / (np.abs(b2).max(axis=1) + 1e-3 * np.abs(b2).max())
+        gerr[name] = (rel_l2(a2, b2), float(per.max()))
+    del hip, out
     c_part = {"value": round(1.0 / total, 5), "unit": "iters/s", "cores": 1, "kind": "port",
               "sample": f"C oracle (oracle/gs_oracle.c, 1 thread): 3 views, full preprocess+sort of all Gaussians, "
                         f"compositing fwd+bwd on {rows} of {gy} tile rows extrapolated by tile instances; loss/Adam excluded",
               "detail": detail}
-    parity = {"rows_checked": rows * 16 * len(cams), "max_abs_diff": max(diffs),
+    parity = {"path": "forward_multi/backward_multi, E3DGS_FLAG_PREACT | E3DGS_FLAG_SH_PLANAR (the timed path)",
+              "rows_checked": rows * 16 * len(cams), "max_abs_diff": max(diffs), "radii_mismatch": sum(radii_bad),
               "psnr_db": None if max(diffs) == 0.0 else round(-20.0 * math.log10(max(diffs)), 1),
               "grad_rel_l2": {k: float("%.3g" % v[0]) for k, v in gerr.items()},
               "grad_per_gaussian_max": {k: float("%.3g" % v[1]) for k, v in gerr.items()},
-              "note": "HIP operator vs C oracle on identical inputs (the trained parameters after the timed steps), sampled "
-                      "tile rows of the three views; image: 0.0 = bit-identical (PSNR unbounded); gradients of a random pixel "
-                      "gradient supported on those rows: global relative L2 and max over Gaussians of "
-                      "|d_i| / (|ref_i| + 1e-3 max_j |ref_j|)"}
+              "note": "the multi-view PREACT path bench.py timed vs the C oracle fed gso_activate() of the same raw parameters "
+                      "(the trained parameters after the timed steps), sampled tile rows of the three views; image: 0.0 = "
+                      "bit-identical (PSNR unbounded); gradients w.r.t. the raw parameters of a random pixel gradient supported "
+                      "on those rows: global relative L2 and max over Gaussians of |d_i| / (|ref_i| + 1e-3 max_j |ref_j|)"}
     return c_part, parity
 
 

@@ -173,11 +173,14 @@ __device__ __forceinline__ void render_bwd_body(
                 const float4 c = make_float4(vc.x, vc.y, vc.z, vc.w);
                 const uint32_t contributor = (uint32_t)(nrem - j);         // 1-based position in the list
                 const float dx = a.x - pfx;
-                // power(dy) = -(A dx^2 + C dy^2)/2 - B dx dy as a quadratic in dy (Horner: 2 FMAs per strip instead of the
-                // forward's 4-op expression, whose rounding order only the bit-exact forward has to keep)
-                const float h0 = -0.5f * (a.z * dx) * dx;     // -A dx^2 / 2
-                const float h1 = -(a.w * dx);                 // -B dx
-                const float h2 = -0.5f * b.x;                 // -C / 2
+                // power in the FORWARD's operation order (q = fma(C dy, dy, (A dx) dx); power = fma(-0.5, q, -((B dx) dy))):
+                // the same bits as the forward / the oracle.  A Horner form in dy is 2 VALU cheaper per strip, but for a
+                // large anisotropic splat the three terms cancel (|terms| ~ 1e3 against a sum of ~5 along the major axis), so
+                // a different rounding order moves G by 1e-4 at exactly the far pixels that dominate the conic sums (weights
+                // dx^2, dy^2): measured 5e-5 on the sums and 1.4e-3 on one scale gradient per million Gaussians.  With
+                // identical bits the backward's G is the forward's up to the 1-ulp v_exp_f32.
+                const float qx = (a.z * dx) * dx;
+                const float cydx = a.w * dx;
                 // per-lane partial sums over its (up to) 4 pixels, with u = G dL/dalpha (so that dL/dG * G = o u):
                 //   So = sum u, Uy = sum u dy, Uyy = sum u dy^2, Sc* = sum alpha T dL/dC*.
                 // A lane's four pixels share dx, and the opacity o is the entry's: the x moments are dx So, dx^2 So and
@@ -190,36 +193,30 @@ __device__ __forceinline__ void render_bwd_body(
                 for (int k = 0; k < 4; ++k) {
                     if (((em >> k) & 1u) == 0u) continue;   // scalar: the forward did not evaluate this strip
                     const float dy = a.y - pfy[k];
-                    const float power = FMA(FMA(h2, dy, h1), dy, h0);
+                    const float power = FMA(-0.5f, FMA(b.x * dy, dy, qx), -(cydx * dy));
                     // All decisions are lane masks in SGPR pairs (compare intrinsics) combined with scalar ops; the one
                     // divergent branch takes its mask through inverse_ballot (an s_and_saveexec, no VALU).
                     // c.y = pmin: below it alpha < 1/255 whatever the rounding (preprocess_kernel)
                     const unsigned long long live = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
                                                     __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
                     if (live != 0ull) {
-                        // The two skip decisions (alpha < 1/255, power > 0) are discontinuities, and the forward took them
-                        // with ITS arithmetic (its rounding order of `power`, the polynomial exp).  Away from the
-                        // thresholds the outcome cannot depend on that: power >= c.z = pmin + 4e-4 keeps, power <= -1e-5
-                        // is not positive.  Inside the bands the forward's own computation is redone, so that backward
-                        // differentiates exactly the set of (pixel, Gaussian) pairs the forward composited.
+                        // The two skip decisions of the forward: power > 0 -- exact here, `power` has the forward's bits --
+                        // and alpha < 1/255, which the forward took with its polynomial exp.  Away from that threshold the
+                        // outcome cannot depend on the exp: power >= c.z = pmin + 4e-4 keeps.  Inside the band the forward's
+                        // own exp is redone, so that backward differentiates exactly the set of (pixel, Gaussian) pairs the
+                        // forward composited.
                         // hardware exp2 (1 ulp) instead of the forward's bit-reproducible polynomial: the VALUES of
                         // backward are tolerance-checked, and 2 issue slots replace 10 on the most executed path.
                         // Issued before the mask algebra so that its latency overlaps the compares.
                         float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                         asm volatile("" : "+v"(G));          // keep it here: the compiler would sink it into the branch
                         const unsigned long long hi = __builtin_amdgcn_fcmpf(power, c.z, 3 /* OGE */);
-                        const unsigned long long nzp = __builtin_amdgcn_fcmpf(power, -1e-5f, 2 /* OGT */);
-                        const unsigned long long safe = hi & ~nzp;          // power in [pmin + 4e-4, -1e-5]: no recheck needed
-                        unsigned long long keep = live & safe;
-                        const unsigned long long near = live & ~safe;
+                        const unsigned long long nonpos = __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE: !(power > 0) */);
+                        unsigned long long keep = live & hi & nonpos;
+                        const unsigned long long near = live & ~hi & nonpos;
                         if (near != 0ull) {                  // rare (<1 % of the live strips)
-                            float adx = a.z * dx;
-                            asm volatile("" : "+v"(adx));      // (keeps the product below in this rare branch: as a common
-                            const float qf = FMA(b.x * dy, dy, adx * dx);   //  subexpression it is hoisted to every entry)
-                            const float pf = FMA(-0.5f, qf, -((a.w * dx) * dy));
-                            const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(pf));
-                            keep |= near & __builtin_amdgcn_fcmpf(pf, 0.0f, 13 /* ULE: !(pf > 0) */) &
-                                    __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
+                            const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(power));
+                            keep |= near & __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
                         }
                         any |= keep;
                         if (__builtin_amdgcn_inverse_ballot_w64(keep)) {

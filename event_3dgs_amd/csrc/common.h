@@ -63,20 +63,28 @@ __device__ __forceinline__ float exp_det_noclamp(float x) {
     return __builtin_ldexpf(p, (int)n);
 }
 
-// activations of scene/gaussian_model.py:95-118 (used when E3_FLAG_PREACT is set)
-__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// activations of scene/gaussian_model.py:33-41,95-118 (used when E3_FLAG_PREACT is set): scaling = exp, opacity = sigmoid,
+// rotation = F.normalize.  DETERMINISTIC forms, restated operation for operation by the CPU checker (gso_activate() under oracle/): the
+// polynomial exp_det (|rel err| < 2e-6 against exp on |x| <= 20), IEEE division / sqrt, explicit fmaf chain -- so that the
+// rasteriser fed raw parameters is bit-identical to the oracle fed gso_activate()'s values (radii, lists, image), exactly
+// as the operator fed activated values is.  (libm-style expf differs from torch's by <= 1 ulp, which is enough to flip a
+// radius or an alpha threshold at a handful of Gaussians per million.)
+__device__ __forceinline__ float act_exp(float x) { return exp_det(x); }
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + exp_det(-x)); }
 __device__ __forceinline__ void act_load_scale_rot(const float* __restrict__ s3, const float* __restrict__ q4, bool preact,
                                                    float s[3], float q[4], float& qinv) {
     s[0] = s3[0]; s[1] = s3[1]; s[2] = s3[2];
     q[0] = q4[0]; q[1] = q4[1]; q[2] = q4[2]; q[3] = q4[3];
     qinv = 1.0f;
     if (preact) {
-        s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+        s[0] = act_exp(s[0]); s[1] = act_exp(s[1]); s[2] = act_exp(s[2]);
         float nrm = __builtin_sqrtf(FMA(q[0], q[0], FMA(q[1], q[1], FMA(q[2], q[2], q[3] * q[3]))));
         qinv = 1.0f / fmaxf(nrm, 1e-12f);          // torch.nn.functional.normalize eps
         q[0] *= qinv; q[1] *= qinv; q[2] *= qinv; q[3] *= qinv;
     }
 }
+// libm-style sigmoid for the densification decisions (pinned to torch.sigmoid by golden G8, csrc/densify.hip)
+__device__ __forceinline__ float sigmoid_libm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // flat[4*c + r]: row r of the column-vector matrix applied to (x,y,z,1)
 #define XFORM(M, r, x, y, z) FMA((M)[(r)], (x), FMA((M)[4 + (r)], (y), FMA((M)[8 + (r)], (z), (M)[12 + (r)])))

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void densify_flags_kernel(int N, const float* 
     const float smax = fmaxf(fmaxf(e0, e1), e2);
     const bool clone = (fabsf(g) >= max_grad) && (smax <= thr_dense);       // :376-378
     const bool split = (g >= max_grad) && (smax > thr_dense);              // :354-356
-    const bool low = act_sigmoid(param[L.opac + i]) < min_opacity;          // :396
+    const bool low = sigmoid_libm(param[L.opac + i]) < min_opacity;          // :396
     const bool big = size_prune && (smax > thr_big);                        // :399 (world-space half of the size test)
     // the children carry scaling = log(exp(s) / (0.8 * 2)) (:362): their size test sees exp() of THAT
     const float c0 = expf(logf(e0 / 1.6f)), c1 = expf(logf(e1 / 1.6f)), c2 = expf(logf(e2 / 1.6f));

@@ -819,8 +819,57 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 
 unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries, hw_id} (tools/trace_fwd.py)
 
+// Strip pre-test of the forward compositing kernel, LANE-PARALLEL: at staging time lane j holds the record of list entry j
+// of the round, and decides for ITS entry which of the tile's four 16x4 pixel strips the entry can contribute to at all
+// -- i.e. whether some LIVE pixel of the strip can have power >= pmin (alpha >= 1/255 needs that, preprocess_kernel).  The
+// entry loop then skips a dead strip with one scalar bit test, where it used to spend 6 VALU instructions per (entry,
+// strip) on every one of the wave's 64 lanes to find the same thing out: 4 x 6 wave-instructions per entry become
+// ~200 / 64 = 3.
+// "Live pixel": most of the entries a tile walks lie behind pixels that have already saturated, so the test runs against
+// the bounding box of the strip's live pixels at the start of the round (columns [cmin, cmax] of the lane mask alive[k],
+// rows with a live pixel -- scalar bit arithmetic, once per round), not against the whole strip.  Per pixel row r (dy
+// fixed, exact) the maximum of the concave quadratic
+//   power(dx) = -C dy^2 / 2 - dx (A dx / 2 + B dy)      over the continuous column range dx in [dxlo, dxhi]
+// is attained at clamp(-B dy / A); a strip is live when one of its live rows reaches pmin - margin.  The margin covers
+// the rounding of this evaluation AND of the kernel's own `power` (a few ulp of the largest term each; bounded once per
+// entry over the tile's box, times a safety factor of ~5): a strip is only ever skipped when no live pixel of it can pass
+// the kernel's alpha >= 1/255 test, so image, final_T and n_contrib are unchanged bit for bit.  Conics that are not safely
+// concave in dx (A <= 0, NaN) keep every strip.
+__device__ __forceinline__ void strip_pretest(const float4 ra, const float4 rb, const float4 rc, float X0, float Y0,
+                                              const unsigned long long alive[4], unsigned long long m[4]) {
+    const float A = ra.z, B = ra.w, C = rb.x, pmin = rc.y;
+    const float xr = ra.x - X0;                              // dx = xr - column
+    const float y0r = ra.y - Y0;                             // dy of row r = y0r - r
+    const float nBA = -B / A;
+    const float hA = 0.5f * A, hC = 0.5f * C;
+    const float DX = fmaxf(fabsf(xr), fabsf(xr - 15.0f)), DY = fmaxf(fabsf(y0r), fabsf(y0r - 15.0f));
+    const float margin = 2e-6f * (hA * DX * DX + fabsf(B) * DX * DY + hC * DY * DY) + 1e-6f;
+    const float thr = pmin - margin;
+    const bool keep_all = !(A > 0.0f) || !(thr == thr) || !(fabsf(nBA) < 3e38f);
+    const unsigned long long all = __builtin_amdgcn_ballot_w64(keep_all);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long al = alive[k];
+        if (al == 0ull) { m[k] = 0ull; continue; }           // (wave-uniform: every pixel of the strip has finished)
+        // columns that still hold a live pixel in any of the strip's rows (lane l = row (l >> 4), column (l & 15))
+        const uint32_t cols = (uint32_t)((al | (al >> 16) | (al >> 32) | (al >> 48)) & 0xFFFFull);
+        const float dxlo = xr - (float)(31 - __builtin_clz(cols)), dxhi = xr - (float)__builtin_ctz(cols);
+        float pk = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (((al >> (16 * r)) & 0xFFFFull) == 0ull) continue;      // (wave-uniform) no live pixel in this row
+            const float dy = y0r - (float)(4 * k + r);
+            const float dxc = __builtin_amdgcn_fmed3f(dy * nBA, dxlo, dxhi);
+            const float u = FMA(hA, dxc, B * dy);
+            const float p = FMA(-(hC * dy), dy, -(dxc * u));
+            pk = fmaxf(pk, p);
+        }
+        m[k] = __builtin_amdgcn_fcmpf(pk, thr, 3 /* OGE */) | all;
+    }
+}
+
 #ifndef E3_FWD_WAVES
-#define E3_FWD_WAVES 1
+#define E3_FWD_WAVES 7      // 72 VGPRs: the lane-parallel strip pre-test at the top of a round must not cost the loop a wave per SIMD
 #endif
 __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_kernel(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
@@ -847,6 +896,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     const int px = tx * E3_TILE + (lane & 15);
     const int py0 = ty * E3_TILE + (lane >> 4);
     const float pfx = (float)px;
+    const float tile_x0 = (float)(tx * E3_TILE), tile_y0 = (float)(ty * E3_TILE);
     // Which pixels are still live is wave-level state: alive[k] holds, as a lane mask in an SGPR pair, the pixels of
     // strip k that are inside the image and have not reached T < 1e-4.  The strip test ANDs it with one compare
     // (no per-pixel "T > 0" compare per entry and strip), and a finished pixel simply leaves the mask.
@@ -887,6 +937,10 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
         const int cnt = min(WAVE, n - base);
         processed += cnt;
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
+        // which strips each of the round's entries can contribute to at all (lane j decides for entry j; bit j of gm[k]):
+        // tested against the live pixels' bounding box; a strip whose pixels have all finished drops out of gm for good
+        unsigned long long gm[4];
+        strip_pretest(ra, rb, rc, tile_x0, tile_y0, alive, gm);
         wave_sync();
         if (base + WAVE + lane < n) {
             ra = rec[3 * (size_t)id_next]; rb = rec[3 * (size_t)id_next + 1]; rc = rec[3 * (size_t)id_next + 2];
@@ -905,44 +959,50 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
         auto entry = [&](const int j) __attribute__((always_inline)) {
             const float4 a = sA[wave][j];
             const float4 b = sB[wave][j];
-            const float4 c = sC[wave][j];
+            const float c_x = sC[wave][j].x;
             contributor += 1u;
             asm volatile("" : "+v"(contributor));
             const float dx = a.x - pfx;
             const float cxdx = a.z * dx;
             const float qx = cxdx * dx;
             const float cydx = a.w * dx;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // lanes of one k form a 16x4 pixel strip: skip the strip when no pixel can reach alpha >= 1/255
-                const float dy = a.y - pfy[k];
-                const float q = FMA(b.x * dy, dy, qx);
-                const float power = FMA(-0.5f, q, -(cydx * dy));
-                // wave-wide "any pixel of the strip live": compare intrinsics deliver the lane masks in SGPR pairs, so
-                // the test is 2 v_cmp + s_and + s_cbranch_scc (ballot(bool) costs two more VALU slots per strip);
-                // power > 0 (degenerate conic) is rejected by `valid` below
-                const unsigned long long live_mask = alive[k] & __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
-                if (live_mask != 0ull) {
-                    sm[k] |= jbit;
-                    const float G = exp_det_noclamp(power);
-                    const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
-                    // lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255)
-                    const unsigned long long valid = alive[k] & __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE */) &
-                                                     __builtin_amdgcn_fcmpf(alpha, E3_ALPHA_SKIP, 11 /* UGE */);
-                    const float w = alpha * T[k];
-                    const float test_T = T[k] - w;
-                    const unsigned long long stop = valid & __builtin_amdgcn_fcmpf(test_T, E3_T_STOP, 4 /* OLT */);
-                    const bool apply = __builtin_amdgcn_inverse_ballot_w64(valid & ~stop);
-                    // one select instead of five: a zero weight leaves C and T bit-unchanged (x + 0*c == x, x - 0 == x)
-                    const float we = apply ? w : 0.0f;
-                    C0[k] = FMA(b.z, we, C0[k]);
-                    C1[k] = FMA(b.w, we, C1[k]);
-                    C2[k] = FMA(c.x, we, C2[k]);
-                    last[k] = apply ? contributor : last[k];
-                    T[k] = T[k] - we;                     // a pixel that stops here keeps its T and leaves the mask
-                    alive[k] &= ~stop;
-                }
-            }
+            // lanes of one k form a 16x4 pixel strip: skipped with one scalar bit test when
+            // the staging-time pre-test (strip_pretest) found that no pixel of it can reach alpha >= 1/255, or when all its
+            // pixels have finished
+#define E3_FWD_STRIP(k)                                                                                                     \
+            {                                                                                                               \
+                if ((gm[k] & jbit) == 0ull) goto skip##k;                                                                   \
+                const float dy = a.y - pfy[k];                                                                              \
+                const float q = FMA(b.x * dy, dy, qx);                                                                      \
+                const float power = FMA(-0.5f, q, -(cydx * dy));                                                            \
+                const float G = exp_det_noclamp(power);                                                                     \
+                const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);                                                         \
+                /* lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255) */                             \
+                const unsigned long long valid = alive[k] & __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE */) &             \
+                                                 __builtin_amdgcn_fcmpf(alpha, E3_ALPHA_SKIP, 11 /* UGE */);                \
+                const float w = alpha * T[k];                                                                               \
+                const float test_T = T[k] - w;                                                                              \
+                const unsigned long long stop = valid & __builtin_amdgcn_fcmpf(test_T, E3_T_STOP, 4 /* OLT */);             \
+                /* app = valid & ~stop: the pixels the entry is composited on; the strip-mask bit for the backward is set   \
+                   only when there is one (s_andn2 leaves "result != 0" in SCC: one s_cselect, no compare) */               \
+                unsigned long long app, bit;                                                                                \
+                asm("s_andn2_b64 %0, %2, %3\n\ts_cselect_b64 %1, %4, 0"                                                     \
+                    : "=&s"(app), "=s"(bit) : "s"(valid), "s"(stop), "s"(jbit) : "scc");                                    \
+                sm[k] |= bit;                                                                                               \
+                const bool apply = __builtin_amdgcn_inverse_ballot_w64(app);                                                \
+                /* one select instead of five: a zero weight leaves C and T bit-unchanged (x + 0*c == x, x - 0 == x) */     \
+                const float we = apply ? w : 0.0f;                                                                          \
+                C0[k] = FMA(b.z, we, C0[k]);                                                                                \
+                C1[k] = FMA(b.w, we, C1[k]);                                                                                \
+                C2[k] = FMA(c_x, we, C2[k]);                                                                                \
+                last[k] = apply ? contributor : last[k];                                                                    \
+                T[k] = T[k] - we;                     /* a pixel that stops here keeps its T and leaves the mask */         \
+                /* alive &= ~stop; when the strip's last pixel has finished no entry evaluates it again (gm = 0) */         \
+                asm("s_andn2_b64 %0, %0, %2\n\ts_cselect_b64 %1, %1, 0" : "+s"(alive[k]), "+s"(gm[k]) : "s"(stop) : "scc");  \
+            }                                                                                                               \
+            skip##k:;
+            E3_FWD_STRIP(0) E3_FWD_STRIP(1) E3_FWD_STRIP(2) E3_FWD_STRIP(3)
+#undef E3_FWD_STRIP
             jbit <<= 1;
         };
         // two entries per trip: halves the loop bookkeeping (counter, LDS address, branch) of an issue-bound loop

@@ -601,6 +601,8 @@ def forward_multi_capacity(means3D, sh, opacities, scales, rotations, settings_l
             _lib.ptr(rots_c), *arrays, _lib.ptr(out_color), _lib.ptr(radii), int(bool(rs.debug)), flags, int(capacity),
             count_host.data_ptr(), notify, None, _lib.current_stream())
     _lib.check(rc, "e3dgs_rasterize_forward_multi_capacity")
+    if P == 0:
+        count_host[0] = 0          # (no kernel runs for an empty scene: nothing would ever store the count)
     return dict(color=out_color, radii=radii, num_rendered=int(capacity) if P else 0, capacity=int(capacity), M=M,
                 settings=rs, settings_list=list(settings_list),
                 flags=(flags & ~(_lib.FLAG_COUNT_MAPPED | _lib.FLAG_DEFER_COLOR)) | _lib.FLAG_COUNT_DEVICE,

@@ -87,7 +87,7 @@ class EventTrainer:
         #                parameters.  Same bytes on the links; the replicas stay bit-identical (everyone receives the same
         #                updated shards).  The moments of the other ranks' shards are stale on this rank until
         #                sync_optimizer_state() gathers them (export, densification, checkpoints do).
-        sched = os.environ.get("E3DGS_DP_SCHEDULE") or dp_schedule or "allreduce"
+        sched = dp_schedule or os.environ.get("E3DGS_DP_SCHEDULE") or "allreduce"      # (argument first, as factorize_sh)
         if sched not in ("allreduce", "rs_ag"):
             raise ValueError("dp_schedule must be 'allreduce' or 'rs_ag'")
         self.dp_schedule = sched if self.world > 1 else "allreduce"
@@ -135,13 +135,16 @@ class EventTrainer:
         # render #1 == render #2 of an event iteration (same pose) rendered once: see compute_gradients()
         self.share_coincident_views = os.environ.get("E3DGS_SHARE_VIEWS", "1") != "0"
         self.shared_pose_iterations = 0
+        self._share_stats_on = False
         self._coincide = {}
         self._dstat = None             # render #1's own pixel gradient on shared-pose iterations that collect statistics
         self._instances_per_view = 0.0 # of the last forward whose count is known (_note_count)
         self._capacity = {}            # (N, views, H, W) -> instances the binning buffers are sized for
         self.count_retries = 0         # iterations repeated because the count exceeded the capacity
-        self._packed = None            # this rank's [3 x P x 3 colour gradients | 3 x 3 camera centres]
-        self._gathered = None
+        self._packed = None            # this rank's [nv x P x 3 colour gradients | nv x 3 camera centres]: a prefix of
+        self._gathered = None          # _packed_store (room for three views, allocated once per N)
+        self._packed_store = None
+        self._gathered_store = None
         self._packed_views = 0         # views whose colour gradients the last backward left in _packed (0: none)
         self._packed_cams = None       # (camera-centre tensors, versions) whose values sit in the tail of _packed
         self._xyz_prev = None          # the means the gradients were computed with (Adam moves them meanwhile)
@@ -217,7 +220,11 @@ class EventTrainer:
     def export_groups(self):
         """Reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]  (scene/gaussian_model.py:154-163 groups)."""
         self.sync_features()
-        self.sync_optimizer_state()
+        if self._shard is not None and self.world > 1:
+            # (rs_ag: the moments of the other ranks' shards are stale here, and gathering them is a COLLECTIVE -- hidden
+            # inside an export that typically only rank 0 performs it would deadlock the job)
+            raise RuntimeError("dp_schedule='rs_ag': the Adam moments are sharded over the ranks -- call "
+                               "sync_optimizer_state() on EVERY rank before export_groups() / checkpointing")
         N = self.N
         out = {}
         for idx, buf in enumerate((self.flat, self.exp_avg, self.exp_avg_sq)):
@@ -344,16 +351,21 @@ class EventTrainer:
 
     def step(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
         """One event iteration (train.py:97-332 without densification).  Returns the device scalars tensor of
-        the loss kernel ([0] = loss; one of two alternating buffers -- valid until the step after the next one).  The
+        the loss kernel ([0] = loss; a copy the caller owns, as step_image() returns).  The
         three renders are ONE multi-view pass of the rasteriser (every kernel of the pipeline runs once over the three
         cameras), forward and backward.  Nothing waits for the host: forward, loss and backward are enqueued back to back
         with binning buffers sized from earlier instance counts; the host reads this iteration's count once the backward
         is enqueued and only then enqueues the optimizer step (_count_fits).  When cam_int and cam_now are the same view
         (the reference's datasets: compute_gradients) that view is rendered once -- two views per iteration."""
+        return self.step_nocopy(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur, sync_grads).clone()
+
+    def step_nocopy(self, cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur=None, sync_grads=True):
+        """step() without the copy of its result: returns a VIEW of one of two alternating scalar blocks, valid until the
+        step after the next one (a loop that only logs the current loss)."""
         scalars = self.compute_gradients(cam_int, cam_now, cam_next, gt_int, gt_now, gt_next, bg, gt_blur,
                                          sh_via_colour=self.sh_via_colour and not self.overlap_features)
         self.apply_update(sync_grads)
-        return scalars                # (one of two alternating buffers: valid until the step after the next one)
+        return scalars
 
     def apply_update(self, sync_grads=True, skip=()):
         """Gradient averaging over the ranks (if any) + Adam (train.py:210-212,330-332) for the iteration whose gradients
@@ -460,6 +472,7 @@ class EventTrainer:
                 self._feat_event = side.record_event()
 
     CAPACITY_MARGIN = 1.25
+    CAPACITY_KEYS = 4
 
     def _forward_views(self, settings):
         """The renders of one iteration as ONE multi-view pass.  Without a known capacity (first iteration, new size):
@@ -497,7 +510,10 @@ class EventTrainer:
             return
         cap = self._capacity.get(key)
         if cap is None or count > 0.95 * cap:          # (stable otherwise: the scratch pool and its pointers stay put)
-            self._capacity = {key: int(count * self.CAPACITY_MARGIN) + 65536}      # one frame size at a time
+            self._capacity.pop(key, None)
+            while len(self._capacity) >= self.CAPACITY_KEYS:         # the most recent few (views, frame size) combinations:
+                self._capacity.pop(next(iter(self._capacity)))       # 2- and 3-view iterations alternate on real datasets
+            self._capacity[key] = int(count * self.CAPACITY_MARGIN) + 65536
 
     def _count_fits(self, raw):
         """For a pre-sized forward: wait for its instance count (the GPU produced it early in the iteration; by now it is
@@ -553,7 +569,11 @@ class EventTrainer:
             # duration (800 x 800: 30 k Gaussians 0.53 ms with three renders, 0.55 ms shared + statistics, 200 k: 0.95 /
             # 0.91; 1080p: 500 k 1.96 / 1.74, 1 M 2.52 / 2.25 -- tools/shared_pose_time.py)
             tiles = ((settings[0].image_width + 15) // 16) * ((settings[0].image_height + 15) // 16)
-            if tiles < self.SHARE_STATS_MIN_TILES or self._instances_per_view < self.SHARE_STATS_MIN_INSTANCES:
+            # (hysteresis: the decision only flips when the instance count leaves a +-10 % band around the threshold, so a
+            # scene that hovers there does not alternate between two- and three-view iterations)
+            lim = self.SHARE_STATS_MIN_INSTANCES * (0.9 if self._share_stats_on else 1.1)
+            self._share_stats_on = tiles >= self.SHARE_STATS_MIN_TILES and self._instances_per_view >= lim
+            if not self._share_stats_on:
                 shared = False
         if shared:
             settings = [settings[0], settings[2]]
@@ -599,9 +619,19 @@ class EventTrainer:
         rank rendered a shared-pose iteration with two views."""
         n_real, P = len(settings), self.N
         nv = max(n_real, pad_to or 0)
-        if self._packed is None or self._packed.numel() != nv * P * 3 + nv * 3:
-            self._packed = torch.empty(nv * P * 3 + nv * 3, dtype=torch.float32, device=self.device)
-            self._gathered = torch.empty(self.world, self._packed.numel(), dtype=torch.float32, device=self.device)
+        # (storage for three views, allocated once: iterations with one, two and three views alternate on real datasets and
+        # must not reallocate 9 P floats -- and the gather buffer -- each time; the active block is a prefix)
+        need = max(nv, 3) * (P * 3 + 3)
+        if self._packed_store is None or self._packed_store.numel() != need:
+            self._packed_store = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._gathered_store = torch.empty(self.world, need, dtype=torch.float32, device=self.device) \
+                if self.world > 1 else None
+            self._packed_cams = None
+        if self._packed is None or self._packed.numel() != nv * (P * 3 + 3) or \
+                self._packed.data_ptr() != self._packed_store.data_ptr():
+            self._packed = self._packed_store[:nv * (P * 3 + 3)]
+            self._gathered = None if self._gathered_store is None else \
+                self._gathered_store.view(-1)[:self.world * self._packed.numel()].view(self.world, -1)
             self._packed_cams = None
         self._packed_views = nv
         out["sh"] = None
@@ -651,6 +681,8 @@ class EventTrainer:
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
         if self.factorize_sh or sh_via_colour:
+            # (several ranks: the block always holds three views -- a rank that rendered a shared-pose iteration pads with
+            # zero gradients -- so the all-gather blocks keep one size)
             self._colour_gradients_instead_of_sh(out, settings, pad_to=3 if self.world > 1 else None)
         if want_vs:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)

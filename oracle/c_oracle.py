@@ -62,6 +62,7 @@ def lib():
     L.gso_backward.argtypes = [vp, fp] + [fp] * 9
     L.gso_exp_det.restype = C.c_float
     L.gso_exp_det.argtypes = [C.c_float]
+    L.gso_activate.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp]
     L.gso_knn3.argtypes = [C.c_int, fp, fp]
     L.gso_event_loss.argtypes = [C.c_int, C.c_int] + [fp] * 7 + [C.c_float, C.c_float, fp, fp, fp,
                                                                  C.POINTER(C.c_double)]
@@ -184,6 +185,35 @@ class Forward:
 def exp_det(x):
     L = lib()
     return np.array([L.gso_exp_det(float(v)) for v in np.asarray(x, np.float32).reshape(-1)], np.float32)
+
+
+def activate(log_scales=None, raw_rotations=None, logit_opacities=None):
+    """gso_activate(): the oracle's deterministic exp / normalize / sigmoid (scene/gaussian_model.py:33-41,95-118) of
+    the RAW parameters -- what the E3DGS_FLAG_PREACT kernels compute.  Returns (scales, rotations, opacities)."""
+    n = [np.asarray(a).reshape(-1, k).shape[0] for a, k in ((log_scales, 3), (raw_rotations, 4), (logit_opacities, 1))
+         if a is not None]
+    P = n[0]
+    assert all(m == P for m in n)
+    ins = [_f(None if a is None else np.asarray(a, np.float32).reshape(P, k))
+           for a, k in ((log_scales, 3), (raw_rotations, 4), (logit_opacities, 1))]
+    outs = [None if a is None else np.zeros((P, k), np.float32)
+            for a, k in ((log_scales, 3), (raw_rotations, 4), (logit_opacities, 1))]
+    p = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+    lib().gso_activate(P, ins[0][1], ins[1][1], ins[2][1], p(outs[0]), p(outs[1]), p(outs[2]))
+    return tuple(outs)
+
+
+def activate_backward(raw_rotations, scales, rotations, opacities, g_scales, g_rotations, g_opacities):
+    """Chain rule of activate() in float64: gradients w.r.t. the activated values -> w.r.t. the raw parameters
+    (d exp = s, d sigmoid = o (1 - o), d normalize = (g - q^ (q^ . g)) / |q|)."""
+    s, o = np.asarray(scales, np.float64), np.asarray(opacities, np.float64).reshape(-1, 1)
+    qh = np.asarray(rotations, np.float64)
+    nrm = np.maximum(np.linalg.norm(np.asarray(raw_rotations, np.float64), axis=1, keepdims=True), 1e-12)
+    gs = np.asarray(g_scales, np.float64).reshape(s.shape) * s
+    go = np.asarray(g_opacities, np.float64).reshape(o.shape) * o * (1.0 - o)
+    gq = np.asarray(g_rotations, np.float64).reshape(qh.shape)
+    gq = (gq - qh * (qh * gq).sum(axis=1, keepdims=True)) / nrm
+    return gs, gq, go
 
 
 def knn3(points):

@@ -75,6 +75,29 @@ static inline float exp_det(float x) {
 }
 float gso_exp_det(float x) { return exp_det(x); }
 
+/* Activations of the raw parameters (scene/gaussian_model.py:33-41 setup_functions, :95-118 getters):
+ *   scaling = exp(_scaling), opacity = sigmoid(_opacity), rotation = F.normalize(_rotation) (eps 1e-12).
+ * The rasteriser's fused entry points take the RAW parameters (E3DGS_FLAG_PREACT) and apply these inside the projection
+ * kernel; this function is the oracle's statement of them, operation for operation: exp is exp_det (the same
+ * deterministic polynomial as in compositing; |rel err| < 2e-6 against exp() on |x| <= 20), division and sqrt are IEEE,
+ * the norm is one explicit fmaf chain.  gso_forward() fed these values must equal the PREACT kernels bit for bit.
+ * Any of the three inputs may be NULL. */
+void gso_activate(int P, const float *log_scales /*P,3*/, const float *raw_rots /*P,4*/, const float *logit_opac /*P*/,
+                  float *scales, float *rots, float *opac) {
+    for (int i = 0; i < P; ++i) {
+        if (log_scales) {
+            for (int k = 0; k < 3; ++k) scales[3 * i + k] = exp_det(log_scales[3 * i + k]);
+        }
+        if (raw_rots) {
+            const float *q = raw_rots + 4 * i;
+            float nrm = sqrtf(FMA(q[0], q[0], FMA(q[1], q[1], FMA(q[2], q[2], q[3] * q[3]))));
+            float qinv = 1.0f / fmaxf(nrm, 1e-12f);
+            for (int k = 0; k < 4; ++k) rots[4 * i + k] = q[k] * qinv;
+        }
+        if (logit_opac) opac[i] = 1.0f / (1.0f + exp_det(-logit_opac[i]));
+    }
+}
+
 /* flat[4*c + r]: row r of the column-vector matrix applied to (x,y,z,1) */
 #define XFORM(M, r, x, y, z) FMA((M)[(r)], (x), FMA((M)[4 + (r)], (y), FMA((M)[8 + (r)], (z), (M)[12 + (r)])))
 

@@ -126,28 +126,26 @@ def _n_contrib_equal_after_mapping(pl_h, rg_h, nc_h, pl_o, rg_o, nc_o, W, H, r0,
 def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
     """The path bench.py TIMES against the C oracle at full size: ONE multi-view pass (rasterizer.forward_multi /
     backward_multi) with the trainer's flags -- activations inside the kernels (E3DGS_FLAG_PREACT) on the raw parameters,
-    coefficient-major SH (E3DGS_FLAG_SH_PLANAR) -- instead of single-view calls on torch-activated AoS inputs
-    (window_parity).  The oracle gets the parameters activated with torch on the CPU and composites one window of tile
-    rows per view; the pixel gradients are supported on those windows; its gradients are summed over the views and taken
-    through torch's activations (chain rule by autograd) to the raw parameters.
+    coefficient-major SH (E3DGS_FLAG_SH_PLANAR) -- instead of single-view calls on activated AoS inputs (window_parity).
+    The oracle activates the raw parameters with its own statement of scene/gaussian_model.py:33-41 (gso_activate:
+    deterministic exp / sigmoid / normalize, the operations the kernels perform) and composites one window of tile rows
+    per view; the pixel gradients are supported on those windows; its gradients are summed over the views and taken
+    through the activations' chain rule (c_oracle.activate_backward, float64) to the raw parameters.
 
-    The in-kernel activations differ from torch's by <= 1 ulp, and the rasteriser is discontinuous at its thresholds, so
-    -- unlike window_parity -- a handful of pixels / Gaussians may gain or lose ONE borderline contribution: the result
-    reports how many."""
+    Same contract as the operator path: radii, final_T and the image bit for bit, gradients <= 1e-3 per Gaussian."""
     from event_3dgs_amd import rasterizer
     from oracle import c_oracle
     dev = trainer.device
-    raw_cpu = {k: t.detach().cpu().clone().requires_grad_(True) for k, t in trainer.views.items()}
-    scales_a = torch.exp(raw_cpu["scaling"])
-    rots_a = torch.nn.functional.normalize(raw_cpu["rotation"])
-    opac_a = torch.sigmoid(raw_cpu["opacity"])
-    shs_np = np.ascontiguousarray(raw_cpu["features"].detach().t().reshape(-1, 16, 3).numpy())
+    raw_cpu = {k: t.detach().cpu().numpy() for k, t in trainer.views.items()}
+    scales_a, rots_a, opac_a = c_oracle.activate(raw_cpu["scaling"], raw_cpu["rotation"], raw_cpu["opacity"])
+    shs_np = np.ascontiguousarray(raw_cpu["features"].T.reshape(-1, 16, 3))
     P = raw_cpu["xyz"].shape[0]
     W, H = int(cams[0].image_width), int(cams[0].image_height)
     settings = [trainer._settings(c, bg) for c in cams]
     v = trainer.views
     hip = rasterizer.forward_multi(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
                                    flags=trainer.FWD_FLAGS)
+    st = rasterizer.state_views_multi(hip, P, W, H) if hasattr(rasterizer, "state_views_multi") else None
     gw = np.zeros((len(cams), 3, H, W), np.float32)
     rng = np.random.default_rng(grad_seed)
     res = {"views": []}
@@ -155,26 +153,27 @@ def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
     for k, (cam, (r0, r1)) in enumerate(zip(cams, rows_per_view)):
         y0, y1 = r0 * 16, min(H, r1 * 16)
         gw[k, :, y0:y1] = rng.standard_normal((3, y1 - y0, W)).astype(np.float32)
-        f = c_oracle.Forward(means3D=raw_cpu["xyz"].detach().numpy(), opacities=opac_a.detach().numpy(),
+        f = c_oracle.Forward(means3D=raw_cpu["xyz"], opacities=opac_a,
                              viewmatrix=cam.world_view_transform.contiguous().cpu().numpy(),
                              projmatrix=cam.full_proj_transform.cpu().numpy(),
                              campos=cam.camera_center.contiguous().cpu().numpy(), bg=bg.cpu().numpy(), width=W, height=H,
                              tanfovx=settings[k].tanfovx, tanfovy=settings[k].tanfovy, shs=shs_np, sh_degree=3,
-                             scales=scales_a.detach().numpy(), rotations=rots_a.detach().numpy(), tile_rows=(r0, r1))
+                             scales=scales_a, rotations=rots_a, tile_rows=(r0, r1))
         d = np.abs(hip["color"][k][:, y0:y1].cpu().numpy() - f.out_color[:, y0:y1])
-        res["views"].append({"image_max_abs": float(d.max()), "pixels_off_by_1e-4": float((d > 1e-4).mean()),
-                             "radii_mismatch": int((hip["radii"][k].cpu().numpy() != f.radii).sum()),
-                             "visible": int((f.radii > 0).sum())})
+        view = {"image_max_abs": float(d.max()), "pixels_off_by_1e-4": float((d > 1e-4).mean()),
+                "radii_mismatch": int((hip["radii"][k].cpu().numpy() != f.radii).sum()),
+                "visible": int((f.radii > 0).sum())}
+        if st is not None:
+            view["final_T_equal"] = bool(np.array_equal(st["final_T"][k][y0:y1].cpu().numpy(), f.final_T[y0:y1]))
+        res["views"].append(view)
         gb = f.backward(gw[k])
         for name in acc:
             acc[name] = acc[name] + np.asarray(gb[name], np.float64)
         f.close()
-    # oracle gradients w.r.t. the RAW parameters: torch's chain rule through exp / normalize / sigmoid
-    t64 = lambda a, like: torch.from_numpy(np.asarray(a)).to(like.dtype).reshape(like.shape)
-    torch.autograd.backward([scales_a, rots_a, opac_a], [t64(acc["scales"], scales_a), t64(acc["rotations"], rots_a),
-                                                          t64(acc["opacities"], opac_a)])
-    ref = {"xyz": acc["means3D"], "scaling": raw_cpu["scaling"].grad.numpy(), "rotation": raw_cpu["rotation"].grad.numpy(),
-           "opacity": raw_cpu["opacity"].grad.numpy(),
+    # oracle gradients w.r.t. the RAW parameters: chain rule through exp / normalize / sigmoid
+    gs, gq, go = c_oracle.activate_backward(raw_cpu["rotation"], scales_a, rots_a, opac_a, acc["scales"], acc["rotations"],
+                                            acc["opacities"])
+    ref = {"xyz": acc["means3D"], "scaling": gs, "rotation": gq, "opacity": go,
            "features": np.ascontiguousarray(acc["shs"].reshape(P, 48).T)}              # (P,16,3) -> (48,P) planar
     e = lambda like: torch.full_like(like, float("nan"))
     out = dict(means3D=e(v["xyz"]), sh=e(v["features"]), opacities=e(v["opacity"]), scales=e(v["scaling"]), rots=e(v["rotation"]))
@@ -191,9 +190,21 @@ def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
         a2, b2 = a.reshape(P, -1), b.reshape(P, -1)
         scale = 1e-3 * np.abs(b2).max()
         per = np.abs(a2 - b2).max(axis=1) / (np.abs(b2).max(axis=1) + scale)
-        res["grad"][name] = {"rel_l2": rel_l2(a2, b2), "per_gaussian_q999": float(np.quantile(per, 0.999)),
+        res["grad"][name] = {"rel_l2": rel_l2(a2, b2), "per_gaussian_max": float(per.max()),
+                             "per_gaussian_q999": float(np.quantile(per, 0.999)),
                              "per_gaussian_over_1e-3": int((per > 1e-3).sum())}
     return res
+
+
+def assert_trainer_path_parity(res, grad_l2=1e-3, grad_pg=1e-3):
+    """The operator's contract on the fused (PREACT, multi-view) path: no exceptions."""
+    for v in res["views"]:
+        assert v["radii_mismatch"] == 0, v
+        assert v["image_max_abs"] == 0.0, v
+        assert v.get("final_T_equal", True), v
+    for name, g in res["grad"].items():
+        assert g["rel_l2"] <= grad_l2, (name, g)
+        assert g["per_gaussian_max"] <= grad_pg and g["per_gaussian_over_1e-3"] == 0, (name, g)
 
 
 def assert_window_parity(res, grad_l2=1e-3, grad_pg=1e-3):

@@ -118,20 +118,16 @@ def test_cfg3_full_size_gradient_parity_per_gaussian(cfg3, view, rows):
 def test_cfg3_the_path_the_benchmark_times_against_the_oracle(cfg3):
     """helpers.trainer_path_parity: ONE multi-view pass with in-kernel activations and coefficient-major SH -- the
     calls EventTrainer.step (and bench.py) make -- for the three cfg3 cameras against the C oracle, not via the
-    single-view operator.  A few borderline pixels / Gaussians may flip (<= 1-ulp activations at the rasteriser's
-    thresholds); everything else agrees as in the single-view test."""
-    from helpers import trainer_path_parity
+    single-view operator.  The kernels' activations are the oracle's (gso_activate: deterministic exp / sigmoid /
+    normalize, scene/gaussian_model.py:33-41), so the contract is the operator's: every radius equal, the image bit for
+    bit, every Gaussian's gradient within 1e-3 -- no exceptions."""
+    from helpers import assert_trainer_path_parity, trainer_path_parity
     tr, cams, bg, _ = cfg3
     res = trainer_path_parity(tr, cams, bg, [(32, 34), (0, 2), (66, 68)])
     print("cfg3 trainer path", res)
     for v in res["views"]:
         assert v["visible"] > 600_000
-        assert v["radii_mismatch"] <= 8
-        assert v["image_max_abs"] <= 1.0 / 255.0 + 1e-6 and v["pixels_off_by_1e-4"] <= 2e-4
-    for name, g in res["grad"].items():
-        assert g["rel_l2"] <= 1e-3, (name, g)
-        assert g["per_gaussian_q999"] <= 1e-3, (name, g)
-        assert g["per_gaussian_over_1e-3"] <= 200, (name, g)              # of 1 M Gaussians
+    assert_trainer_path_parity(res)
 
 
 def test_cfg4_full_size_deblur_iteration(cfg3):

