@@ -37,7 +37,9 @@ __device__ __forceinline__ void render_bwd_body(
     const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
     float* __restrict__ part /* (I,9) per-instance records at their SLOTS, packed: mx my A B C o c0 c1 c2 */,
     const float* __restrict__ dL_dpix2 /* STATS: (3,H,W) second pixel gradient of view 0 */,
-    float* __restrict__ part2 /* STATS: (I,2) NDC-unit screen-space mean gradient under dL_dpix2, view-0 slots */) {
+    float* __restrict__ part2 /* STATS: (I,2) NDC-unit screen-space mean gradient under dL_dpix2, view-0 slots */,
+    const uint32_t* __restrict__ lpt_cnt /* order == NULL: the backward's per-class tile lists (ImageState::lpt_*) */,
+    const uint32_t* __restrict__ lpt_list, uint32_t lpt_cap) {
     // the 64 staged records of a round, 48 B each: one LDS address per entry, the three 16-B broadcasts are immediate
     // offsets of it (three separate arrays cost two more address adds per entry); 48-B stride keeps the staging stores
     // conflict-free (8 lanes x 16 B per LDS cycle land on 32 distinct banks)
@@ -64,7 +66,8 @@ __device__ __forceinline__ void render_bwd_body(
     asm volatile("" : "+v"(recs_base_v));       // the same address kept in a VGPR for the per-entry v_mad
     const int unit = blockIdx.x * BWD_WAVES + wave;
     if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
-    const int tile = __builtin_amdgcn_readfirstlane((int)order[unit]);   // global tile id (made scalar: see render_fwd_kernel)
+    // global tile id (made scalar: see render_fwd_kernel)
+    const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[unit] : lpt_lookup(lpt_cnt, lpt_list, lpt_cap, (uint32_t)unit, lane));
     if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
@@ -347,16 +350,17 @@ __device__ __forceinline__ void render_bwd_body(
         int W, int H, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ emit_gid,                           \
         const float4 *__restrict__ rec, const float *__restrict__ bg, const float *__restrict__ final_T,                 \
         const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ perm,                                       \
-        const uint8_t *__restrict__ strip_mask, const float *__restrict__ dL_dpix, float *__restrict__ part
+        const uint8_t *__restrict__ strip_mask, const float *__restrict__ dL_dpix, float *__restrict__ part,             \
+        const uint32_t *__restrict__ lpt_cnt, const uint32_t *__restrict__ lpt_list, uint32_t lpt_cap
 #define E3_RENDER_BWD_ARGS \
     trace, ntiles, tiles_per_view, order, gx, W, H, ranges, emit_gid, rec, bg, final_T, n_contrib, perm, strip_mask, dL_dpix, part
 // (two plain kernels around the one body: the profiles, the bench line and the reviews name `render_bwd_kernel`)
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(E3_RENDER_BWD_PARAMS) {
-    render_bwd_body<false>(E3_RENDER_BWD_ARGS, nullptr, nullptr);
+    render_bwd_body<false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap);
 }
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_kernel(
     E3_RENDER_BWD_PARAMS, const float* __restrict__ dL_dpix2, float* __restrict__ part2) {
-    render_bwd_body<true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2);
+    render_bwd_body<true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap);
 }
 
 // ------------------------------------------------------------------------------------ per-Gaussian backward
@@ -1181,18 +1185,25 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     ImageState img = ImageState::from(ip, (size_t)W * H * nv, ntiles);
     if (num_rendered > 0 && !(flags & E3_FLAG_BWD_ONLY_GEOM)) {
         ProfScope ps(PS_RENDER_BWD, s);
-        const int nslots = launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, img.work, img.order_bwd, s);
+        // launch order by the cost the forward measured per tile: per-class lists the forward kernel filled, or the
+        // ordering kernel (e3_use_lpt_lists: the same answer as in the forward)
+        const bool use_lpt = e3_use_lpt_lists(ntiles, num_rendered, P);
+        const int nslots = use_lpt ? ntiles : launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, img.work, img.order_bwd, s);
+        const uint32_t* ord = use_lpt ? nullptr : img.order_bwd;
+        const uint32_t* lc = img.lpt_cnt + E3_LPT_CLASSES;
+        const uint32_t* ll = img.lpt_list + (size_t)E3_LPT_CLASSES * ntiles;
         // (STATS: the second chain's records sit in the slack between the packed 9-float records and the per-splat sums:
         // the caller provides E3_ACC_STRIDE = 12 floats per instance)
         float* part2 = grad_acc + E3_REC_FLOATS * (size_t)num_rendered;
         if (dL_dpix_stats)
             render_bwd_stats_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-                g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, dL_dpix_stats, part2);
+                g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles,
+                dL_dpix_stats, part2);
         else
             render_bwd_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-                g_trace, nslots, tiles_per_view, img.order_bwd, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc);
+                g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles);
     }
     KERNEL_OK("render_bwd_kernel");
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;

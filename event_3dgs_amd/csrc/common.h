@@ -134,6 +134,28 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The tile a compositing wave owns when the launch order is kept as per-class lists (ImageState::lpt_*): the unit-th tile
+// in class order, or -1 behind the last one.  Wave-uniform; one 4-byte load per lane + one dependent load.
+// (E3_LPT_CLASSES = 128, declared with ImageState below: two classes per lane)
+__device__ __forceinline__ int lpt_lookup(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ list, uint32_t cap,
+                                          uint32_t unit, int lane) {
+    const uint2 c = reinterpret_cast<const uint2*>(cnt)[lane];                // classes 2 lane, 2 lane + 1
+    uint32_t inc = c.x + c.y;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(unit < inc);   // lanes whose inclusive prefix passes `unit`
+    if (hit == 0ull) return -1;
+    const int l = __builtin_ctzll(hit);
+    const uint32_t excl = (uint32_t)__builtin_amdgcn_readlane((int)(inc - c.x - c.y), l);
+    const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)c.x, l);
+    uint32_t idx = unit - excl, b = 2u * (uint32_t)l;
+    if (idx >= cx) { idx -= cx; b += 1u; }
+    return (int)list[(size_t)b * cap + idx];
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
@@ -265,6 +287,29 @@ __host__ __device__ static inline int e3_xcd_region(int tile, int tiles_per_view
     return ((tx / B) + 3 * (ty / B) + 5 * view) & 7;
 }
 
+// Launch order of the compositing kernels without an ordering kernel (E3_LPT_BUCKETS): the kernel that LEARNS a tile's
+// cost appends the tile to one of 128 cost classes -- log scale, 8 per octave, class 0 = heaviest -- with one atomic:
+// the last pass of the tile sort knows every list length when it writes the tile ranges (forward order), the forward
+// compositing kernel knows the backward walk's cost when a tile finishes (backward order).  The consumer's wave u finds
+// "the u-th tile in class order" itself: two counts per lane, a wave prefix sum, one ballot (lpt_lookup).  That removes two
+// single-workgroup launches (14-20 us each, alone on the GPU) and their four kernel boundaries from every iteration.  The
+// order inside a class is whatever the atomics produced: it only affects scheduling, never a result.
+#ifndef E3_LPT_SUB
+#define E3_LPT_SUB 3                                   // log2(classes per octave)
+#endif
+constexpr int E3_LPT_CLASSES = 128;                    // two per lane of the consumer's wave (lpt_lookup)
+__host__ __device__ static inline uint32_t e3_lpt_class(uint32_t cost) {
+    constexpr uint32_t S = E3_LPT_SUB, LIN = 1u << (S + 1);       // costs below LIN: one class each
+    if (cost < LIN) return (uint32_t)(E3_LPT_CLASSES - 1) - cost;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(cost);
+#else
+    uint32_t e = 0; while ((cost >> (e + 1)) != 0u) ++e;
+#endif
+    const uint32_t asc = LIN + ((e - (S + 1)) << S) + ((cost >> (e - S)) & ((1u << S) - 1u));
+    return asc >= (uint32_t)E3_LPT_CLASSES ? 0u : (uint32_t)(E3_LPT_CLASSES - 1) - asc;
+}
+
 struct ImageState {
     uint2* ranges;       // per tile [start, end) into BinningState::perm
     float* final_T;      // per pixel
@@ -272,6 +317,8 @@ struct ImageState {
     uint32_t* order;     // tiles by descending list length (launch order of the forward compositing kernel)
     uint32_t* work;      // per tile: entries the backward walk has to visit (max n_contrib), written by forward
     uint32_t* order_bwd; // tiles by descending `work` (launch order of the backward compositing kernel)
+    uint32_t* lpt_cnt;   // [2][E3_LPT_CLASSES] tiles per cost class: [0] forward order, [1] backward order (zeroed by preprocess)
+    uint32_t* lpt_list;  // [2][E3_LPT_CLASSES][ntiles] the tiles of each class
     static size_t required(size_t npix, size_t ntiles) {
         char* p = nullptr;
         from(p, npix, ntiles);
@@ -285,6 +332,8 @@ struct ImageState {
         s.order = carve<uint32_t>(p, 2 * ntiles + 64);        // XCD-partitioned orders leave holes (launch_tile_order)
         s.work = carve<uint32_t>(p, ntiles ? ntiles : 1);
         s.order_bwd = carve<uint32_t>(p, 2 * ntiles + 64);
+        s.lpt_cnt = carve<uint32_t>(p, 2 * E3_LPT_CLASSES);
+        s.lpt_list = carve<uint32_t>(p, 2 * (size_t)E3_LPT_CLASSES * (ntiles ? ntiles : 1));
         return s;
     }
 };
@@ -384,14 +433,21 @@ int launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint3
 // ranges_out:       after the sort, ranges_out[k] = [first, last + 1) positions of key k (k < nranges); keys without an
 //                   element keep what they held (an empty range).  A two-pass sort derives them inside its last pass and
 //                   writes no sorted keys (*keys_out = NULL).
+// lpt_cnt / lpt_list: (a two-pass sort with ranges_out) the last pass also appends every key value k < nranges to the list
+//                   of its cost class e3_lpt_class(run length): lpt_list[class * nranges + lpt_cnt[class]++] = k  (ImageState).
 int launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
                             bool identity_payload = false, uint32_t* drop_count_dev = nullptr,
-                            const uint32_t* n_dev = nullptr, uint2* ranges_out = nullptr, uint32_t nranges = 0);
+                            const uint32_t* n_dev = nullptr, uint2* ranges_out = nullptr, uint32_t nranges = 0,
+                            uint32_t* lpt_cnt = nullptr, uint32_t* lpt_list = nullptr);
 int launch_radix_sort_pairs_u16(uint16_t* k0, uint16_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                                 uint32_t* scratch, uint16_t** keys_out, uint32_t** vals_out, hipStream_t s,
                                 bool identity_payload = false, const uint32_t* n_dev = nullptr,
-                                uint2* ranges_out = nullptr, uint32_t nranges = 0);
+                                uint2* ranges_out = nullptr, uint32_t nranges = 0,
+                                uint32_t* lpt_cnt = nullptr, uint32_t* lpt_list = nullptr);
+// whether a forward with these sizes keeps its launch orders as per-class lists (both halves of the forward and the
+// backward must agree): a two-pass tile sort that derives the ranges, and no XCD-partitioned order requested
+bool e3_use_lpt_lists(int ntiles, int num_rendered, int P);
 static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 
 // ---------------------------------------------------------------- optional event profiler (capi.hip)

@@ -141,8 +141,9 @@ __global__ __launch_bounds__(256, E3_PRE_WAVES) void preprocess_kernel(
     float4* __restrict__ rec, uint32_t* __restrict__ clamped,
     uint2* __restrict__ rect, uint32_t* __restrict__ key,
     uint2* __restrict__ ranges_to_zero, int nranges, uint32_t* __restrict__ offsets0,
-    uint32_t* __restrict__ scan_desc, int ndesc) {
+    uint32_t* __restrict__ scan_desc, int ndesc, uint32_t* __restrict__ lpt_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * E3_LPT_CLASSES) lpt_cnt[i] = 0u;       // class counters of both launch orders (ImageState::lpt_cnt)
     // housekeeping that would otherwise be memset commands (each costs a barrier packet on the queue): the tile ranges,
     // offsets[0], and the descriptors of the single-launch scan behind the binning count pass
     for (int t = i; t < nranges; t += gridDim.x * blockDim.x) ranges_to_zero[t] = make_uint2(0u, 0u);
@@ -792,6 +793,16 @@ static int xcd_block() {
     return v;
 }
 
+static bool lpt_lists_enabled() {      // E3DGS_LPT_LISTS=0: ordering kernels as before (A/B switch)
+    static const bool v = [] { const char* e = getenv("E3DGS_LPT_LISTS"); return !(e && e[0] == '0'); }();
+    return v;
+}
+bool e3_use_lpt_lists(int ntiles, int num_rendered, int P) {
+    if (!lpt_lists_enabled() || xcd_block() > 0 || num_rendered <= 0 || P <= 0) return false;
+    // a TWO-pass tile sort (257 ... 65536 tiles per call) derives the ranges -- and the forward order -- in its last pass
+    return ntiles > 256 && ntiles <= 65536;
+}
+
 // Returns the number of launch slots (== ntiles unless the XCD-partitioned order is on).
 int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, const uint32_t* work, uint32_t* order,
                       hipStream_t s) {
@@ -877,7 +888,9 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     const uint32_t* __restrict__ emit_gid,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_work, uint8_t* __restrict__ strip_mask,
-    uint8_t* __restrict__ touched /* per slot, see BinningState */) {
+    uint8_t* __restrict__ touched /* per slot, see BinningState */,
+    uint32_t* __restrict__ lpt_cnt /* order == NULL: launch orders as per-class lists (ImageState::lpt_*) */,
+    uint32_t* __restrict__ lpt_list, uint32_t lpt_cap) {
     __shared__ float4 sA[RENDER_WAVES][WAVE];
     __shared__ float4 sB[RENDER_WAVES][WAVE];
     __shared__ float4 sC[RENDER_WAVES][WAVE];
@@ -887,7 +900,8 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     // (wave-uniform values are made scalar explicitly: the compiler cannot see that `wave` is uniform, and a loop whose
     // trip count sits in a VGPR is compiled as a divergent loop -- exec-mask bookkeeping per iteration, and every
     // scalar the loop carries copied to VGPRs at the latch)
-    const int tile = __builtin_amdgcn_readfirstlane((int)order[unit]);   // global tile id: view * tiles_per_view + local tile
+    // global tile id: view * tiles_per_view + local tile
+    const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[unit] : lpt_lookup(lpt_cnt, lpt_list, lpt_cap, (uint32_t)unit, lane));
     if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     int processed = 0;
@@ -1027,7 +1041,15 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
         // evaluated strip (measured: dense tiles cost ~2.4x more per entry than sparse ones)
         uint32_t mw = max(max(last[0], last[1]), max(last[2], last[3]));
         mw = wave_max_u32(mw);
-        if (lane == 0) tile_work[tile] = 2u * mw + (uint32_t)live_strips;
+        const uint32_t cost = 2u * mw + (uint32_t)live_strips;
+        if (lane == 0) {
+            tile_work[tile] = cost;
+            if (!order) {              // the backward's launch order: the tile joins the list of its cost class
+                const uint32_t cls = e3_lpt_class(cost);
+                const uint32_t pos = atomicAdd(&lpt_cnt[E3_LPT_CLASSES + cls], 1u);
+                lpt_list[((size_t)E3_LPT_CLASSES + cls) * lpt_cap + pos] = (uint32_t)tile;
+            }
+        }
     }
     if (trace && lane == 0) {
         trace[4 * (size_t)tile + 0] = t_start;
@@ -1132,7 +1154,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
                                                                             : preprocess_kernel<4, false>);
         kern<<<dim3(pb), dim3(256), 0, s>>>(P, M, means3D, shs, colors, opac, scales, rots, cov_pre, vs, flags, radii,
                                             geom.rec, geom.clamped, geom.rect, geom.key0, img.ranges, ntiles * nv,
-                                            geom.offsets, bin_scan_desc, (int)scan_desc_words(Q));
+                                            geom.offsets, bin_scan_desc, (int)scan_desc_words(Q), img.lpt_cnt);
         }
         KERNEL_OK("preprocess_kernel");
         uint32_t *keys_sorted, *order;
@@ -1189,6 +1211,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     char* bp = bin_alloc(bin_user, BinningState::required(I));
     if (!bp) return e3_fail(hipErrorOutOfMemory, "binning allocation callback returned NULL");
     BinningState bin = BinningState::from(bp, I);
+    const bool use_lpt = e3_use_lpt_lists(ntiles, num_rendered, P);
     if (I > 0 && P > 0) {
         // at least one pass even for a single tile: the first pass is what materialises the identity payload
         const int tile_bits = ntiles > 1 ? ceil_log2((uint32_t)ntiles) : 1;
@@ -1214,18 +1237,21 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         uint32_t* vs;
         {
         // stable sort by tile id; the [start, end) of every tile comes out of the same launches (img.ranges: zeroed by
-        // the preprocess kernel, tiles without an instance stay / are rewritten as (0, 0) by the ordering kernel)
+        // the preprocess kernel, tiles without an instance stay / are rewritten as (0, 0)), and so does the forward
+        // launch order when it is kept as per-class lists
         ProfScope ps(PS_SORT_TILE, s);
         int rc;
+        uint32_t* lc = use_lpt ? img.lpt_cnt : nullptr;
+        uint32_t* ll = use_lpt ? img.lpt_list : nullptr;
         if (keys16) {
             uint16_t* ks16;
             rc = launch_radix_sort_pairs_u16(reinterpret_cast<uint16_t*>(k0), reinterpret_cast<uint16_t*>(k1), v0, v1,
                                              (size_t)I, tile_bits, bin.scratch, &ks16, &vs, s, true, count_dev, img.ranges,
-                                             (uint32_t)ntiles);
+                                             (uint32_t)ntiles, lc, ll);
         } else {
             uint32_t* ks;
             rc = launch_radix_sort_pairs(k0, k1, v0, v1, (size_t)I, tile_bits, bin.scratch, &ks, &vs, s, true, nullptr,
-                                         count_dev, img.ranges, (uint32_t)ntiles);
+                                         count_dev, img.ranges, (uint32_t)ntiles, lc, ll);
         }
         if (rc) return rc;
         }
@@ -1233,7 +1259,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         if (vs != bin.perm) return e3_fail(hipErrorUnknown, "internal: sorted list not in perm");
     }
     int nslots = ntiles;
-    {
+    if (!use_lpt) {
     ProfScope ps(PS_RANGES, s);
     nslots = launch_tile_order(ntiles, tiles_per_view, gx, img.ranges, nullptr, img.order, s);
     }
@@ -1251,8 +1277,9 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     }
     ProfScope ps_render(PS_RENDER_FWD, s);
     render_fwd_kernel<<<dim3((nslots + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
-        g_trace, nslots, tiles_per_view, img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec, background,
-        out_color, img.final_T, img.n_contrib, img.work, bin.strip_mask, bin.touched);
+        g_trace, nslots, tiles_per_view, use_lpt ? nullptr : img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec,
+        background, out_color, img.final_T, img.n_contrib, img.work, bin.strip_mask, bin.touched, img.lpt_cnt, img.lpt_list,
+        (uint32_t)ntiles);
     KERNEL_OK("render_fwd_kernel");
     return 0;
 }

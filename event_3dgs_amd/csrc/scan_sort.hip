@@ -346,12 +346,15 @@ struct ScatterLds {
 // offs[h][first workgroup of low digit l] is exactly where the run of tile (h << 8 | l) starts, and the run ends
 // where the last workgroup of l puts its last key of h: the tile ranges fall out of numbers this kernel holds anyway --
 // no pass over the sorted keys (tile_ranges_kernel), no sorted keys at all.
-struct SegBlock { uint32_t first, count, low, is_first, is_last; };
+struct SegBlock { uint32_t first, count, low, is_first, is_last, first_block, valid; };
 __device__ __forceinline__ SegBlock seg_block(const uint32_t* __restrict__ seg, uint32_t b, uint32_t* s_tmp /* >= 8 words */) {
-    // thread d: segment d = [seg[d], seg[d+1]) is cut into ceil(len / SORT_TILE) workgroups; exclusive scan over d
+    // thread d: segment d = [seg[d], seg[d+1]) is cut into max(1, ceil(len / SORT_TILE)) workgroups -- an EMPTY segment keeps
+    // one (keyless) workgroup, so that every low digit, hence every key value, has a workgroup that writes its ranges --;
+    // exclusive scan over d.  (sum <= n / SORT_TILE + 256 workgroups: seg_blocks())
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
     const uint32_t s0 = seg[d], s1 = seg[d + 1];
-    const uint32_t nblk = (s1 - s0 + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t nblk_keys = (s1 - s0 + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t nblk = nblk_keys ? nblk_keys : 1u;
     uint32_t inc = nblk;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
@@ -369,11 +372,14 @@ __device__ __forceinline__ SegBlock seg_block(const uint32_t* __restrict__ seg, 
         s_tmp[2] = (uint32_t)d;
         s_tmp[3] = (k == 0 ? 1u : 0u) | (k + 1 == nblk ? 2u : 0u);
         s_tmp[4] = 0u;
+        s_tmp[5] = bf;
     }
     __syncthreads();
     SegBlock r;
-    r.first = s_tmp[0]; r.count = s_tmp[4] ? 0u : s_tmp[1]; r.low = s_tmp[2];
-    r.is_first = s_tmp[4] ? 0u : (s_tmp[3] & 1u); r.is_last = s_tmp[4] ? 0u : (s_tmp[3] >> 1);
+    r.valid = s_tmp[4] ? 0u : 1u;
+    r.first = s_tmp[0]; r.count = r.valid ? s_tmp[1] : 0u; r.low = s_tmp[2];
+    r.is_first = r.valid ? (s_tmp[3] & 1u) : 0u; r.is_last = r.valid ? (s_tmp[3] >> 1) : 0u;
+    r.first_block = s_tmp[5];
     __syncthreads();
     return r;
 }
@@ -416,7 +422,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
                                                                      const uint32_t* __restrict__ offs,
                                                                      unsigned nblocks,
                                                                      uint32_t* __restrict__ seg /* RANGES: in; else: out (or null) */,
-                                                                     uint2* __restrict__ ranges, uint32_t nranges) {
+                                                                     uint2* __restrict__ ranges, uint32_t nranges,
+                                                                     uint32_t* __restrict__ lpt_cnt,
+                                                                     uint32_t* __restrict__ lpt_list) {
     constexpr int NW = SORT_THREADS / WAVE;          // 4 waves
     constexpr int WAVE_KEYS = SORT_TILE / NW;        // 1024 consecutive keys per wave
     __shared__ ScatterLds<KeyT> L;
@@ -428,7 +436,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
         sb = seg_block(seg, blockIdx.x, L.seg_tmp);
         block_first = sb.first;
         n = (size_t)sb.first + sb.count;
-        if (sb.count == 0) return;                    // (uniform; no workgroup barrier is pending)
+        if (!sb.valid) return;                        // (uniform; no workgroup barrier is pending.  A valid workgroup
+                                                      // without keys -- an empty segment -- still writes its ranges below)
     } else {
         // segment boundaries of THIS pass's digit for a later RANGES pass: position of the first key of digit d = the
         // scanned counter of (d, workgroup 0)
@@ -489,14 +498,32 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
     for (int w = 0; w < wave; ++w) lbase += L.wtot[w];
     L.glob[d] = gfirst - lbase;
     if (d == SORT_THREADS - 1) L.nvalid = lbase + total;
-    if (RANGES) {
+    if (RANGES && sb.is_last) {
         // runs of the tiles (d << shift | low): they start where the FIRST workgroup of the low digit puts its first key
-        // of d and end behind the last key of d of the LAST one.  Plain stores, every word written at most once; tiles
-        // without a key keep an empty range (start == end; tile_order_reg_kernel rewrites those as (0, 0)).
+        // of d (its scanned counter) and end behind the last key of d of the LAST one -- this workgroup, which therefore
+        // knows both ends: one plain 8-byte store per tile, every tile written exactly once (every low digit has a last
+        // workgroup, seg_block), tiles without a key as the documented (0, 0).
         const uint32_t tile = ((uint32_t)d << shift) | sb.low;
-        if (tile < nranges) {                         // (digits beyond the last tile id hold no key)
-            if (sb.is_first) ranges[tile].x = gfirst;
-            if (sb.is_last) ranges[tile].y = gfirst + total;
+        const bool mine = tile < nranges;             // (digits beyond the last tile id hold no key)
+        const uint32_t start = offs[(size_t)d * nblocks + sb.first_block], end = gfirst + total;
+        if (mine) ranges[tile] = end > start ? make_uint2(start, end) : make_uint2(0u, 0u);
+        if (lpt_cnt) {
+            // launch order of the compositing kernel (ImageState::lpt_*): the tile joins the list of its cost class.  One
+            // atomic per (wave, class): the lanes of a class are matched with ballots, the first one reserves for all.
+            const uint32_t cls = e3_lpt_class(end - start);
+            unsigned long long peers = __ballot(mine);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {               // (E3_LPT_CLASSES = 128)
+                const unsigned long long bal = __ballot((cls >> b) & 1u);
+                peers &= ((cls >> b) & 1u) ? bal : ~bal;
+            }
+            if (mine) {
+                const int leader = __builtin_ctzll(peers);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&lpt_cnt[cls], (uint32_t)__popcll(peers));
+                base = (uint32_t)__shfl((int)base, leader, 64);
+                lpt_list[(size_t)cls * nranges + base + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull))] = tile;
+            }
         }
     }
     uint32_t l = lbase;
@@ -535,7 +562,8 @@ static inline unsigned seg_blocks(size_t n) { return (unsigned)(sort_blocks(n) +
 template <typename KeyT>
 static int radix_sort_pairs_t(KeyT* k0, KeyT* k1, uint32_t* v0, uint32_t* v1, size_t n, const uint32_t* n_dev_in, int nbits,
                               uint32_t* scratch, KeyT** keys_out, uint32_t** vals_out, hipStream_t s, bool identity_payload,
-                              uint32_t* drop_count_dev, uint2* ranges_out, uint32_t nranges) {
+                              uint32_t* drop_count_dev, uint2* ranges_out, uint32_t nranges, uint32_t* lpt_cnt,
+                              uint32_t* lpt_list) {
     KeyT *ki = k0, *ko = k1;
     uint32_t *vi = v0, *vo = v1;
     if (identity_payload && nbits < 1) nbits = 1;        // the payload (0, 1, 2, ...) only exists after a pass
@@ -573,13 +601,13 @@ static int radix_sort_pairs_t(KeyT* k0, KeyT* k1, uint32_t* v0, uint32_t* v1, si
             uint32_t* seg_arg = (ranges || (fuse_ranges && p == passes - 2)) ? seg : nullptr;
             if (ranges)
                 radix_scatter_kernel<KeyT, false, true, true><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(
-                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, ranges_out, nranges);
+                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, ranges_out, nranges, lpt_cnt, lpt_list);
             else if (drop)
                 radix_scatter_kernel<KeyT, true, false, false><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(
-                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, nullptr, 0u);
+                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, nullptr, 0u, nullptr, nullptr);
             else
                 radix_scatter_kernel<KeyT, false, false, false><<<dim3(blocks), dim3(SORT_THREADS), 0, s>>>(
-                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, nullptr, 0u);
+                    ki, vin, ko, vo, n, n_dev, shift, hist, blocks, seg_arg, nullptr, 0u, nullptr, nullptr);
             LAUNCH_OK("radix_scatter_kernel");
             if (drop) n_dev = drop_count_dev;           // the later passes sort the kept keys only
             KeyT* t = ki; ki = ko; ko = t;
@@ -598,14 +626,15 @@ static int radix_sort_pairs_t(KeyT* k0, KeyT* k1, uint32_t* v0, uint32_t* v1, si
 int launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                             uint32_t* scratch, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s,
                             bool identity_payload, uint32_t* drop_count_dev, const uint32_t* n_dev, uint2* ranges_out,
-                            uint32_t nranges) {
+                            uint32_t nranges, uint32_t* lpt_cnt, uint32_t* lpt_list) {
     return radix_sort_pairs_t<uint32_t>(k0, k1, v0, v1, n, n_dev, nbits, scratch, keys_out, vals_out, s, identity_payload,
-                                        drop_count_dev, ranges_out, nranges);
+                                        drop_count_dev, ranges_out, nranges, lpt_cnt, lpt_list);
 }
 
 int launch_radix_sort_pairs_u16(uint16_t* k0, uint16_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                                 uint32_t* scratch, uint16_t** keys_out, uint32_t** vals_out, hipStream_t s,
-                                bool identity_payload, const uint32_t* n_dev, uint2* ranges_out, uint32_t nranges) {
+                                bool identity_payload, const uint32_t* n_dev, uint2* ranges_out, uint32_t nranges,
+                                uint32_t* lpt_cnt, uint32_t* lpt_list) {
     return radix_sort_pairs_t<uint16_t>(k0, k1, v0, v1, n, n_dev, nbits > 16 ? 16 : nbits, scratch, keys_out, vals_out, s,
-                                        identity_payload, nullptr, ranges_out, nranges);
+                                        identity_payload, nullptr, ranges_out, nranges, lpt_cnt, lpt_list);
 }
