@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 NOTIFY_FN = C.CFUNCTYPE(None, C.c_void_p)
@@ -46,7 +46,7 @@ def lib():
                                                                                    C.c_int, _vp, _vp])
     L.e3dgs_rasterize_forward_finish.restype = C.c_int
     L.e3dgs_rasterize_forward_finish.argtypes = [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp, C.c_int, _fp,
-                                                 C.c_int, _vp]
+                                                 C.c_int, C.c_int, _vp]
     L.e3dgs_rasterize_backward.restype = C.c_int
     L.e3dgs_rasterize_backward.argtypes = (
         [C.c_int] * 4 + [_fp, C.c_int, C.c_int] + [_fp] * 5 + [C.c_float] + [_fp] * 5 + [C.c_float, C.c_float]
@@ -62,7 +62,7 @@ def lib():
         + [_ip, C.c_int, C.c_int, _vp, _vp])
     L.e3dgs_rasterize_forward_multi_finish.restype = C.c_int
     L.e3dgs_rasterize_forward_multi_finish.argtypes = [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp,
-                                                       C.c_int, _fp, C.c_int, _vp]
+                                                       C.c_int, _fp, C.c_int, C.c_int, _vp]
     L.e3dgs_rasterize_forward_multi_finish_colour.restype = C.c_int
     L.e3dgs_rasterize_forward_multi_finish_colour.argtypes = (
         [ALLOC_FN, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _cp, _cp, C.c_int, _fp, C.c_int]
@@ -94,6 +94,8 @@ def lib():
     L.e3dgs_state_offset_emit_gid.argtypes = [C.c_int]
     L.e3dgs_state_offsets.restype = None
     L.e3dgs_state_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)]
+    L.e3dgs_state_offsets_multi.restype = None
+    L.e3dgs_state_offsets_multi.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t)]
     L.e3dgs_mark_visible.restype = C.c_int
     L.e3dgs_mark_visible.argtypes = [C.c_int, _fp, _fp, _fp, _vp, _vp]
     L.e3dgs_knn_scratch_bytes.restype = C.c_size_t
@@ -175,14 +177,40 @@ FLAG_BWD_ONLY_GEOM = 16
 FLAG_COUNT_MAPPED = 64
 FLAG_DEFER_COLOR = 128
 FLAG_COUNT_DEVICE = 256
+# per-call options (include/e3dgs_hip.h): with FLAG_OPTIONS the bits describe the call and no process-wide default is read
+FLAG_OPTIONS = 0x0800
+FLAG_CULL_RECT = 0x1000
+FLAG_CULL_NO_BOX = 0x2000
+FLAG_NO_SMALL_PATHS = 0x4000
+FLAG_FAST_EXP = 0x8000
+OPTION_MASK = FLAG_OPTIONS | FLAG_CULL_RECT | FLAG_CULL_NO_BOX | FLAG_NO_SMALL_PATHS | FLAG_FAST_EXP
 ACC_STRIDE = 12
+
+
+def option_flags(tile_cull=None, small_scene_paths=None, fast_exp=False):
+    """The option bits of a call.  tile_cull: True / 1 exact culling, False / 0 the reference's rectangle binning, 3 exact
+    culling without the tight candidate box; small_scene_paths: adapt the work decomposition to few splats.  Leaving both
+    None keeps the process-wide defaults (environment E3DGS_TILE_CULL / E3DGS_SMALL_SCENE_PATHS, deprecated setters);
+    giving either makes the call self-describing (missing ones default to ON)."""
+    f = FLAG_FAST_EXP if fast_exp else 0
+    if tile_cull is None and small_scene_paths is None:
+        return f
+    f |= FLAG_OPTIONS
+    if tile_cull is not None:
+        if int(tile_cull) == 0:
+            f |= FLAG_CULL_RECT
+        elif int(tile_cull) == 3:
+            f |= FLAG_CULL_NO_BOX
+    if small_scene_paths is not None and not small_scene_paths:
+        f |= FLAG_NO_SMALL_PATHS
+    return f
 
 EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
     "e3dgs_rasterize_backward", "e3dgs_rasterize_forward_multi", "e3dgs_rasterize_forward_multi_begin",
     "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi", "e3dgs_rasterize_backward_multi_stats",
     "e3dgs_sh_grad_from_colour", "e3dgs_sh_adam_from_colour",
-    "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
+    "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offsets_multi", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_query", "e3dgs_profile_slot_name",
     "e3dgs_sort_scratch_bytes", "e3dgs_sort_pairs", "e3dgs_rasterize_forward_multi_capacity",
 ]

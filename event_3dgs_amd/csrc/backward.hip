@@ -29,7 +29,10 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 // pixel gradient `dL_dpix2` ALONE.  The backward is linear in the pixel gradient, so the tiles of view 0 run a second
 // dL/dalpha chain on dL_dpix2 next to the first -- sharing G, alpha, T and the keep decisions -- and store its two
 // screen-space sums per instance in `part2` (2 floats at the instance's slot).  The default instantiation is unchanged.
-template <bool STATS>
+// FAST: the forward ran with E3DGS_FLAG_FAST_EXP -- its alpha is min(0.99, o v_exp_f32(power log2 e)), which this kernel
+// computes with the same instruction on the same bits: the forward's keep decisions are reproduced by one compare, without
+// the band logic the polynomial exp of the exact mode needs.
+template <bool STATS, bool FAST>
 __device__ __forceinline__ void render_bwd_body(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
@@ -213,13 +216,19 @@ __device__ __forceinline__ void render_bwd_body(
                         // Issued before the mask algebra so that its latency overlaps the compares.
                         float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                         asm volatile("" : "+v"(G));          // keep it here: the compiler would sink it into the branch
-                        const unsigned long long hi = __builtin_amdgcn_fcmpf(power, c.z, 3 /* OGE */);
                         const unsigned long long nonpos = __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE: !(power > 0) */);
-                        unsigned long long keep = live & hi & nonpos;
-                        const unsigned long long near = live & ~hi & nonpos;
-                        if (near != 0ull) {                  // rare (<1 % of the live strips)
-                            const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(power));
-                            keep |= near & __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
+                        unsigned long long keep;
+                        if (FAST) {
+                            const float a_f = fminf(E3_ALPHA_CLAMP, b.y * G);
+                            keep = live & nonpos & __builtin_amdgcn_fcmpf(a_f, E3_ALPHA_SKIP, 11 /* UGE: !(alpha < 1/255) */);
+                        } else {
+                            const unsigned long long hi = __builtin_amdgcn_fcmpf(power, c.z, 3 /* OGE */);
+                            keep = live & hi & nonpos;
+                            const unsigned long long near = live & ~hi & nonpos;
+                            if (near != 0ull) {                  // rare (<1 % of the live strips)
+                                const float af = fminf(E3_ALPHA_CLAMP, b.y * exp_det_noclamp(power));
+                                keep |= near & __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
+                            }
                         }
                         any |= keep;
                         if (__builtin_amdgcn_inverse_ballot_w64(keep)) {
@@ -356,11 +365,18 @@ __device__ __forceinline__ void render_bwd_body(
     trace, ntiles, tiles_per_view, order, gx, W, H, ranges, emit_gid, rec, bg, final_T, n_contrib, perm, strip_mask, dL_dpix, part
 // (two plain kernels around the one body: the profiles, the bench line and the reviews name `render_bwd_kernel`)
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(E3_RENDER_BWD_PARAMS) {
-    render_bwd_body<false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap);
+    render_bwd_body<false, false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap);
+}
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_fast_kernel(E3_RENDER_BWD_PARAMS) {
+    render_bwd_body<false, true>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap);
 }
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_kernel(
     E3_RENDER_BWD_PARAMS, const float* __restrict__ dL_dpix2, float* __restrict__ part2) {
-    render_bwd_body<true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap);
+    render_bwd_body<true, false>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap);
+}
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_fast_kernel(
+    E3_RENDER_BWD_PARAMS, const float* __restrict__ dL_dpix2, float* __restrict__ part2) {
+    render_bwd_body<true, true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap);
 }
 
 // ------------------------------------------------------------------------------------ per-Gaussian backward
@@ -1150,7 +1166,6 @@ int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
 
 // ------------------------------------------------------------------------------------ host driver
 int e3_fail(hipError_t e, const char* what);
-extern int g_small_scene_paths;
 #define KERNEL_OK(name)                                       \
     do {                                                      \
         hipError_t _e = hipGetLastError();                    \
@@ -1195,13 +1210,14 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         // (STATS: the second chain's records sit in the slack between the packed 9-float records and the per-splat sums:
         // the caller provides E3_ACC_STRIDE = 12 floats per instance)
         float* part2 = grad_acc + E3_REC_FLOATS * (size_t)num_rendered;
+        const bool fast = e3_call_opts(flags).fast_exp != 0;
         if (dL_dpix_stats)
-            render_bwd_stats_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+            (fast ? render_bwd_stats_fast_kernel : render_bwd_stats_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
                 background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles,
                 dL_dpix_stats, part2);
         else
-            render_bwd_kernel<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+            (fast ? render_bwd_fast_kernel : render_bwd_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
                 background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles);
     }
@@ -1215,10 +1231,10 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     // element of the forward's scan of the per-wave instance counts
     const uint32_t* count_dev = nullptr;
     if (flags & E3_FLAG_COUNT_DEVICE) {
-        const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
+        const int gshift = e3_bin_group_shift(Q, e3_call_opts(flags).small_paths);
         count_dev = geom.offsets + (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
     }
-    if (num_rendered > 0 && Q <= E3_RUN_REDUCE_WAVE_MAX && g_small_scene_paths)
+    if (num_rendered > 0 && Q <= E3_RUN_REDUCE_WAVE_MAX && e3_call_opts(flags).small_paths)
         run_reduce_wave_kernel<<<dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s>>>((uint32_t)Q, geom.ord0, geom.run,
                                                                                     grad_acc, gsum, bin.touched, geom.nvis,
                                                                                     count_dev, (uint32_t)num_rendered);

@@ -17,33 +17,56 @@ int e3_fail(hipError_t e, const char* what) {
 int g_tile_cull = [] { const char* e = getenv("E3DGS_TILE_CULL"); return (e && e[0] == '0') ? 0 : (e && e[0] == '3') ? 3 : 1; }();
 int g_small_scene_paths = [] { const char* e = getenv("E3DGS_SMALL_SCENE_PATHS"); return (e && e[0] == '0') ? 0 : 1; }();
 
-// ---- event profiler
-bool g_prof_on = false;
-unsigned g_prof_mask = 0;
+// The options of a call: its own flags word when E3_FLAG_OPTIONS is set -- nothing process-global is consulted, so
+// calls with different settings may run concurrently from any number of threads and streams -- and the process-wide
+// defaults above otherwise (environment at load time; the e3dgs_set_* setters are deprecated shims that change them).
+CallOpts e3_call_opts(int flags) {
+    CallOpts o;
+    if (flags & E3_FLAG_OPTIONS) {
+        o.cull = (flags & E3_FLAG_CULL_RECT) ? 0 : ((flags & E3_FLAG_CULL_NO_BOX) ? 3 : 1);
+        o.small_paths = (flags & E3_FLAG_NO_SMALL_PATHS) ? 0 : 1;
+    } else {
+        o.cull = g_tile_cull;
+        o.small_paths = g_small_scene_paths;
+    }
+    o.fast_exp = (flags & E3_FLAG_FAST_EXP) ? 1 : 0;
+    return o;
+}
+
+// ---- event profiler.  State per HOST THREAD (enable / the timed calls / query belong to one thread; the event table is
+// allocated on that thread's first enable): a profiled trainer cannot race with calls another thread makes.
+thread_local bool g_prof_on = false;
+thread_local unsigned g_prof_mask = 0;
 namespace {
 struct ProfPair { hipEvent_t a, b; };
 constexpr int PROF_MAX = 4096;
-ProfPair g_pairs[PS_COUNT][PROF_MAX];
-int g_created[PS_COUNT] = {0}, g_used[PS_COUNT] = {0};
-bool g_open[PS_COUNT] = {false};
+struct ProfState {
+    ProfPair pairs[PS_COUNT][PROF_MAX];
+    int created[PS_COUNT] = {0}, used[PS_COUNT] = {0};
+    bool open[PS_COUNT] = {false};
+};
+thread_local ProfState* g_ps = nullptr;
 const char* g_names[PS_COUNT] = {"preprocess", "sort_depth", "scan_emit", "sort_tile", "tile_ranges", "render_fwd",
                                  "render_bwd", "geom_bwd"};
 }  // namespace
 void prof_begin(int slot, hipStream_t s) {
-    int k = g_used[slot];
+    ProfState* P = g_ps;
+    if (!P) return;
+    int k = P->used[slot];
     if (k >= PROF_MAX) return;
-    if (k >= g_created[slot]) {
-        if (hipEventCreate(&g_pairs[slot][k].a) != hipSuccess || hipEventCreate(&g_pairs[slot][k].b) != hipSuccess) return;
-        g_created[slot] = k + 1;
+    if (k >= P->created[slot]) {
+        if (hipEventCreate(&P->pairs[slot][k].a) != hipSuccess || hipEventCreate(&P->pairs[slot][k].b) != hipSuccess) return;
+        P->created[slot] = k + 1;
     }
-    (void)hipEventRecord(g_pairs[slot][k].a, s);
-    g_open[slot] = true;
+    (void)hipEventRecord(P->pairs[slot][k].a, s);
+    P->open[slot] = true;
 }
 void prof_end(int slot, hipStream_t s) {
-    if (!g_open[slot]) return;
-    (void)hipEventRecord(g_pairs[slot][g_used[slot]].b, s);
-    g_used[slot]++;
-    g_open[slot] = false;
+    ProfState* P = g_ps;
+    if (!P || !P->open[slot]) return;
+    (void)hipEventRecord(P->pairs[slot][P->used[slot]].b, s);
+    P->used[slot]++;
+    P->open[slot] = false;
 }
 
 int e3_mark_visible_impl(int, const float*, const float*, uint8_t*, hipStream_t);
@@ -70,7 +93,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 12; }
+int e3dgs_abi_version(void) { return 13; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -162,7 +185,7 @@ static int forward_sync(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_
     if (e != hipSuccess) return e3_fail(e, "hipStreamSynchronize (instance count)");
     *num_rendered_host = count;
     return e3_forward_finish_impl(binning_alloc, binning_user, vb.n, P, width, height, background, kg.ptr, ki.ptr,
-                                  count, out_color, debug, (hipStream_t)stream);
+                                  count, out_color, debug, flags, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_forward(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_fn binning_alloc,
@@ -203,11 +226,11 @@ int e3dgs_rasterize_forward_begin(e3dgs_alloc_fn geom_alloc, void* geom_user, e3
 
 int e3dgs_rasterize_forward_finish(e3dgs_alloc_fn binning_alloc, void* binning_user, int P, int width, int height,
                                    const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                                   float* out_color, int debug, void* stream) {
+                                   float* out_color, int debug, int flags, void* stream) {
     g_err[0] = 0;
     if (P < 0 || num_rendered < 0 || !geom_buffer || !image_buffer) return e3_fail(hipErrorInvalidValue, "bad arguments");
     return e3_forward_finish_impl(binning_alloc, binning_user, 1, P, width, height, background, geom_buffer,
-                                  image_buffer, num_rendered, out_color, debug, (hipStream_t)stream);
+                                  image_buffer, num_rendered, out_color, debug, flags, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
@@ -273,12 +296,12 @@ int e3dgs_rasterize_forward_multi_begin(e3dgs_alloc_fn geom_alloc, void* geom_us
 
 int e3dgs_rasterize_forward_multi_finish(e3dgs_alloc_fn binning_alloc, void* binning_user, int nviews, int P, int width,
                                          int height, const float* background, char* geom_buffer, char* image_buffer,
-                                         int num_rendered, float* out_color, int debug, void* stream) {
+                                         int num_rendered, float* out_color, int debug, int flags, void* stream) {
     g_err[0] = 0;
     if (nviews < 1 || nviews > E3_MAX_VIEWS || P < 0 || num_rendered < 0 || !geom_buffer || !image_buffer)
         return e3_fail(hipErrorInvalidValue, "bad arguments");
     return e3_forward_finish_impl(binning_alloc, binning_user, nviews, P, width, height, background, geom_buffer,
-                                  image_buffer, num_rendered, out_color, debug, (hipStream_t)stream);
+                                  image_buffer, num_rendered, out_color, debug, flags, (hipStream_t)stream);
 }
 
 int e3dgs_rasterize_forward_multi_finish_colour(e3dgs_alloc_fn binning_alloc, void* binning_user, int nviews, int P,
@@ -303,7 +326,7 @@ int e3dgs_rasterize_forward_multi_finish_colour(e3dgs_alloc_fn binning_alloc, vo
     dc.D = D; dc.M = M; dc.flags = flags; dc.means3D = means3D; dc.shs = shs;
     dc.before = before_colour; dc.user = notify_user;
     return e3_forward_finish_impl(binning_alloc, binning_user, nviews, P, width, height, background, geom_buffer,
-                                  image_buffer, num_rendered, out_color, debug, (hipStream_t)stream, &dc);
+                                  image_buffer, num_rendered, out_color, debug, flags, (hipStream_t)stream, &dc);
 }
 
 // ---- the same multi-view forward with NO host wait: binning buffers sized by the caller before the count is known
@@ -344,7 +367,7 @@ int e3dgs_rasterize_forward_multi_capacity(e3dgs_alloc_fn geom_alloc, void* geom
         dc.before = before_colour; dc.user = notify_user;
     }
     return e3_forward_finish_impl(binning_alloc, binning_user, vb.n, P, width, height, background, kg.ptr, ki.ptr,
-                                  P > 0 ? capacity : 0, out_color, debug, (hipStream_t)stream, defer ? &dc : nullptr,
+                                  P > 0 ? capacity : 0, out_color, debug, flags, (hipStream_t)stream, defer ? &dc : nullptr,
                                   P > 0 ? 1 : 0);
 }
 
@@ -461,6 +484,21 @@ void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t*
     p = nullptr;
     int gx = (width + E3_TILE - 1) / E3_TILE, gy = (height + E3_TILE - 1) / E3_TILE;
     ImageState im = ImageState::from(p, (size_t)width * height, (size_t)gx * gy);
+    out9[6] = (size_t)im.ranges; out9[7] = (size_t)im.final_T; out9[8] = (size_t)im.n_contrib;
+}
+
+void e3dgs_state_offsets_multi(int nviews, int P, int num_rendered, int width, int height, size_t* out9) {
+    char* p = nullptr;
+    const size_t Q = (size_t)(P > 0 ? P : 0) * (size_t)(nviews > 0 ? nviews : 1);
+    GeomState g = GeomState::from(p, Q);
+    out9[0] = (size_t)g.rec; out9[1] = (size_t)g.rec + 16; out9[2] = (size_t)g.rec + 32; out9[3] = (size_t)g.clamped;
+    out9[4] = (size_t)g.rect;
+    p = nullptr;
+    BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
+    out9[5] = (size_t)b.perm;
+    p = nullptr;
+    const int gx = (width + E3_TILE - 1) / E3_TILE, gy = (height + E3_TILE - 1) / E3_TILE;
+    ImageState im = ImageState::from(p, (size_t)width * height * (nviews > 0 ? nviews : 1), (size_t)gx * gy * (nviews > 0 ? nviews : 1));
     out9[6] = (size_t)im.ranges; out9[7] = (size_t)im.final_T; out9[8] = (size_t)im.n_contrib;
 }
 
@@ -592,29 +630,33 @@ int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys
 
 extern unsigned long long* g_trace;
 void e3dgs_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }   /* not in the public header */
+/* deprecated shims: they change the process-wide DEFAULTS that calls without E3DGS_FLAG_OPTIONS fall back to */
 void e3dgs_set_tile_cull(int on) { g_tile_cull = on == 3 ? 3 : (on ? 1 : 0); }
 int e3dgs_get_tile_cull(void) { return g_tile_cull; }
 void e3dgs_set_small_scene_paths(int on) { g_small_scene_paths = on ? 1 : 0; }
 int e3dgs_get_small_scene_paths(void) { return g_small_scene_paths; }
 
 void e3dgs_profile_enable(int slot_mask) {
+    if (slot_mask != 0 && !g_ps) g_ps = new ProfState();
     g_prof_mask = (unsigned)slot_mask;
     g_prof_on = slot_mask != 0;
-    for (int i = 0; i < PS_COUNT; ++i) { g_used[i] = 0; g_open[i] = false; }
+    if (g_ps) for (int i = 0; i < PS_COUNT; ++i) { g_ps->used[i] = 0; g_ps->open[i] = false; }
 }
 int e3dgs_profile_query(int slot, double* total_ms, int* launches) {
     if (slot < 0 || slot >= PS_COUNT) return -1;
     double t = 0.0;
-    for (int k = 0; k < g_used[slot]; ++k) {
-        hipError_t e = hipEventSynchronize(g_pairs[slot][k].b);
+    ProfState* P = g_ps;
+    const int used = P ? P->used[slot] : 0;
+    for (int k = 0; k < used; ++k) {
+        hipError_t e = hipEventSynchronize(P->pairs[slot][k].b);
         if (e != hipSuccess) return e3_fail(e, "profile event sync");
         float ms = 0.0f;
-        e = hipEventElapsedTime(&ms, g_pairs[slot][k].a, g_pairs[slot][k].b);
+        e = hipEventElapsedTime(&ms, P->pairs[slot][k].a, P->pairs[slot][k].b);
         if (e != hipSuccess) return e3_fail(e, "profile elapsed");
         t += ms;
     }
     *total_ms = t;
-    *launches = g_used[slot];
+    *launches = used;
     return 0;
 }
 const char* e3dgs_profile_slot_name(int slot) { return (slot >= 0 && slot < PS_COUNT) ? g_names[slot] : ""; }

@@ -28,6 +28,13 @@
 #define E3_FLAG_COUNT_MAPPED 64     // begin: num_rendered_host is pinned + device-mapped; the GPU stores the count there
 #define E3_FLAG_DEFER_COLOR 128     // multi begin: no SH evaluation in preprocess; finish runs colour_kernel
 #define E3_FLAG_COUNT_DEVICE 256    // backward: num_rendered is the CAPACITY of a forward_multi_capacity call
+// per-call options (include/e3dgs_hip.h: E3DGS_FLAG_OPTIONS ...): with E3_FLAG_OPTIONS the bits below describe the call;
+// without it the process-wide defaults apply (environment at load time / the deprecated e3dgs_set_* setters)
+#define E3_FLAG_OPTIONS 0x0800
+#define E3_FLAG_CULL_RECT 0x1000          // reference rectangle binning (no exact tile culling)
+#define E3_FLAG_CULL_NO_BOX 0x2000        // exact culling without the tight candidate box
+#define E3_FLAG_NO_SMALL_PATHS 0x4000     // large-scene work decomposition whatever the splat count
+#define E3_FLAG_FAST_EXP 0x8000           // tolerance mode: hardware exp2 in the compositing forward (and its backward twin)
 #define E3_MAX_VIEWS 4       // views per e3dgs_rasterize_backward_geom_multi call
 #define E3_ACC_STRIDE 12      // floats the CALLER provides per (tile, Gaussian) instance and per splat sum in grad_acc
 #define E3_REC_FLOATS 9       // floats of a per-instance gradient record as stored (packed, 36 B; the rest is slack)
@@ -383,6 +390,14 @@ static inline ViewSet make_view_set(const ViewBatch& b, int W, int H, float scal
     return vs;
 }
 
+// the options of one call, resolved from its flags word (capi.hip holds the process-wide defaults)
+struct CallOpts {
+    int cull;          // 0: reference rectangle binning, 1: exact culling, 3: exact culling without the tight box
+    int small_paths;   // work decomposition adapts to few splats
+    int fast_exp;      // hardware exp2 in compositing (tolerance mode)
+};
+CallOpts e3_call_opts(int flags);
+
 // host drivers (forward.hip / backward.hip), called by the C ABI wrappers in capi.hip
 typedef char* (*e3_alloc_fn)(void*, size_t);
 int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn img_alloc, void* img_user,
@@ -400,7 +415,7 @@ struct DeferredColour {          // inputs of colour_kernel (E3_FLAG_DEFER_COLOR
 };
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc = nullptr,
+                           float* out_color, int debug, int flags, hipStream_t s, const DeferredColour* dc = nullptr,
                            int count_on_device = 0);
 int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_rendered, const float* background, int W,
                      int H, const float* means3D, const float* shs, const float* colors, const float* opacities,
@@ -453,8 +468,8 @@ static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 // ---------------------------------------------------------------- optional event profiler (capi.hip)
 enum ProfSlot { PS_PREPROCESS = 0, PS_SORT_DEPTH, PS_SCAN_EMIT, PS_SORT_TILE, PS_RANGES, PS_RENDER_FWD, PS_RENDER_BWD,
                 PS_GEOM_BWD, PS_COUNT };
-extern bool g_prof_on;
-extern unsigned g_prof_mask;
+extern thread_local bool g_prof_on;        // (per host thread: a profiled trainer does not race with another thread's calls)
+extern thread_local unsigned g_prof_mask;
 void prof_begin(int slot, hipStream_t s);
 void prof_end(int slot, hipStream_t s);
 struct ProfScope {

@@ -882,7 +882,12 @@ __device__ __forceinline__ void strip_pretest(const float4 ra, const float4 rb, 
 #ifndef E3_FWD_WAVES
 #define E3_FWD_WAVES 7      // 72 VGPRs: the lane-parallel strip pre-test at the top of a round must not cost the loop a wave per SIMD
 #endif
-__global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_kernel(
+// FAST (E3DGS_FLAG_FAST_EXP, tolerance mode): G = v_exp_f32(power log2 e) -- 2 instead of 10 VALU instructions on the
+// most executed path -- instead of the bit-reproducible polynomial.  Everything in front of compositing (radii, lists,
+// ranges) is untouched; alpha moves by <= 1 ulp, which can flip the alpha >= 1/255 / T < 1e-4 decisions at a handful of
+// pixels per frame (tests/test_hip_parity.py::test_fast_exp_mode counts them).
+template <bool FAST>
+__device__ __forceinline__ void render_fwd_body(
     unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
     int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ perm,
     const uint32_t* __restrict__ emit_gid,
@@ -989,7 +994,7 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
                 const float dy = a.y - pfy[k];                                                                              \
                 const float q = FMA(b.x * dy, dy, qx);                                                                      \
                 const float power = FMA(-0.5f, q, -(cydx * dy));                                                            \
-                const float G = exp_det_noclamp(power);                                                                     \
+                const float G = FAST ? __builtin_amdgcn_exp2f(power * 1.4426950408889634f) : exp_det_noclamp(power);        \
                 const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);                                                         \
                 /* lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255) */                             \
                 const unsigned long long valid = alive[k] & __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE */) &             \
@@ -1076,6 +1081,24 @@ __global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_
     }
 }
 
+#define E3_RENDER_FWD_PARAMS                                                                                             \
+    unsigned long long *__restrict__ trace, int ntiles, int tiles_per_view, const uint32_t *__restrict__ order, int gx,  \
+        int W, int H, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ perm,                               \
+        const uint32_t *__restrict__ emit_gid, const float4 *__restrict__ rec, const float *__restrict__ bg,            \
+        float *__restrict__ out, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,                          \
+        uint32_t *__restrict__ tile_work, uint8_t *__restrict__ strip_mask, uint8_t *__restrict__ touched,              \
+        uint32_t *__restrict__ lpt_cnt, uint32_t *__restrict__ lpt_list, uint32_t lpt_cap
+#define E3_RENDER_FWD_ARGS                                                                                               \
+    trace, ntiles, tiles_per_view, order, gx, W, H, ranges, perm, emit_gid, rec, bg, out, final_T, n_contrib, tile_work, \
+        strip_mask, touched, lpt_cnt, lpt_list, lpt_cap
+// (plain kernels around the one body: the profiles, the bench line and the reviews name `render_fwd_kernel`)
+__global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_kernel(E3_RENDER_FWD_PARAMS) {
+    render_fwd_body<false>(E3_RENDER_FWD_ARGS);
+}
+__global__ __launch_bounds__(RENDER_WAVES * WAVE, E3_FWD_WAVES) void render_fwd_fast_kernel(E3_RENDER_FWD_PARAMS) {
+    render_fwd_body<true>(E3_RENDER_FWD_ARGS);
+}
+
 // background fill for P == 0 or empty scenes is handled by the same kernel (ranges are zero).
 
 // ------------------------------------------------------------------------------------ mark_visible
@@ -1091,8 +1114,6 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* _
 
 // ------------------------------------------------------------------------------------ host driver
 extern thread_local char g_err[512];
-extern int g_tile_cull;          // 0: reference rectangle binning, 1: exact culling, 3: exact culling without the tight box
-extern int g_small_scene_paths;
 int e3_fail(hipError_t e, const char* what);
 #define HIP_OK(expr)                                          \
     do {                                                      \
@@ -1168,14 +1189,15 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0 || keys_sorted != geom.key0)
             return e3_fail(hipErrorUnknown, "internal: depth order not in ord0 / key0");
-        const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
+        const CallOpts opt = e3_call_opts(flags);
+        const int gshift = e3_bin_group_shift(Q, opt.small_paths);
         const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         {
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<false><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nv, ntiles, order, geom.nvis,
                                                                      geom.rect, vs.v[0].gx <= 255 && vs.v[0].gy <= 255,
-                                                                     geom.rec, vs.v[0].gx, g_tile_cull, nullptr, geom.tiles,
+                                                                     geom.rec, vs.v[0].gx, opt.cull, nullptr, geom.tiles,
                                                                      nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0u,
                                                                      bin_handoff() ? geom.binrec : nullptr);
         // inclusive scan of the per-wave counts; offsets[w] = end of wave w, so start = offsets[w-1]
@@ -1198,7 +1220,9 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
 // word as usual, repeats the call with larger buffers.
 int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, int P, int W, int H,
                            const float* background, char* geom_buffer, char* image_buffer, int num_rendered,
-                           float* out_color, int debug, hipStream_t s, const DeferredColour* dc, int count_on_device) {
+                           float* out_color, int debug, int flags, hipStream_t s, const DeferredColour* dc,
+                           int count_on_device) {
+    const CallOpts opt = e3_call_opts(flags);      // (the caller passes the option bits it gave to `begin`)
     const int gx = (W + E3_TILE - 1) / E3_TILE, gy = (H + E3_TILE - 1) / E3_TILE;
     const int tiles_per_view = gx * gy;
     const int ntiles = tiles_per_view * nviews;
@@ -1220,7 +1244,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         // choose the emit target so that the final sorted values (slot indices) land in bin.perm
         uint32_t *k0 = bin.keys, *k1 = bin.keys_alt, *v0 = bin.perm, *v1 = bin.vals_alt;
         if (passes & 1) { uint32_t* t = v0; v0 = v1; v1 = t; }
-        const int gshift = e3_bin_group_shift(Q, g_small_scene_paths);
+        const int gshift = e3_bin_group_shift(Q, opt.small_paths);
         const unsigned nwaves = (unsigned)((Q + ((size_t)1 << gshift) - 1) >> gshift);
         const unsigned bb = (nwaves + BIN_WAVES - 1) / BIN_WAVES;
         // the instance count on the device: the last element of the inclusive scan of the per-wave counts
@@ -1229,7 +1253,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         ProfScope ps(PS_SCAN_EMIT, s);
         bin_kernel<true><<<dim3(bb), dim3(BIN_WAVES * WAVE), 0, s>>>((int)Q, gshift, nviews, tiles_per_view, geom.ord0,
                                                                     geom.nvis, geom.rect, gx <= 255 && gy <= 255, geom.rec, gx,
-                                                                    g_tile_cull, geom.offsets, nullptr, k0, keys16,
+                                                                    opt.cull, geom.offsets, nullptr, k0, keys16,
                                                                     bin.emit_gid, geom.run, bin.touched, count_dev, I,
                                                                     bin_handoff() ? geom.binrec : nullptr);
         }
@@ -1276,7 +1300,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
         KERNEL_OK("colour_kernel");
     }
     ProfScope ps_render(PS_RENDER_FWD, s);
-    render_fwd_kernel<<<dim3((nslots + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
+    (opt.fast_exp ? render_fwd_fast_kernel : render_fwd_kernel)<<<dim3((nslots + RENDER_WAVES - 1) / RENDER_WAVES), dim3(RENDER_WAVES * WAVE), 0, s>>>(
         g_trace, nslots, tiles_per_view, use_lpt ? nullptr : img.order, gx, W, H, img.ranges, bin.perm, bin.emit_gid, geom.rec,
         background, out_color, img.final_T, img.n_contrib, img.work, bin.strip_mask, bin.touched, img.lpt_cnt, img.lpt_list,
         (uint32_t)ntiles);

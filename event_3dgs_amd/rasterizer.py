@@ -263,7 +263,7 @@ def forward_finish(pending):
     with torch.cuda.device(p.device):
         rc = L.e3dgs_rasterize_forward_finish(binning.cb, None, p.P, p.W, p.H, _lib.ptr(p.consts[0]), _lib.ptr(p.geom),
                                               _lib.ptr(p.image), I, _lib.ptr(out_color), int(bool(p.rs.debug)),
-                                              _lib.current_stream())
+                                              p.flags & _lib.OPTION_MASK, _lib.current_stream())
     _lib.check(rc, "e3dgs_rasterize_forward_finish")
     return dict(color=out_color, radii=p.radii, num_rendered=I, M=p.M, settings=p.rs, flags=p.flags, inputs=p.inputs,
                 opacities=p.opacities, consts=p.consts, geom=p.geom, binning=binning.tensor, image=p.image)
@@ -292,6 +292,22 @@ def state_views(raw, P, W, H):
         ranges=view(im, offs[6], torch.int32, 2 * gx * gy, (gx * gy, 2)),
         final_T=view(im, offs[7], torch.float32, W * H, (H, W)),
         n_contrib=view(im, offs[8], torch.int32, W * H, (H, W)))
+
+
+def state_views_multi(raw, P, W, H):
+    """Typed views into the image scratch of a forward_multi() result: ranges (n*tiles, 2), final_T / n_contrib (n, H, W)."""
+    import ctypes as C
+    n = len(raw["settings_list"])
+    offs = (C.c_size_t * 9)()
+    _lib.lib().e3dgs_state_offsets_multi(n, P, int(raw["num_rendered"]), W, H, offs)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    im = raw["image"]
+    def view(off, dtype, count, shape):
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        return im[off:off + nbytes].view(dtype).reshape(shape)
+    return dict(ranges=view(offs[6], torch.int32, 2 * gx * gy * n, (gx * gy * n, 2)),
+                final_T=view(offs[7], torch.float32, W * H * n, (n, H, W)),
+                n_contrib=view(offs[8], torch.int32, W * H * n, (n, H, W)))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -538,11 +554,12 @@ def prepare_multi_finish(pending):
         p._colour_keep = (campos, notify)
         fn = L.e3dgs_rasterize_forward_multi_finish_colour
         tail = (int(p.rs.sh_degree), p.M, _lib.ptr(means3D_c), _lib.ptr(sh_c), campos,
-                p.flags & _lib.FLAG_SH_PLANAR, notify, None, stream)
+                p.flags & (_lib.FLAG_SH_PLANAR | _lib.OPTION_MASK), notify, None, stream)
         p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b, *tail))
     else:
         fn = L.e3dgs_rasterize_forward_multi_finish
-        p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b, stream))
+        opts = p.flags & _lib.OPTION_MASK
+        p.prepared = (out_color, binning, lambda count: fn(*fixed_a, count, *fixed_b, opts, stream))
     return p.prepared
 
 

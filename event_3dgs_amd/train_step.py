@@ -63,8 +63,19 @@ class EventTrainer:
     def __init__(self, params, device, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
-                 track_densification_stats=False, overlap_features=None, factorize_sh=None, dp_schedule=None):
+                 track_densification_stats=False, overlap_features=None, factorize_sh=None, dp_schedule=None,
+                 tile_cull=None, small_scene_paths=None, fast_exp=None):
         self.device = torch.device(device)
+        # Rasteriser options of THIS trainer, carried in the flags word of every call it makes (E3DGS_FLAG_OPTIONS: the
+        # library reads no process-wide setting then, so trainers with different options can share a process, also on
+        # concurrent streams).  tile_cull / small_scene_paths: None keeps the process defaults (_lib.option_flags).
+        # fast_exp (default: environment E3DGS_FAST_EXP=1, else off): TOLERANCE MODE of the compositing kernels -- hardware
+        # exp2 instead of the bit-reproducible polynomial; integer binning unchanged, image <= 1e-4 apart from a handful of
+        # threshold-flip pixels, gradients <= 1e-3 (tests/test_hip_parity.py::test_fast_exp_mode...).
+        if fast_exp is None:
+            fast_exp = os.environ.get("E3DGS_FAST_EXP", "0") == "1"
+        self.fast_exp = bool(fast_exp)
+        self.FWD_FLAGS = _lib.FLAG_PREACT | _lib.FLAG_SH_PLANAR | _lib.option_flags(tile_cull, small_scene_paths, self.fast_exp)
         self.c_lr = c_lr
         self.xyz_lr = get_expon_lr_func(position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale,
                                         lr_delay_mult=position_lr_delay_mult, max_steps=position_lr_max_steps)

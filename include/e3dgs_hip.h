@@ -69,6 +69,22 @@ const char* e3dgs_last_error(void);
                                        another stream while this iteration projects, sorts and bins. */
 #define E3DGS_FLAG_COUNT_DEVICE 256   /* backward_multi: the forward was e3dgs_rasterize_forward_multi_capacity and
                                         num_rendered is its `capacity` (the count itself sits in the geometry scratch) */
+/* ---- per-call OPTIONS (ABI 13).  The library keeps no mutable process-wide state that a call reads when
+ * E3DGS_FLAG_OPTIONS is set: calls with different settings may run concurrently from any number of host threads and
+ * streams.  Every call of one forward / backward (begin, finish, backward) must be given the same option bits.
+ * Without E3DGS_FLAG_OPTIONS the process-wide defaults apply (environment at load time, the deprecated setters
+ * e3dgs_set_tile_cull / e3dgs_set_small_scene_paths). */
+#define E3DGS_FLAG_OPTIONS 0x0800         /* the option bits below describe this call */
+#define E3DGS_FLAG_CULL_RECT 0x1000       /* reference rectangle binning: no exact tile culling (see e3dgs_set_tile_cull) */
+#define E3DGS_FLAG_CULL_NO_BOX 0x2000     /* exact culling without the tight candidate box (test switch) */
+#define E3DGS_FLAG_NO_SMALL_PATHS 0x4000  /* large-scene work decomposition whatever the splat count (see
+                                             e3dgs_set_small_scene_paths) */
+#define E3DGS_FLAG_FAST_EXP 0x8000        /* TOLERANCE MODE (default off, independent of E3DGS_FLAG_OPTIONS): the compositing
+                                             forward evaluates exp with the hardware v_exp_f32 (1 ulp) instead of the
+                                             bit-reproducible polynomial -- integer outputs (radii, lists, ranges) are
+                                             unchanged, the image agrees to <= 1e-4 except at the handful of pixels where
+                                             an alpha >= 1/255 or T < 1e-4 decision flips (<= 1/255 each), gradients to
+                                             1e-3.  Give the same bit to the backward. */
 #define E3DGS_FLAG_BWD_ONLY_RENDER 8   /* backward: only the compositing backward (pixels -> grad_acc) */
 #define E3DGS_FLAG_BWD_ONLY_GEOM 16    /* backward: only the per-Gaussian backward (grad_acc -> parameter gradients).
                                           Together these let a caller overlap the compositing backward of several
@@ -135,7 +151,9 @@ int e3dgs_rasterize_forward_begin(
     int* radii, int debug, int flags, int* num_rendered_host, void* stream);
 int e3dgs_rasterize_forward_finish(
     e3dgs_alloc_fn binning_alloc, void* binning_user, int P, int width, int height, const float* background,
-    char* geom_buffer, char* image_buffer, int num_rendered, float* out_color, int debug, void* stream);
+    char* geom_buffer, char* image_buffer, int num_rendered, float* out_color, int debug,
+    int flags,                        /* the option bits given to `begin` (E3DGS_FLAG_OPTIONS ..., E3DGS_FLAG_FAST_EXP) */
+    void* stream);
 
 /*
  * Backward of the above.  Replaces:
@@ -232,7 +250,9 @@ int e3dgs_rasterize_forward_multi_finish(
     e3dgs_alloc_fn binning_alloc, void* binning_user,
     int nviews, int P, int width, int height, const float* background,
     char* geom_buffer, char* image_buffer, int num_rendered,
-    float* out_color, int debug, void* stream);
+    float* out_color, int debug,
+    int flags,                        /* the option bits given to `begin` */
+    void* stream);
 
 /*
  * The multi-view forward WITHOUT a host wait (a training loop: train.py:144-161 renders the same scene every iteration,
@@ -255,7 +275,7 @@ int e3dgs_rasterize_forward_multi_capacity(
     const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy, float* out_color, int* radii, int debug,
     int flags, int capacity, int* num_rendered_host, e3dgs_notify_fn before_colour, void* notify_user, void* stream);
 
-/* finish() for a begin() issued with E3DGS_FLAG_DEFER_COLOR.  flags: E3DGS_FLAG_SH_PLANAR as given to begin().
+/* finish() for a begin() issued with E3DGS_FLAG_DEFER_COLOR.  flags: E3DGS_FLAG_SH_PLANAR and the option bits as given to begin().
  * before_colour (optional) is called on the host immediately before the colour kernel is enqueued: make `stream`
  * wait there for whatever still writes `shs`. */
 int e3dgs_rasterize_forward_multi_finish_colour(
@@ -343,6 +363,10 @@ int e3dgs_sh_adam_from_colour(int P, int nranks, int views_per_rank, int D, int 
                               int step, int flags, void* stream);
 
 /*
+ * DEPRECATED setters: they change the process-wide DEFAULT that calls without E3DGS_FLAG_OPTIONS fall back to (not
+ * synchronised: set them before any call is in flight).  New code passes E3DGS_FLAG_OPTIONS | E3DGS_FLAG_CULL_RECT /
+ * E3DGS_FLAG_NO_SMALL_PATHS per call.
+ *
  * Exact tile culling (default ON; environment E3DGS_TILE_CULL=0 turns it off at load time).
  * The reference op bins every Gaussian into all tiles of its 3-sigma bounding rectangle.  With
  * culling ON, (tile, Gaussian) instances that provably reach no pixel of the tile with
@@ -376,6 +400,9 @@ int e3dgs_get_small_scene_paths(void);
  *   out[6..8]  image:   ranges (uint2 per tile), final_T (float per pixel), n_contrib (u32 per pixel)
  */
 void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9);
+/* the same for a call with nviews views (P Gaussians each): geometry members are indexed by splat q = i * nviews + v,
+ * out[6] -> ranges of the nviews * tiles tiles, out[7] / out[8] -> final_T / n_contrib as (nviews, H, W) planes */
+void e3dgs_state_offsets_multi(int nviews, int P, int num_rendered, int width, int height, size_t* out9);
 size_t e3dgs_state_offset_emit_gid(int num_rendered);
 
 /*
@@ -550,7 +577,8 @@ int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys
  *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set
  * (0 = off, 0xFF = all; every timed slot costs two event packets per launch group, so a benchmark times only
  * the kernel it reports inside its timed region); query() synchronises the recorded events and returns the
- * accumulated milliseconds and the number of launches.
+ * accumulated milliseconds and the number of launches.  The profiler's state belongs to the CALLING HOST THREAD: enable,
+ * the calls to be timed and query are made from one thread; calls of other threads are never timed and never race.
  */
 void e3dgs_profile_enable(int slot_mask);
 int e3dgs_profile_query(int slot, double* total_ms, int* launches);
