@@ -73,6 +73,7 @@ __device__ __forceinline__ void render_bwd_body(
     const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[unit] : lpt_lookup(lpt_cnt, lpt_list, lpt_cap, (uint32_t)unit, lane));
     if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
+    const unsigned long long c_start = trace ? __builtin_readcyclecounter() : 0ull;     // s_memtime: shader cycles
     const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
     const int tx = ltile % gx, ty = ltile / gx;
     const int px = tx * E3_TILE + (lane & 15);
@@ -345,11 +346,13 @@ __device__ __forceinline__ void render_bwd_body(
         if (STATS && sv) { part2[2 * (size_t)perm[e]] = 0.0f; part2[2 * (size_t)perm[e] + 1] = 0.0f; }
     }
     if (trace && lane == 0) {
-        trace[4 * (size_t)tile + 0] = t_start;
-        trace[4 * (size_t)tile + 1] = wall_clock64();
-        trace[4 * (size_t)tile + 2] = ((unsigned long long)(range.y - range.x) << 32) | (unsigned)n;
-        trace[4 * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
+        trace[E3_TRACE_WORDS * (size_t)tile + 0] = t_start;
+        trace[E3_TRACE_WORDS * (size_t)tile + 1] = wall_clock64();
+        trace[E3_TRACE_WORDS * (size_t)tile + 2] = ((unsigned long long)(range.y - range.x) << 32) | (unsigned)n;
+        trace[E3_TRACE_WORDS * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
                                       (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        trace[E3_TRACE_WORDS * (size_t)tile + 4] = c_start;                    // effective clock of the kernel = cycles / wall time
+        trace[E3_TRACE_WORDS * (size_t)tile + 5] = __builtin_readcyclecounter();
         (void)t_loop;
     }
 }

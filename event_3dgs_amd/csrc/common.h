@@ -39,6 +39,8 @@
 #define E3_ACC_STRIDE 12      // floats the CALLER provides per (tile, Gaussian) instance and per splat sum in grad_acc
 #define E3_REC_FLOATS 9       // floats of a per-instance gradient record as stored (packed, 36 B; the rest is slack)
 
+#define E3_TRACE_WORDS 6       // debug trace (e3dgs_debug_set_trace): per tile {wall start, wall end (100 MHz), entries, hw id,
+                              // shader-cycle start, shader-cycle end (s_memtime)}
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define WAVE 64
 

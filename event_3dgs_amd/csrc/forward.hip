@@ -909,6 +909,7 @@ __device__ __forceinline__ void render_fwd_body(
     const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[unit] : lpt_lookup(lpt_cnt, lpt_list, lpt_cap, (uint32_t)unit, lane));
     if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
+    const unsigned long long c_start = trace ? __builtin_readcyclecounter() : 0ull;     // s_memtime: shader cycles
     int processed = 0;
     const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
     const int tx = ltile % gx, ty = ltile / gx;
@@ -1057,11 +1058,13 @@ __device__ __forceinline__ void render_fwd_body(
         }
     }
     if (trace && lane == 0) {
-        trace[4 * (size_t)tile + 0] = t_start;
-        trace[4 * (size_t)tile + 1] = wall_clock64();
-        trace[4 * (size_t)tile + 2] = ((unsigned long long)n << 32) | (unsigned)processed;
-        trace[4 * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
+        trace[E3_TRACE_WORDS * (size_t)tile + 0] = t_start;
+        trace[E3_TRACE_WORDS * (size_t)tile + 1] = wall_clock64();
+        trace[E3_TRACE_WORDS * (size_t)tile + 2] = ((unsigned long long)n << 32) | (unsigned)processed;
+        trace[E3_TRACE_WORDS * (size_t)tile + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
                                       (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        trace[E3_TRACE_WORDS * (size_t)tile + 4] = c_start;                    // effective clock of the kernel = cycles / wall time
+        trace[E3_TRACE_WORDS * (size_t)tile + 5] = __builtin_readcyclecounter();
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;

@@ -26,9 +26,9 @@ def run(trace=None):
     L.e3dgs_debug_set_trace(None)
 L.e3dgs_debug_set_trace.argtypes = [C.c_void_p]
 for _ in range(3): run()
-buf = torch.zeros(T * 4, dtype=torch.int64, device=dev)
+buf = torch.zeros(T * 6, dtype=torch.int64, device=dev)
 run(buf.data_ptr())
-t = buf.cpu().numpy().reshape(T, 4)
+t = buf.cpu().numpy().reshape(T, 6)
 dur = t[:, 1] - t[:, 0]
 n_list, n = t[:, 2] >> 32, t[:, 2] & 0xFFFFFFFF
 xcc, hw = (t[:, 3] >> 32) & 0xF, t[:, 3] & 0xFFFFFFFF

@@ -15,12 +15,12 @@ rs = rasterizer.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math
 T = ((W + 15) // 16) * ((H + 15) // 16)
 run = lambda: rasterizer.forward_raw(act["means3D"], act["shs"], None, act["opacities"], act["scales"], act["rotations"], None, rs)
 for _ in range(3): run()
-buf = torch.zeros(T * 4, dtype=torch.int64, device=dev)
+buf = torch.zeros(T * 6, dtype=torch.int64, device=dev)
 L.e3dgs_debug_set_trace.argtypes = [C.c_void_p]
 L.e3dgs_debug_set_trace(buf.data_ptr())
 run(); torch.cuda.synchronize()
 L.e3dgs_debug_set_trace(None)
-t = buf.cpu().numpy().reshape(T, 4)
+t = buf.cpu().numpy().reshape(T, 6)
 start, end = t[:, 0], t[:, 1]
 n, proc = t[:, 2] >> 32, t[:, 2] & 0xFFFFFFFF
 xcc, hw = (t[:, 3] >> 32) & 0xF, t[:, 3] & 0xFFFFFFFF

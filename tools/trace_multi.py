@@ -21,7 +21,7 @@ names = dict(means3D=v["xyz"], sh=v["features"], opacities=v["opacity"], scales=
 dpix = torch.randn(3, 3, H, W, device=dev)
 
 def profile(which):
-    buf = torch.zeros(T * 4, dtype=torch.int64, device=dev)
+    buf = torch.zeros(T * 6, dtype=torch.int64, device=dev)
     for rep in range(3):
         arm_f = buf.data_ptr() if (rep == 2 and which == "fwd") else None
         L.e3dgs_debug_set_trace(arm_f)
@@ -33,7 +33,7 @@ def profile(which):
         rasterizer.backward_multi(raw, dpix, out)
         torch.cuda.synchronize()
         L.e3dgs_debug_set_trace(None)
-    t = buf.cpu().numpy().reshape(T, 4)
+    t = buf.cpu().numpy().reshape(T, 6)
     t = t[t[:, 1] > 0]
     T0, span = t[:, 0].min(), t[:, 1].max() - t[:, 0].min()
     edges = np.linspace(0, span, 21)

@@ -1,79 +1,174 @@
-// Micro-benchmark: issue cost (cycles per wave64 instruction per SIMD) of the VALU ops the compositing kernels use.
+// valu_rate.hip -- issue cost of single instructions on MI355X (gfx950), measured so that the numbers can be used as a
+// roofline for the compositing kernels (bench.py roofline.issue).
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/valu_rate tools/ubench/valu_rate.hip && tools/ubench/valu_rate
+//
+// Method (each point answers one objection to the round-3 version of this file):
+//   * every timed launch runs >= 20 ms, after a >= 50 ms warm-up of the same kernel (DVFS settles within a few ms; a 0.3 ms
+//     launch straight after a short warm-up measured the ramp, not the rate);
+//   * the EFFECTIVE CLOCK of every run is printed: one wave per workgroup reads s_memtime (shader cycles) at its first and
+//     last instruction, and the delta is divided by the launch's wall time from HIP events -- so a row reads both as ns
+//     and as cycles per wave-instruction per SIMD;
+//   * the instruction under test is emitted with inline asm (the mnemonic in the table IS the instruction; the loop body
+//     is NI copies on NI independent registers, 8 dependent steps apart); tools/ubench/check_isa.sh greps the device
+//     assembly of this file for every mnemonic of the table;
+//   * 8 waves per SIMD (2048 threads per CU on all 256 CUs): the rate is the chip's, not a single wave's latency.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
-#define N_ITERS 4096
-#define CHAINS 8
-#define OPS(NAME, BODY)                                                                       \
-    __global__ void k_##NAME(float* out, float a, float b, int n) {                            \
-        float x[CHAINS];                                                                     \
-        int ix[CHAINS];                                                                       \
-        for (int i = 0; i < CHAINS; ++i) { x[i] = a + i + threadIdx.x; ix[i] = (int)x[i]; }  \
-        for (int it = 0; it < n; ++it) {                                                     \
-            _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) { BODY; }                      \
-        }                                                                                     \
-        float s = 0; for (int i = 0; i < CHAINS; ++i) s += x[i] + ix[i];                      \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                        \
-    }
-OPS(fma, x[i] = __builtin_fmaf(x[i], a, b))
-OPS(mul, x[i] = x[i] * a)
-OPS(add, x[i] = x[i] + a)
-OPS(minf, x[i] = fminf(x[i], a))
-OPS(cndmask, x[i] = (x[i] > b) ? a : x[i] + 1.0f)   // cmp + add + cndmask (3 ops)
-OPS(ldexp, x[i] = __builtin_ldexpf(x[i], ix[i] & 1))   // and + ldexp
-OPS(rndne, x[i] = __builtin_rintf(x[i]) + a)           // rndne + add
-OPS(cvt, ix[i] = (int)(x[i]); x[i] = x[i] + (float)ix[i])   // cvt_i32, cvt_f32, add
-OPS(rcp, x[i] = __builtin_amdgcn_rcpf(x[i]) + a)       // rcp + add
-OPS(exp2, x[i] = __builtin_amdgcn_exp2f(x[i]) * a)     // exp + mul
-OPS(dpp, x[i] = x[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[i]), 0xB1, 0xf, 0xf, false)))
-OPS(cmp_sel, x[i] = (x[i] >= a) ? x[i] : b)           // cmp + cndmask
-OPS(sub, x[i] = a - x[i])
-OPS(swz, x[i] = x[i] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x[i]), 0x041F)))
-OPS(bperm, x[i] = x[i] + __int_as_float(__builtin_amdgcn_ds_bpermute((threadIdx.x ^ 16) << 2, __float_as_int(x[i]))))
-OPS(dpp_ror, x[i] = x[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[i]), 0x124, 0xf, 0xf, false)))
-OPS(dpp_mov, x[i] = a + __int_as_float(__builtin_amdgcn_update_dpp(0, ix[i], 0xB1, 0xf, 0xf, false)); ix[i] += 1)
-OPS(sel3, x[i] = (ix[i] & 1) ? x[i] * a : b)
+#include <string>
+#include <vector>
 
-// packed fp32: one v_pk_* instruction carries two independent fp32 operations per lane
-typedef float f2 __attribute__((ext_vector_type(2)));
-#define PKOPS(NAME, BODY)                                                                     \
-    __global__ void k_##NAME(float* out, float a, float b, int n) {                            \
-        f2 x[CHAINS];                                                                        \
-        const f2 av = {a, a + 0.25f}, bv = {b, b - 0.125f};                                   \
-        for (int i = 0; i < CHAINS; ++i) { x[i].x = a + i + threadIdx.x; x[i].y = b + i - threadIdx.x; } \
-        for (int it = 0; it < n; ++it) {                                                     \
-            _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) { BODY; }                      \
-        }                                                                                     \
-        float s = 0; for (int i = 0; i < CHAINS; ++i) s += x[i].x + x[i].y;                   \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                        \
-    }
-PKOPS(pk_fma, x[i] = __builtin_elementwise_fma(x[i], av, bv))
-PKOPS(pk_mul, x[i] = x[i] * av)
-PKOPS(pk_add, x[i] = x[i] + av)
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <typename K>
-void run(const char* name, K kern, int ops_per_body) {
-    float* out; hipMalloc(&out, 256 * 2048 * 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    int blocks = 256 * 8;   // 8 blocks of 256 per CU -> 8 waves per SIMD
-    kern<<<blocks, 256>>>(out, 1.0001f, 0.5f, 16);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
-    kern<<<blocks, 256>>>(out, 1.0001f, 0.5f, N_ITERS);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double wave_instr = (double)blocks * 4 * N_ITERS * CHAINS * ops_per_body;     // wave-instructions
-    double per_simd = wave_instr / 1024.0;
-    printf("%-8s %7.3f ms  -> %.2f ns per wave-instr per SIMD (x clock GHz = cycles; @2.4: %.2f cyc)\n", name, ms,
-           ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
-    hipFree(out);
-}
-int main() {
-    run("fma", k_fma, 1); run("mul", k_mul, 1); run("add", k_add, 1); run("sub", k_sub, 1); run("min", k_minf, 1);
-    run("cmp+add+sel", k_cndmask, 3); run("cmp+sel", k_cmp_sel, 2); run("and+ldexp", k_ldexp, 2);
-    run("rndne+add", k_rndne, 2); run("cvt,cvt,add", k_cvt, 3); run("rcp+add", k_rcp, 2); run("exp2+mul", k_exp2, 2);
-    run("dpp+add", k_dpp, 1); run("dpp_ror+add", k_dpp_ror, 1); run("swz+add", k_swz, 1); run("bperm+add", k_bperm, 1);
-    run("dppmov,add,iadd", k_dpp_mov, 3); run("and,mul,sel", k_sel3, 3);
-    run("pk_fma", k_pk_fma, 1); run("pk_mul", k_pk_mul, 1); run("pk_add", k_pk_add, 1);
+constexpr int NI = 8;          // independent chains per thread
+constexpr int UNROLL = 16;     // copies of the NI-instruction group per loop trip
+
+struct Stamp { unsigned long long c0, c1; };
+
+// One kernel per instruction: BODY(i) is the asm for chain i.
+#define KERNEL(name, DECL, BODY, SINK)                                                                  \
+    __global__ __launch_bounds__(256) void name(int trips, float seed, float* out, Stamp* st) {        \
+        DECL                                                                                            \
+        const unsigned long long c0 = __builtin_readcyclecounter();                                    \
+        for (int t = 0; t < trips; ++t) {                                                               \
+            _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                        \
+                BODY(0) BODY(1) BODY(2) BODY(3) BODY(4) BODY(5) BODY(6) BODY(7)                         \
+            }                                                                                           \
+        }                                                                                               \
+        const unsigned long long c1 = __builtin_readcyclecounter();                                    \
+        SINK                                                                                            \
+        if ((threadIdx.x & 63) == 0) { st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c0, c1}; }       \
+    }
+
+#define DECL_F float a[NI], b = seed, c = seed * 0.5f; _Pragma("unroll") for (int i = 0; i < NI; ++i) a[i] = seed + (float)(i + threadIdx.x);
+#define SINK_F float s = 0.f; _Pragma("unroll") for (int i = 0; i < NI; ++i) s += a[i]; if (s == 12345.678f) out[0] = s;
+
+#define B_FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define B_ADD(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_SUB(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_MIN(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_EXP(i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+#define B_RCP(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+#define B_RNDNE(i) asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i]));
+#define B_CVT(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+#define B_LDEXP(i) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[i]) : "v"(1));
+#define B_CMP(i) asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+#define B_CMPS(i) asm volatile("v_cmp_ge_f32 s[20:21], %0, %1" : : "v"(a[i]), "v"(b) : "s20", "s21");
+#define B_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+#define B_CNDMASK_S(i) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b));
+#define B_DPPMOV(i) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+#define B_DPPADD(i) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+#define B_MED3(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define B_MADU24(i) asm volatile("v_mad_u32_u24 %0, %0, 48, %1" : "+v"(a[i]) : "v"(b));
+#define B_READLANE(i) asm volatile("v_readlane_b32 s22, %0, 5" : : "v"(a[i]) : "s22");
+#define B_SAND(i) asm volatile("s_and_b64 s[20:21], s[20:21], s[22:23]" : : : "s20", "s21", "scc");
+#define B_SCSEL(i) asm volatile("s_cselect_b64 s[20:21], s[22:23], 0" : : : "s20", "s21");
+#define B_SNOP(i) asm volatile("s_nop 0");
+
+KERNEL(k_fma, DECL_F, B_FMA, SINK_F)
+KERNEL(k_add, DECL_F, B_ADD, SINK_F)
+KERNEL(k_sub, DECL_F, B_SUB, SINK_F)
+KERNEL(k_mul, DECL_F, B_MUL, SINK_F)
+KERNEL(k_min, DECL_F, B_MIN, SINK_F)
+KERNEL(k_mov, DECL_F, B_MOV, SINK_F)
+KERNEL(k_exp, DECL_F, B_EXP, SINK_F)
+KERNEL(k_rcp, DECL_F, B_RCP, SINK_F)
+KERNEL(k_rndne, DECL_F, B_RNDNE, SINK_F)
+KERNEL(k_cvt, DECL_F, B_CVT, SINK_F)
+KERNEL(k_ldexp, DECL_F, B_LDEXP, SINK_F)
+KERNEL(k_cmp, DECL_F, B_CMP, SINK_F)
+KERNEL(k_cmps, DECL_F, B_CMPS, SINK_F)
+KERNEL(k_cndmask, DECL_F, B_CNDMASK, SINK_F)
+KERNEL(k_cndmask_s, DECL_F, B_CNDMASK_S, SINK_F)
+KERNEL(k_dppmov, DECL_F, B_DPPMOV, SINK_F)
+KERNEL(k_dppadd, DECL_F, B_DPPADD, SINK_F)
+KERNEL(k_med3, DECL_F, B_MED3, SINK_F)
+KERNEL(k_madu24, DECL_F, B_MADU24, SINK_F)
+KERNEL(k_readlane, DECL_F, B_READLANE, SINK_F)
+KERNEL(k_sand, DECL_F, B_SAND, SINK_F)
+KERNEL(k_scsel, DECL_F, B_SCSEL, SINK_F)
+KERNEL(k_snop, DECL_F, B_SNOP, SINK_F)
+
+// The live-strip bodies of the two compositing kernels, instruction for instruction as the compiler emits them
+// (forward.hip render_fwd_body / backward.hip render_bwd_body, objdump of the library): what ONE evaluated (entry, strip)
+// pair costs when 7 / 6 waves per SIMD run nothing else.
+#define B_FWD_STRIP(i)                                                                                                   \
+    asm volatile(                                                                                                         \
+        "v_sub_f32 %0, %1, %0\n v_mul_f32 %0, %2, %0\n v_fma_f32 %0, %0, %1, %2\n v_mul_f32 %0, %0, %1\n"                 \
+        "v_fmac_f32 %0, -0.5, %2\n v_mul_f32 %0, 0x3fb8aa3b, %0\n v_rndne_f32 %0, %0\n v_sub_f32 %0, %0, %1\n"            \
+        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_cvt_i32_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"         \
+        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, 1.0\n v_ldexp_f32 %0, %0, 1\n v_mul_f32 %0, %1, %0\n"           \
+        "v_min_f32 %0, 0x3f7d70a4, %0\n v_cmp_nlt_f32 vcc, 0, %0\n v_cmp_ngt_f32 s[20:21], %1, %0\n v_mul_f32 %0, %0, %1\n"\
+        "s_and_b64 s[20:21], vcc, s[20:21]\n v_sub_f32 %0, %1, %0\n s_and_b64 s[22:23], s[20:21], s[24:25]\n"             \
+        "v_cmp_gt_f32 vcc, %2, %0\n s_and_b64 s[26:27], vcc, s[22:23]\n s_andn2_b64 s[20:21], s[22:23], s[26:27]\n"       \
+        "s_cselect_b64 s[22:23], s[28:29], 0\n s_or_b64 s[30:31], s[22:23], s[30:31]\n v_cndmask_b32 %0, 0, %0, s[20:21]\n"\
+        "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_cndmask_b32 %0, %0, %1, s[20:21]\n"     \
+        "v_sub_f32 %0, %0, %1\n s_andn2_b64 s[24:25], s[24:25], s[26:27]\n s_cselect_b64 s[28:29], s[28:29], 0\n"          \
+        "s_and_b64 s[22:23], s[28:29], s[30:31]\n s_cmp_eq_u64 s[22:23], 0\n"                                              \
+        : "+v"(a[i]) : "v"(b), "v"(c)                                                                                      \
+        : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+KERNEL(k_fwd_strip, DECL_F, B_FWD_STRIP, SINK_F)
+
+typedef void (*kern_t)(int, float, float*, Stamp*);
+struct Row { const char* name; kern_t k; int valu_per_body; int salu_per_body; const char* isa_token; };
+
+int main(int argc, char** argv) {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * 8;                 // 8 workgroups of 256 threads per CU = 8 waves per SIMD
+    float* out; Stamp* st;
+    CK(hipMalloc(&out, 256)); CK(hipMalloc(&st, sizeof(Stamp) * blocks * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<Row> rows = {
+        {"v_fma_f32", k_fma, 1, 0, "v_fma_f32"}, {"v_add_f32", k_add, 1, 0, "v_add_f32"}, {"v_sub_f32", k_sub, 1, 0, "v_sub_f32"},
+        {"v_mul_f32", k_mul, 1, 0, "v_mul_f32"}, {"v_min_f32", k_min, 1, 0, "v_min_f32"}, {"v_mov_b32", k_mov, 1, 0, "v_mov_b32"},
+        {"v_med3_f32", k_med3, 1, 0, "v_med3_f32"}, {"v_mad_u32_u24", k_madu24, 1, 0, "v_mad_u32_u24"},
+        {"v_rndne_f32", k_rndne, 1, 0, "v_rndne_f32"}, {"v_cvt_i32_f32", k_cvt, 1, 0, "v_cvt_i32_f32"},
+        {"v_ldexp_f32", k_ldexp, 1, 0, "v_ldexp_f32"}, {"v_cmp_ge_f32 -> vcc", k_cmp, 1, 0, "v_cmp_ge_f32"},
+        {"v_cmp_ge_f32 -> sgpr pair", k_cmps, 1, 0, "v_cmp_ge_f32"},         {"v_cndmask_b32 (sgpr pair)", k_cndmask_s, 1, 0, "v_cndmask_b32"},
+        {"v_exp_f32", k_exp, 1, 0, "v_exp_f32"}, {"v_rcp_f32", k_rcp, 1, 0, "v_rcp_f32"},
+        {"v_mov_b32_dpp quad_perm", k_dppmov, 1, 0, "v_mov_b32_dpp"}, {"v_add_f32_dpp quad_perm", k_dppadd, 1, 0, "v_add_f32_dpp"},
+        {"v_readlane_b32", k_readlane, 1, 0, "v_readlane_b32"},
+        {"s_and_b64", k_sand, 0, 1, "s_and_b64"}, {"s_cselect_b64", k_scsel, 0, 1, "s_cselect_b64"}, {"s_nop 0", k_snop, 0, 1, "s_nop"},
+        {"render_fwd live strip (28 VALU + 10 SALU)", k_fwd_strip, 28, 10, "v_ldexp_f32"},
+    };
+    printf("# MI355X instruction issue cost: %d CUs x 4 SIMDs, 8 waves per SIMD, %d x %d independent instructions per trip\n", cus, UNROLL, NI);
+    printf("# every row: >= 50 ms warm-up + one launch of >= 20 ms; clock = s_memtime delta of the waves / HIP-event wall time\n");
+    printf("%-44s %9s %9s %10s %12s %12s\n", "instruction", "ms", "eff_GHz", "ns/instr", "cyc/instr", "cyc/body");
+    for (const Row& r : rows) {
+        // calibrate: a short launch, then scale the trip count to ~25 ms
+        int trips = 64;
+        float ms = 0.f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0)); r.k<<<blocks, 256>>>(trips, 1.001f, out, st); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms > 1.0f) break;
+            trips *= 8;
+        }
+        trips = (int)(trips * 25.0f / ms) + 1;
+        for (int w = 0; w < 3; ++w) r.k<<<blocks, 256>>>(trips, 1.001f, out, st);          // >= 50 ms warm-up (3 x 25 ms)
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0)); r.k<<<blocks, 256>>>(trips, 1.001f, out, st); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<Stamp> h(blocks * 4);
+        CK(hipMemcpy(h.data(), st, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
+        // every wave runs the whole loop and all of them are resident together: a wave's own s_memtime delta spans the
+        // launch (the counters of different XCDs are not synchronised, so stamps of different waves are never compared)
+        unsigned long long dmax = 0;
+        for (const Stamp& s : h) { if (s.c1 - s.c0 > dmax) dmax = s.c1 - s.c0; }
+        const double cycles = (double)dmax;
+        const double ghz = cycles / (ms * 1e6);
+        const double bodies_per_simd = (double)trips * UNROLL * NI * 8.0;      // 8 waves per SIMD
+        const double per_body_ns = ms * 1e6 / bodies_per_simd;
+        const int v = r.valu_per_body, s = r.salu_per_body;
+        const double instr = (double)(v + s);
+        printf("%-44s %9.2f %9.3f %10.3f %12.3f %12.3f\n", r.name, ms, ghz, per_body_ns / instr, per_body_ns * ghz / instr,
+               per_body_ns * ghz);
+    }
     return 0;
 }
