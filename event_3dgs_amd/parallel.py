@@ -6,14 +6,23 @@ no distributed path (utils/general_utils.py:133 pins cuda:0); this is the new ca
 import torch
 import torch.distributed as dist
 
+# Test hook: issue the collectives also in a ONE-rank process group (they are short-circuited there otherwise), so that
+# the real RCCL entry points -- ncclAvg all-reduce, reduce_scatter_tensor, all_gather_into_tensor -- execute on a box with a
+# single GPU (tests/test_hip_rccl.py; EventTrainer(force_distributed=True) sets it for its own calls).
+FORCE_SINGLE_RANK_COLLECTIVES = False
+
+
+def _collective_needed(group=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_SINGLE_RANK_COLLECTIVES
+
 
 def allreduce_mean_(flat_grad, group=None):
     """In-place mean over ranks of one flat gradient buffer."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _collective_needed(group):
         return flat_grad
     world = dist.get_world_size(group)
-    if world == 1:
-        return flat_grad
     op, divide = _mean_op(group)
     dist.all_reduce(flat_grad, op=op, group=group)
     if divide:
@@ -49,7 +58,7 @@ def allreduce_mean_async_(chunk, group=None):
     """Starts the in-place mean over ranks of one contiguous chunk of the gradient buffer and returns at once.
     Issuing the chunks of the buffer back to back and waiting for chunk k only before the optimizer step of chunk k
     overlaps the optimizer (HBM-bound) with the remaining collectives (xGMI-bound)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_needed(group):
         return PendingMean(chunk, None, 0)
     op, divide = _mean_op(group)
     work = dist.all_reduce(chunk, op=op, group=group, async_op=True)
@@ -68,7 +77,7 @@ class PendingGather:
 
 def allgather_async_(out, local, group=None):
     """Starts the all-gather of one contiguous `local` block per rank into the rows of `out` (world, numel)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_needed(group):
         out[0].copy_(local)
         return PendingGather(out, None)
     try:

@@ -64,7 +64,7 @@ class EventTrainer:
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
                  scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, active_sh_degree=3, process_group=None,
                  track_densification_stats=False, overlap_features=None, factorize_sh=None, dp_schedule=None,
-                 tile_cull=None, small_scene_paths=None, fast_exp=None):
+                 tile_cull=None, small_scene_paths=None, fast_exp=None, force_distributed=False):
         self.device = torch.device(device)
         # Rasteriser options of THIS trainer, carried in the flags word of every call it makes (E3DGS_FLAG_OPTIONS: the
         # library reads no process-wide setting then, so trainers with different options can share a process, also on
@@ -91,6 +91,11 @@ class EventTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        # `multi`: the distributed branches of the iteration are taken.  force_distributed (test hook) takes them in a
+        # ONE-rank process group too, so that the schedules run over the real RCCL backend on a single GPU.
+        self.multi = self.world > 1 or (bool(force_distributed) and dist.is_available() and dist.is_initialized())
+        if self.multi and self.world == 1:
+            parallel.FORCE_SINGLE_RANK_COLLECTIVES = True
         # Exchange of the non-SH groups (11 floats per Gaussian + c) between the ranks:
         #   "allreduce"  in-place mean (RCCL picks ring / tree), every rank then runs Adam on all of them;
         #   "rs_ag"      the direct schedule of SURVEY 5.8: reduce-scatter of the gradients, Adam on the OWNED shard only
@@ -101,7 +106,7 @@ class EventTrainer:
         sched = dp_schedule or os.environ.get("E3DGS_DP_SCHEDULE") or "allreduce"      # (argument first, as factorize_sh)
         if sched not in ("allreduce", "rs_ag"):
             raise ValueError("dp_schedule must be 'allreduce' or 'rs_ag'")
-        self.dp_schedule = sched if self.world > 1 else "allreduce"
+        self.dp_schedule = sched if self.multi else "allreduce"
         self._shard = None
         self.track_stats = track_densification_stats
         # The SH coefficients are 48 of the 59 floats per Gaussian, and nothing in front of the compositing kernel reads
@@ -112,7 +117,7 @@ class EventTrainer:
         # HBM-bound Adam and the next preprocess only compete for bandwidth and the separate colour kernel costs
         # 60 us (measured 299 vs 302 iters/s).  E3DGS_OVERLAP=0/1 overrides.
         if overlap_features is None:
-            overlap_features = self.world > 1
+            overlap_features = self.multi
         env = os.environ.get("E3DGS_OVERLAP")
         if env is not None:
             overlap_features = env != "0"
@@ -130,12 +135,12 @@ class EventTrainer:
             # by the bytes that cross the links (parallel.sh_exchange_bytes): 9 floats per Gaussian from every other rank
             # against a ring all-reduce of 48 -- the factorised exchange wins while world < 10.67
             factorize_sh = (env != "0") if env is not None else parallel.choose_sh_exchange(self.world) == "factorised"
-        self.factorize_sh = self.world > 1 and bool(factorize_sh)
+        self.factorize_sh = self.multi and bool(factorize_sh)
         # One rank: the same factorisation pays inside the GPU.  step() lets the backward hand out the per-view colour
         # gradients (9 floats per Gaussian) instead of the 48-float SH gradient, and ONE streaming kernel rebuilds that
         # gradient in registers and applies Adam to the SH coefficients (e3dgs_sh_adam_from_colour): 0.3 GB less HBM
         # traffic per iteration at 1 M Gaussians, bit-identical parameters.  E3DGS_SH_VIA_COLOUR=0 disables it.
-        self.sh_via_colour = self.world == 1 and os.environ.get("E3DGS_SH_VIA_COLOUR", "1") != "0"
+        self.sh_via_colour = (not self.multi) and os.environ.get("E3DGS_SH_VIA_COLOUR", "1") != "0"
         # No host wait inside an iteration: the binning buffers of the forward are sized from the instance counts of the
         # previous iterations (+ margin) and the kernels read the count from device memory
         # (e3dgs_rasterize_forward_multi_capacity); the host looks at the count only after it has enqueued the backward,
@@ -231,7 +236,7 @@ class EventTrainer:
     def export_groups(self):
         """Reference-layout tensors  name -> [param, exp_avg, exp_avg_sq]  (scene/gaussian_model.py:154-163 groups)."""
         self.sync_features()
-        if self._shard is not None and self.world > 1:
+        if self._shard is not None and self.multi:
             # (rs_ag: the moments of the other ranks' shards are stale here, and gathering them is a COLLECTIVE -- hidden
             # inside an export that typically only rank 0 performs it would deadlock the job)
             raise RuntimeError("dp_schedule='rs_ag': the Adam moments are sharded over the ranks -- call "
@@ -395,8 +400,8 @@ class EventTrainer:
             else:
                 self.steps[name] += 1
                 st[name] = self.steps[name]
-        dist_on = self.world > 1 and sync_grads
-        if self.world > 1 and (not dist_on or "gaussians" in skip):
+        dist_on = self.multi and sync_grads
+        if self.multi and (not dist_on or "gaussians" in skip):
             self.sync_optimizer_state()        # (rs_ag: these paths update the FULL moment buffers on every rank)
         if "gaussians" in skip:
             if st["c"]:
@@ -636,7 +641,7 @@ class EventTrainer:
         if self._packed_store is None or self._packed_store.numel() != need:
             self._packed_store = torch.empty(need, dtype=torch.float32, device=self.device)
             self._gathered_store = torch.empty(self.world, need, dtype=torch.float32, device=self.device) \
-                if self.world > 1 else None
+                if self.multi else None
             self._packed_cams = None
         if self._packed is None or self._packed.numel() != nv * (P * 3 + 3) or \
                 self._packed.data_ptr() != self._packed_store.data_ptr():
@@ -694,7 +699,7 @@ class EventTrainer:
         if self.factorize_sh or sh_via_colour:
             # (several ranks: the block always holds three views -- a rank that rendered a shared-pose iteration pads with
             # zero gradients -- so the all-gather blocks keep one size)
-            self._colour_gradients_instead_of_sh(out, settings, pad_to=3 if self.world > 1 else None)
+            self._colour_gradients_instead_of_sh(out, settings, pad_to=3 if self.multi else None)
         if want_vs:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out, stats_grad_view0=d_int if (shared and want_vs) else None)
@@ -833,7 +838,7 @@ class EventTrainer:
         full exp_avg / exp_avg_sq buffers (collective: every rank calls it -- before exporting, checkpointing, densifying
         or resetting).  A no-op for the other schedules."""
         S = self._shard
-        if S is None or self.world == 1:
+        if S is None or not self.multi:
             return
         for shard, full in ((S["m"], self.exp_avg), (S["v"], self.exp_avg_sq)):
             parallel.allgather_flat_async_(S["p"], shard, self.pg).wait()
