@@ -162,7 +162,6 @@ __device__ __forceinline__ void render_bwd_body(
         const unsigned long long nz = __builtin_amdgcn_ballot_w64(mvec != 0u);
         int nrem = n - base;
         asm volatile("" : "+s"(nrem));           // (opaque: otherwise re-associated into two scalar ops per entry)
-        unsigned long long touched = 0ull;
         for (int jb = 0; jb < cnt; jb += 16) {          // 16 entries share one commit
             uint32_t ng = (uint32_t)(nz >> jb) & 0xFFFFu;
             while (ng != 0u) {
@@ -195,7 +194,6 @@ __device__ __forceinline__ void render_bwd_body(
                 // to the reduced sums by the commit lanes.
                 float Uy = 0.0f, Uyy = 0.0f, So = 0.0f, Sc0 = 0.0f, Sc1 = 0.0f, Sc2 = 0.0f;
                 float So2 = 0.0f, Uy2 = 0.0f;               // STATS: sum u', sum u' dy of the second chain
-                unsigned long long any = 0ull;              // lanes that composited this entry at one of their pixels
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (((em >> k) & 1u) == 0u) continue;   // scalar: the forward did not evaluate this strip
@@ -206,7 +204,10 @@ __device__ __forceinline__ void render_bwd_body(
                     // c.y = pmin: below it alpha < 1/255 whatever the rounding (preprocess_kernel)
                     const unsigned long long live = __builtin_amdgcn_uicmp(contributor, last[k], 37 /* ULE */) &
                                                     __builtin_amdgcn_fcmpf(power, c.y, 3 /* OGE */);
-                    if (live != 0ull) {
+                    // (no `live != 0` early-out: the forward sets a strip's mask bit only where the entry was composited on
+                    // some pixel of the strip, and that pixel is live here -- its n_contrib is >= this position, `power` has
+                    // the forward's bits -- so the test would cost two scalar instructions per strip and never fire)
+                    {
                         // The two skip decisions of the forward: power > 0 -- exact here, `power` has the forward's bits --
                         // and alpha < 1/255, which the forward took with its polynomial exp.  Away from that threshold the
                         // outcome cannot depend on the exp: power >= c.z = pmin + 4e-4 keeps.  Inside the band the forward's
@@ -231,7 +232,6 @@ __device__ __forceinline__ void render_bwd_body(
                                 keep |= near & __builtin_amdgcn_fcmpf(af, E3_ALPHA_SKIP, 11 /* UGE: !(af < 1/255) */);
                             }
                         }
-                        any |= keep;
                         if (__builtin_amdgcn_inverse_ballot_w64(keep)) {
                             const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);
                             // 1-ulp v_rcp_f32
@@ -259,8 +259,7 @@ __device__ __forceinline__ void render_bwd_body(
                         }
                     }
                 }
-                if (any != 0ull) {
-                    touched |= 1ull << j;
+                {   // (every visited entry has a contributing pixel: see above)
                     float* r = &sRed[wave][0][0];
                     float* part_base_ptr = &sPart[wave][0][0];
                     const float Sx = dx * So;                  // all of these still lack the factor o (commit)
@@ -302,18 +301,16 @@ __device__ __forceinline__ void render_bwd_body(
                 }
             }
             if (((nz >> jb) & 0xFFFFull) != 0ull) {
-                // commit the (up to) 16 entries of this group.  Records exist only for entries the forward evaluated on
-                // some strip (non-zero mask = BinningState::touched of their slot): those no pixel used here get a zero
-                // record, the others are neither written nor read (run_reduce_kernel).
+                // commit the (up to) 16 entries of this group.  Records exist only for entries the forward composited
+                // somewhere (non-zero mask = BinningState::touched of their slot): the others are neither written nor read
+                // (run_reduce_kernel).
                 wave_sync();
                 if (lane < 16 && ((nz >> (jb + lane)) & 1ull) != 0ull) {
                     const int e = jb + lane;
-                    const bool hit = ((touched >> e) & 1ull) != 0ull;
-                    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     const float4* pp = reinterpret_cast<const float4*>(&sPart[wave][lane][0]);
-                    float4 p0 = hit ? pp[0] : z4, p1 = hit ? pp[1] : z4;
+                    float4 p0 = pp[0], p1 = pp[1];
                     const float4 c0 = pp[2], c1 = pp[3];
-                    const float p2 = hit ? ((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w)) : 0.0f;
+                    const float p2 = ((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w));
                     // p0 = (Sx, Sy, Sxx, Sxy) / o   p1 = (Syy / o, So, Sc0, Sc1)   p2 = Sc2
                     const float4 ea = sRec[wave][e].a;
                     const float4 eb = sRec[wave][e].b;
@@ -324,7 +321,7 @@ __device__ __forceinline__ void render_bwd_body(
                     g[1] = F3{-p0.w, -0.5f * p1.x, p1.y};
                     g[2] = F3{p1.z, p1.w, p2};
                     if (STATS && sv) {                       // the same mean2D formula on the second chain's sums
-                        const float sx = hit ? sPart2[wave][lane][0] * eb.y : 0.0f, sy = hit ? sPart2[wave][lane][1] * eb.y : 0.0f;
+                        const float sx = sPart2[wave][lane][0] * eb.y, sy = sPart2[wave][lane][1] * eb.y;
                         float* g2 = part2 + 2 * (size_t)__float_as_uint(sRec[wave][e].c.w);
                         g2[0] = -(ea.z * sx + ea.w * sy) * ddelx_dx;
                         g2[1] = -(eb.x * sy + ea.w * sx) * ddely_dy;
