@@ -12,7 +12,10 @@
 #include "common.h"
 #include <stdlib.h>
 
-constexpr int BWD_WAVES = 4;
+#ifndef E3_BWD_WG_WAVES
+#define E3_BWD_WG_WAVES 4
+#endif
+constexpr int BWD_WAVES = E3_BWD_WG_WAVES;
 
 extern unsigned long long* g_trace;
 int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, const uint32_t* work, uint32_t* order,

@@ -596,7 +596,10 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
 // x-dependent half of the quadratic form is shared by its four pixels.  Each round the wave
 // gathers 64 list entries (one per lane) into its private LDS slice and every lane then walks
 // them with broadcast ds_read_b128; the next round's gathers are in flight meanwhile.
-constexpr int RENDER_WAVES = 4;
+#ifndef E3_RENDER_WAVES
+#define E3_RENDER_WAVES 2      // waves (= tiles) per workgroup: 4 -> 2 measured -2.4 % on render_fwd_kernel (1: the same); wave slots are refilled at a finer grain
+#endif
+constexpr int RENDER_WAVES = E3_RENDER_WAVES;
 
 // Launch order of the compositing kernels: longest lists first (LPT).  Workgroups are dispatched in index
 // order as slots free up, so heavy tiles start at t = 0 and the short ones fill the tail; without this the
@@ -847,8 +850,20 @@ unsigned long long* g_trace = nullptr;   // debug: per-tile {start, end, entries
 // the kernel's alpha >= 1/255 test, so image, final_T and n_contrib are unchanged bit for bit.  Conics that are not safely
 // concave in dx (A <= 0, NaN) keep every strip.
 __device__ __forceinline__ void strip_pretest(const float4 ra, const float4 rb, const float4 rc, float X0, float Y0,
-                                              const unsigned long long alive[4], unsigned long long m[4]) {
+                                              const unsigned long long alive[4], unsigned long long m[4],
+                                              unsigned long long& unsafe) {
     const float A = ra.z, B = ra.w, C = rb.x, pmin = rc.y;
+    // Entries whose two per-pixel guards are provably no-ops -- the bulk -- skip them (render_fwd_body, E3_FWD_STRIP):
+    //  * `power > 0` (rejected by the reference) cannot come out of the kernel's arithmetic for a conic that is safely
+    //    positive definite: power = -(0.5 a + 0.5 c + b) (a = A dx^2, b = B dx dy, c = C dy^2) is evaluated with an error
+    //    below 3 u (0.5 a + 0.5 c + |b|) <= 3 u lmax r^2 (u = 2^-24) against a true value <= -0.5 lmin r^2, so the
+    //    computed sign is right once lmin / lmax > 6 u; det / tr^2 <= lmin / lmax, and 1e-5 leaves a factor of 28 (and
+    //    covers the rounding of det itself, <= u tr^2 / 2).  r = 0 gives +-0, which is not > 0.
+    //  * min(0.99, o G) is o G when o <= 0.99: G = exp_det(power <= 0) <= 1 (p(f) = fma(q, f, 1) with q > 0 for the
+    //    reduced argument f <= 0; 2^n p <= p(0.5) / 2 < 1 below that).
+    // NaNs fail the comparisons: unsafe.
+    const float det = A * C - B * B, tr = A + C;
+    unsafe = __builtin_amdgcn_ballot_w64(!(det > 1e-5f * (tr * tr)) || !(A > 0.0f) || !(rb.y <= E3_ALPHA_CLAMP));
     const float xr = ra.x - X0;                              // dx = xr - column
     const float y0r = ra.y - Y0;                             // dy of row r = y0r - r
     const float nBA = -B / A;
@@ -879,6 +894,9 @@ __device__ __forceinline__ void strip_pretest(const float4 ra, const float4 rb, 
     }
 }
 
+#ifndef E3_FWD_GUARDS
+#define E3_FWD_GUARDS 1
+#endif
 #ifndef E3_FWD_WAVES
 #define E3_FWD_WAVES 7      // 72 VGPRs: the lane-parallel strip pre-test at the top of a round must not cost the loop a wave per SIMD
 #endif
@@ -959,8 +977,8 @@ __device__ __forceinline__ void render_fwd_body(
         sA[wave][lane] = ra; sB[wave][lane] = rb; sC[wave][lane] = rc;
         // which strips each of the round's entries can contribute to at all (lane j decides for entry j; bit j of gm[k]):
         // tested against the live pixels' bounding box; a strip whose pixels have all finished drops out of gm for good
-        unsigned long long gm[4];
-        strip_pretest(ra, rb, rc, tile_x0, tile_y0, alive, gm);
+        unsigned long long gm[4], um;
+        strip_pretest(ra, rb, rc, tile_x0, tile_y0, alive, gm, um);
         wave_sync();
         if (base + WAVE + lane < n) {
             ra = rec[3 * (size_t)id_next]; rb = rec[3 * (size_t)id_next + 1]; rc = rec[3 * (size_t)id_next + 2];
@@ -986,6 +1004,7 @@ __device__ __forceinline__ void render_fwd_body(
             const float cxdx = a.z * dx;
             const float qx = cxdx * dx;
             const float cydx = a.w * dx;
+            const unsigned long long uj = um & jbit;    // (scalar) this entry keeps the `power > 0` / min(0.99, .) guards
             // lanes of one k form a 16x4 pixel strip: skipped with one scalar bit test when
             // the staging-time pre-test (strip_pretest) found that no pixel of it can reach alpha >= 1/255, or when all its
             // pixels have finished
@@ -996,10 +1015,15 @@ __device__ __forceinline__ void render_fwd_body(
                 const float q = FMA(b.x * dy, dy, qx);                                                                      \
                 const float power = FMA(-0.5f, q, -(cydx * dy));                                                            \
                 const float G = FAST ? __builtin_amdgcn_exp2f(power * 1.4426950408889634f) : exp_det_noclamp(power);        \
-                const float alpha = fminf(E3_ALPHA_CLAMP, b.y * G);                                                         \
-                /* lane masks in SGPR pairs: valid = alive & !(power > 0) & !(alpha < 1/255) */                             \
-                const unsigned long long valid = alive[k] & __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE */) &             \
-                                                 __builtin_amdgcn_fcmpf(alpha, E3_ALPHA_SKIP, 11 /* UGE */);                \
+                float alpha = b.y * G;                                                                                      \
+                /* lane masks in SGPR pairs: valid = alive & !(alpha < 1/255) [& !(power > 0)], alpha = min(0.99, alpha):   \
+                   the two bracketed guards only for the rare entries they can change anything for (strip_pretest: uj; the  \
+                   block is laid out of line) -- v_cmp / v_min issue at half the rate of v_fma (tools/ubench/valu_rate) */  \
+                unsigned long long valid = alive[k] & __builtin_amdgcn_fcmpf(alpha, E3_ALPHA_SKIP, 11 /* UGE */);           \
+                if (!E3_FWD_GUARDS || __builtin_expect(uj != 0ull, 0)) {                                                    \
+                    valid &= __builtin_amdgcn_fcmpf(power, 0.0f, 13 /* ULE */);                                             \
+                    alpha = fminf(E3_ALPHA_CLAMP, alpha);                                                                   \
+                }                                                                                                           \
                 const float w = alpha * T[k];                                                                               \
                 const float test_T = T[k] - w;                                                                              \
                 const unsigned long long stop = valid & __builtin_amdgcn_fcmpf(test_T, E3_T_STOP, 4 /* OLT */);             \
@@ -1008,15 +1032,17 @@ __device__ __forceinline__ void render_fwd_body(
                 unsigned long long app, bit;                                                                                \
                 asm("s_andn2_b64 %0, %2, %3\n\ts_cselect_b64 %1, %4, 0"                                                     \
                     : "=&s"(app), "=s"(bit) : "s"(valid), "s"(stop), "s"(jbit) : "scc");                                    \
-                sm[k] |= bit;                                                                                               \
                 const bool apply = __builtin_amdgcn_inverse_ballot_w64(app);                                                \
-                /* one select instead of five: a zero weight leaves C and T bit-unchanged (x + 0*c == x, x - 0 == x) */     \
+                /* one select instead of five: a zero weight leaves C and T bit-unchanged (x + 0*c == x, x - 0 == x).       \
+                   (The five updates under EXEC = app instead -- s_and_saveexec, v_fmac x3, v_mov x2, s_mov exec: two SALU   \
+                   for two v_cndmask -- measured +2.5 % on the kernel: profiles/EXPERIMENTS.md, round 4.) */                \
                 const float we = apply ? w : 0.0f;                                                                          \
                 C0[k] = FMA(b.z, we, C0[k]);                                                                                \
                 C1[k] = FMA(b.w, we, C1[k]);                                                                                \
                 C2[k] = FMA(c_x, we, C2[k]);                                                                                \
                 last[k] = apply ? contributor : last[k];                                                                    \
                 T[k] = T[k] - we;                     /* a pixel that stops here keeps its T and leaves the mask */         \
+                sm[k] |= bit;                                                                                               \
                 /* alive &= ~stop; when the strip's last pixel has finished no entry evaluates it again (gm = 0) */         \
                 asm("s_andn2_b64 %0, %0, %2\n\ts_cselect_b64 %1, %1, 0" : "+s"(alive[k]), "+s"(gm[k]) : "s"(stop) : "scc");  \
             }                                                                                                               \

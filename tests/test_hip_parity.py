@@ -85,6 +85,35 @@ def test_forward_backward_parity(N, W, H, use_sh, use_cov, bg, boost):
     assert np.all(grads["means2D"][:, 2] == 0)
 
 
+def test_guarded_entries_opaque_and_needle_splats():
+    """render_fwd_kernel takes the `power > 0` rejection and the min(0.99, .) clamp only for the entries they can change
+    anything for (opacity > 0.99, or a conic that is not safely positive definite: strip_pretest's `unsafe` ballot).  A
+    scene where both kinds are common -- a third of the opacities at 0.995 ... 1.0, a third of the splats stretched
+    to needles thousands of pixels long -- mixed with ordinary splats must stay bit-identical to the oracle."""
+    from oracle import c_oracle
+    N, W, H = 1500, 160, 112
+    act, cam = scene(N, W, H, seed=77)
+    g = torch.Generator().manual_seed(5)
+    r = torch.rand(N, generator=g)
+    act["opacities"] = torch.where((r < 0.33)[:, None], 0.995 + 0.005 * torch.rand(N, 1, generator=g), act["opacities"])
+    act["opacities"][:20] = 1.0
+    needle = (r > 0.66)
+    act["scales"] = act["scales"].clone()
+    act["scales"][needle, 0] *= 3000.0              # one axis: conic condition numbers far beyond 1e5
+    act["scales"][needle, 1:] *= 0.05
+    img, radii, grads, gw = _run_hip(act, cam, (0.2, 0.1, 0.0), True, False)
+    f = c_oracle.Forward(**oracle_kwargs(act, cam, (0.2, 0.1, 0.0), True, False))
+    assert (f.radii > 0).sum() > N // 4
+    assert np.array_equal(radii, f.radii)
+    assert np.array_equal(img, f.out_color), np.abs(img - f.out_color).max()
+    # gradients: the rows of the ordinary splats (a needle's own position gradient is cancellation noise in fp32 on both
+    # sides: conic entries ~1e-7 against ~3, tools/fuzz_medium.py)
+    gb = f.backward(gw)
+    keep = ~needle.numpy()
+    for k in ("means3D", "opacities", "shs"):
+        assert rel_l2(grads[k][keep], gb[k].reshape(grads[k].shape)[keep]) <= GRAD_TOL, k
+
+
 @pytest.fixture
 def no_tile_cull():
     """Reproduce the reference's integer binning exactly (all tiles of the 3-sigma rectangle)."""

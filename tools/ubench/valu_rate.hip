@@ -113,6 +113,82 @@ KERNEL(k_snop, DECL_F, B_SNOP, SINK_F)
         : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
 KERNEL(k_fwd_strip, DECL_F, B_FWD_STRIP, SINK_F)
 
+
+// Variants of the live-strip body: how VALU and SALU time combine (round 4: removing half-rate VALU instructions from
+// the real kernel bought nothing, adding SALU instructions cost time).
+#define B_FWD_STRIP_VALU(i)   /* the 28 VALU instructions alone */                                                      \
+    asm volatile(                                                                                                         \
+        "v_sub_f32 %0, %1, %0\n v_mul_f32 %0, %2, %0\n v_fma_f32 %0, %0, %1, %2\n v_mul_f32 %0, %0, %1\n"                 \
+        "v_fmac_f32 %0, -0.5, %2\n v_mul_f32 %0, 0x3fb8aa3b, %0\n v_rndne_f32 %0, %0\n v_sub_f32 %0, %0, %1\n"            \
+        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_cvt_i32_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"         \
+        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, 1.0\n v_ldexp_f32 %0, %0, 1\n v_mul_f32 %0, %1, %0\n"           \
+        "v_min_f32 %0, 0x3f7d70a4, %0\n v_cmp_nlt_f32 vcc, 0, %0\n v_cmp_ngt_f32 s[20:21], %1, %0\n v_mul_f32 %0, %0, %1\n"\
+        "v_sub_f32 %0, %1, %0\n"             \
+        "v_cmp_gt_f32 vcc, %2, %0\n"       \
+        "v_cndmask_b32 %0, 0, %0, s[20:21]\n"\
+        "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_cndmask_b32 %0, %0, %1, s[20:21]\n"     \
+        "v_sub_f32 %0, %0, %1\n"          \
+        : "+v"(a[i]) : "v"(b), "v"(c)                                                                                      \
+        : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+KERNEL(k_fwd_strip_valu, DECL_F, B_FWD_STRIP_VALU, SINK_F)
+#define B_FWD_STRIP_SALU(i)   /* its 10 SALU instructions alone */                                                      \
+    asm volatile(                                                                                                         \
+        "s_and_b64 s[20:21], vcc, s[20:21]\n s_and_b64 s[22:23], s[20:21], s[24:25]\n"             \
+        "s_and_b64 s[26:27], vcc, s[22:23]\n s_andn2_b64 s[20:21], s[22:23], s[26:27]\n"       \
+        "s_cselect_b64 s[22:23], s[28:29], 0\n s_or_b64 s[30:31], s[22:23], s[30:31]\n"\
+        "s_andn2_b64 s[24:25], s[24:25], s[26:27]\n s_cselect_b64 s[28:29], s[28:29], 0\n"          \
+        "s_and_b64 s[22:23], s[28:29], s[30:31]\n s_cmp_eq_u64 s[22:23], 0\n"                                              \
+        : "+v"(a[i]) : "v"(b), "v"(c)                                                                                      \
+        : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+KERNEL(k_fwd_strip_salu, DECL_F, B_FWD_STRIP_SALU, SINK_F)
+#define B_FWD_STRIP_NOGUARD(i)   /* without v_min, the `power > 0` compare and its s_and: 26 VALU + 9 SALU */             \
+    asm volatile(                                                                                                         \
+        "v_sub_f32 %0, %1, %0\n v_mul_f32 %0, %2, %0\n v_fma_f32 %0, %0, %1, %2\n v_mul_f32 %0, %0, %1\n"                 \
+        "v_fmac_f32 %0, -0.5, %2\n v_mul_f32 %0, 0x3fb8aa3b, %0\n v_rndne_f32 %0, %0\n v_sub_f32 %0, %0, %1\n"            \
+        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_cvt_i32_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"         \
+        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, 1.0\n v_ldexp_f32 %0, %0, 1\n v_mul_f32 %0, %1, %0\n"           \
+        "v_cmp_ngt_f32 s[20:21], %1, %0\n v_mul_f32 %0, %0, %1\n"\
+        "v_sub_f32 %0, %1, %0\n s_and_b64 s[22:23], s[20:21], s[24:25]\n"             \
+        "v_cmp_gt_f32 vcc, %2, %0\n s_and_b64 s[26:27], vcc, s[22:23]\n s_andn2_b64 s[20:21], s[22:23], s[26:27]\n"       \
+        "s_cselect_b64 s[22:23], s[28:29], 0\n s_or_b64 s[30:31], s[22:23], s[30:31]\n v_cndmask_b32 %0, 0, %0, s[20:21]\n"\
+        "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_cndmask_b32 %0, %0, %1, s[20:21]\n"     \
+        "v_sub_f32 %0, %0, %1\n s_andn2_b64 s[24:25], s[24:25], s[26:27]\n s_cselect_b64 s[28:29], s[28:29], 0\n"          \
+        "s_and_b64 s[22:23], s[28:29], s[30:31]\n s_cmp_eq_u64 s[22:23], 0\n"                                              \
+        : "+v"(a[i]) : "v"(b), "v"(c)                                                                                      \
+        : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+KERNEL(k_fwd_strip_noguard, DECL_F, B_FWD_STRIP_NOGUARD, SINK_F)
+#define B_FWD_STRIP_FAST(i)   /* v_exp_f32 instead of the polynomial: 20 VALU + 10 SALU */             \
+    asm volatile(                                                                                                         \
+        "v_sub_f32 %0, %1, %0\n v_mul_f32 %0, %2, %0\n v_fma_f32 %0, %0, %1, %2\n v_mul_f32 %0, %0, %1\n"                 \
+        "v_fmac_f32 %0, -0.5, %2\n v_mul_f32 %0, 0x3fb8aa3b, %0\n v_exp_f32 %0, %0\n v_mul_f32 %0, %1, %0\n"           \
+        "v_min_f32 %0, 0x3f7d70a4, %0\n v_cmp_nlt_f32 vcc, 0, %0\n v_cmp_ngt_f32 s[20:21], %1, %0\n v_mul_f32 %0, %0, %1\n"\
+        "s_and_b64 s[20:21], vcc, s[20:21]\n v_sub_f32 %0, %1, %0\n s_and_b64 s[22:23], s[20:21], s[24:25]\n"             \
+        "v_cmp_gt_f32 vcc, %2, %0\n s_and_b64 s[26:27], vcc, s[22:23]\n s_andn2_b64 s[20:21], s[22:23], s[26:27]\n"       \
+        "s_cselect_b64 s[22:23], s[28:29], 0\n s_or_b64 s[30:31], s[22:23], s[30:31]\n v_cndmask_b32 %0, 0, %0, s[20:21]\n"\
+        "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %0, %1, %2\n v_cndmask_b32 %0, %0, %1, s[20:21]\n"     \
+        "v_sub_f32 %0, %0, %1\n s_andn2_b64 s[24:25], s[24:25], s[26:27]\n s_cselect_b64 s[28:29], s[28:29], 0\n"          \
+        "s_and_b64 s[22:23], s[28:29], s[30:31]\n s_cmp_eq_u64 s[22:23], 0\n"                                              \
+        : "+v"(a[i]) : "v"(b), "v"(c)                                                                                      \
+        : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+KERNEL(k_fwd_strip_fast, DECL_F, B_FWD_STRIP_FAST, SINK_F)
+#define B_VAND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_VLSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));
+#define B_VADDU(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define B_VMAX(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+// Does a wave64 VALU instruction whose EXEC mask has an all-zero half skip that half's pass on the SIMD-32 datapath?
+#define DECL_F_LO32 DECL_F asm volatile("s_mov_b64 exec, 0xffffffff");
+#define DECL_F_LO16 DECL_F asm volatile("s_mov_b64 exec, 0xffff");
+#define DECL_F_EVEN DECL_F asm volatile("s_mov_b32 exec_lo, 0x55555555\n s_mov_b32 exec_hi, 0x55555555");
+KERNEL(k_fma_lo32, DECL_F_LO32, B_FMA, SINK_F)
+KERNEL(k_fma_lo16, DECL_F_LO16, B_FMA, SINK_F)
+KERNEL(k_fma_even, DECL_F_EVEN, B_FMA, SINK_F)
+KERNEL(k_cmp_lo32, DECL_F_LO32, B_CMPS, SINK_F)
+KERNEL(k_exp_lo32, DECL_F_LO32, B_EXP, SINK_F)
+KERNEL(k_vand, DECL_F, B_VAND, SINK_F)
+KERNEL(k_vlshladd, DECL_F, B_VLSHLADD, SINK_F)
+KERNEL(k_vaddu, DECL_F, B_VADDU, SINK_F)
+KERNEL(k_vmax, DECL_F, B_VMAX, SINK_F)
+
 typedef void (*kern_t)(int, float, float*, Stamp*);
 struct Row { const char* name; kern_t k; int valu_per_body; int salu_per_body; const char* isa_token; };
 
@@ -135,7 +211,16 @@ int main(int argc, char** argv) {
         {"v_mov_b32_dpp quad_perm", k_dppmov, 1, 0, "v_mov_b32_dpp"}, {"v_add_f32_dpp quad_perm", k_dppadd, 1, 0, "v_add_f32_dpp"},
         {"v_readlane_b32", k_readlane, 1, 0, "v_readlane_b32"},
         {"s_and_b64", k_sand, 0, 1, "s_and_b64"}, {"s_cselect_b64", k_scsel, 0, 1, "s_cselect_b64"}, {"s_nop 0", k_snop, 0, 1, "s_nop"},
+        {"v_fma_f32, EXEC = low 32 lanes", k_fma_lo32, 1, 0, "v_fma_f32"}, {"v_fma_f32, EXEC = low 16 lanes", k_fma_lo16, 1, 0, "v_fma_f32"},
+        {"v_fma_f32, EXEC = even lanes", k_fma_even, 1, 0, "v_fma_f32"}, {"v_cmp_ge_f32 -> sgpr, EXEC = low 32", k_cmp_lo32, 1, 0, "v_cmp_ge_f32"},
+        {"v_exp_f32, EXEC = low 32 lanes", k_exp_lo32, 1, 0, "v_exp_f32"},
+        {"v_and_b32", k_vand, 1, 0, "v_and_b32"}, {"v_lshl_add_u32", k_vlshladd, 1, 0, "v_lshl_add_u32"},
+        {"v_add_u32", k_vaddu, 1, 0, "v_add_u32"}, {"v_max_f32", k_vmax, 1, 0, "v_max_f32"},
         {"render_fwd live strip (28 VALU + 10 SALU)", k_fwd_strip, 28, 10, "v_ldexp_f32"},
+        {"  its 28 VALU alone", k_fwd_strip_valu, 28, 0, "v_ldexp_f32"},
+        {"  its 10 SALU alone", k_fwd_strip_salu, 0, 10, "s_cselect_b64"},
+        {"  without min / power>0 guard (26 + 9)", k_fwd_strip_noguard, 26, 9, "v_ldexp_f32"},
+        {"  with v_exp_f32 (20 + 10)", k_fwd_strip_fast, 20, 10, "v_exp_f32"},
     };
     printf("# MI355X instruction issue cost: %d CUs x 4 SIMDs, 8 waves per SIMD, %d x %d independent instructions per trip\n", cus, UNROLL, NI);
     printf("# every row: >= 50 ms warm-up + one launch of >= 20 ms; clock = s_memtime delta of the waves / HIP-event wall time\n");
