@@ -916,7 +916,13 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
 #pragma unroll
     for (int v = 0; v < E3_MAX_VIEWS; ++v)
         if (v < nv && mv.radii[(size_t)v * P + i] > 0) vis |= 1u << v;
-    if (!vis) {
+    // A Gaussian no view saw gets zeros -- but NOT on a path of its own: a wave mixes seen and unseen Gaussians, and two
+    // paths storing to the same cache lines at different times reach memory as partial-sector writes (WRITE_SIZE of this
+    // kernel: 434 MB for 80 MB of gradients, and it runs at the bandwidth of that traffic).  Unseen lanes therefore walk
+    // the common path with zero sums and every store below is executed by the whole wave: each store instruction covers
+    // whole, contiguous lines.  Only a wave without any seen Gaussian takes the shortcut (its stores are whole lines too).
+    const bool seen = vis != 0u;
+    if (__builtin_amdgcn_ballot_w64(seen) == 0ull) {
         if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
         dL_dopacity[i] = 0.0f;
         dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
@@ -975,14 +981,14 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
         dL_dmean2D[3 * (size_t)i] = m2x; dL_dmean2D[3 * (size_t)i + 1] = m2y; dL_dmean2D[3 * (size_t)i + 2] = 0.0f;
     }
     if (preact) { float o = act_sigmoid(opac_in[i]); gopac = gopac * o * (1.0f - o); }
-    dL_dopacity[i] = gopac;
+    dL_dopacity[i] = seen ? gopac : 0.0f;
     {
         float ds[3], dq[4];
         cov3_backward(cv, gcov, mv.vs.v[0].scale_modifier, qn[0], qn[1], qn[2], qn[3], preact, sact, qinv, ds, dq);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = ds[k];
+        for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = seen ? ds[k] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = dq[k];
+        for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = seen ? dq[k] : 0.0f;
     }
     // ---- SH coefficients: each written once; direction gradients collected per view
     float dx[E3_MAX_VIEWS], dy[E3_MAX_VIEWS], dz[E3_MAX_VIEWS], gc[E3_MAX_VIEWS][3];
@@ -1000,7 +1006,9 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (k < nk) {
-            const float c0 = sh[(size_t)(3 * k) * st], c1 = sh[(size_t)(3 * k + 1) * st], c2 = sh[(size_t)(3 * k + 2) * st];
+            // (unseen Gaussians do not read their coefficients: exec-masked loads)
+            const float c0 = seen ? sh[(size_t)(3 * k) * st] : 0.0f, c1 = seen ? sh[(size_t)(3 * k + 1) * st] : 0.0f,
+                        c2 = seen ? sh[(size_t)(3 * k + 2) * st] : 0.0f;
             float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
             for (int v = 0; v < E3_MAX_VIEWS; ++v) {
@@ -1026,7 +1034,8 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             gmean[2] += (ddz[v] - dz[v] * dot) * il;
         }
     }
-    dL_dmean3D[3 * (size_t)i] = gmean[0]; dL_dmean3D[3 * (size_t)i + 1] = gmean[1]; dL_dmean3D[3 * (size_t)i + 2] = gmean[2];
+    dL_dmean3D[3 * (size_t)i] = seen ? gmean[0] : 0.0f; dL_dmean3D[3 * (size_t)i + 1] = seen ? gmean[1] : 0.0f;
+    dL_dmean3D[3 * (size_t)i + 2] = seen ? gmean[2] : 0.0f;
 }
 
 // ---- SH gradient from per-view colour gradients -------------------------------------------------------------
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int P, int nranks, i
 #define E3_SH_SLICE 2      // SH coefficients (x 3 channels) per workgroup slice: 18 streams per thread (1 / 2 / 4 / 8: 0.329 / 0.303 / 0.318 / 0.388 ms for the optimizer stage)
 #endif
 struct ShAdam { float* m; float* v; float ss_dc, ss_rest, bc2s, b1, b2, eps; };
-__global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
+__global__ __launch_bounds__(256) void sh_adam_views_sliced_kernel(int P, int nranks, int views_per_rank, int D, int M,
                                                             const float* __restrict__ means,
                                                             const float* __restrict__ packed, size_t rank_stride,
                                                             float scale, float* __restrict__ sh, int planar, ShAdam ad) {
@@ -1142,6 +1151,77 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
     }
 }
 
+
+// Up to E3_SH_REG_VIEWS views in all (one rank's triplet): the per-view unit directions and colour gradients of the
+// thread's Gaussian are computed ONCE and kept in registers, and the thread walks the M / E3_SH_SLICE coefficient slices
+// itself -- the sliced kernel above re-reads the colour gradients and means once per slice (8 x 48 MB of its 960 MB of
+// fetches at 1 M Gaussians).  Each slice is the same 18 streams per thread; same arithmetic per element: bit-identical.
+constexpr int E3_SH_REG_VIEWS = 4;
+__global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
+                                                            const float* __restrict__ means,
+                                                            const float* __restrict__ packed, size_t rank_stride,
+                                                            float scale, float* __restrict__ sh, int planar, ShAdam ad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    constexpr int CS = E3_SH_SLICE, NE = 3 * CS, NV = E3_SH_REG_VIEWS;
+    const size_t st = planar ? (size_t)P : (size_t)1;
+    const size_t ebase = planar ? (size_t)i : (size_t)i * M * 3;
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float vx[NV], vy[NV], vz[NV], vg[NV][3];
+    bool von[NV];
+    const int nvt = nranks * views_per_rank;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        von[t] = false; vx[t] = vy[t] = vz[t] = vg[t][0] = vg[t][1] = vg[t][2] = 0.0f;
+        if (t < nvt) {
+            const int r = t / views_per_rank, v = t - r * views_per_rank;
+            const float* blk = packed + (size_t)r * rank_stride;
+            const float* cams = blk + (size_t)views_per_rank * P * 3;
+            const float* gp = blk + ((size_t)v * P + i) * 3;
+            vg[t][0] = gp[0]; vg[t][1] = gp[1]; vg[t][2] = gp[2];
+            von[t] = !(vg[t][0] == 0.0f && vg[t][1] == 0.0f && vg[t][2] == 0.0f);   // culled / clamped in this view
+            const float ox = mx - cams[3 * v], oy = my - cams[3 * v + 1], oz = mz - cams[3 * v + 2];
+            const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+            vx[t] = ox / len; vy[t] = oy / len; vz[t] = oz / len;
+        }
+    }
+    const int nk = (D + 1) * (D + 1);
+    const int nslices = M / CS;
+#pragma unroll 2
+    for (int sl = 0; sl < nslices; ++sl) {
+        const int k0 = CS * sl;
+        const size_t e0 = ebase + (size_t)(3 * k0) * st;
+        float m0[NE], v0[NE], p0[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) { m0[j] = ad.m[e0 + j * st]; v0[j] = ad.v[e0 + j * st]; p0[j] = sh[e0 + j * st]; }
+        float acc[CS][3];
+#pragma unroll
+        for (int k = 0; k < CS; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (von[t]) {
+#pragma unroll
+                for (int kk = 0; kk < CS; ++kk) {
+                    if (k0 + kk < nk) {
+                        float Y, Yx, Yy, Yz;
+                        sh_basis(k0 + kk, vx[t], vy[t], vz[t], Y, Yx, Yy, Yz);
+                        acc[kk][0] = FMA(Y, vg[t][0], acc[kk][0]); acc[kk][1] = FMA(Y, vg[t][1], acc[kk][1]);
+                        acc[kk][2] = FMA(Y, vg[t][2], acc[kk][2]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const float g = (k0 + j / 3 < nk) ? acc[j / 3][j % 3] * scale : 0.0f;     // inactive degrees: zero gradient, moments decay
+            const float mi = m0[j] + (1.0f - ad.b1) * (g - m0[j]);
+            const float vi = v0[j] * ad.b2 + (1.0f - ad.b2) * g * g;
+            ad.m[e0 + j * st] = mi; ad.v[e0 + j * st] = vi;
+            sh[e0 + j * st] = p0[j] - ((k0 == 0 && j < 3) ? ad.ss_dc : ad.ss_rest) * (mi / (__builtin_sqrtf(vi) / ad.bc2s + ad.eps));
+        }
+    }
+}
+
 int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
                           float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s) {
@@ -1150,9 +1230,14 @@ int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
     ShAdam ad;
     ad.m = exp_avg; ad.v = exp_avg_sq; ad.ss_dc = (float)((double)lr_dc / bc1); ad.ss_rest = (float)((double)lr_rest / bc1);
     ad.bc2s = (float)sqrt(bc2); ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
-    sh_adam_views_kernel<<<dim3((P + 255) / 256, M / E3_SH_SLICE), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
-                                                                           rank_stride, scale, sh,
-                                                                           (flags & E3_FLAG_SH_PLANAR) != 0, ad);
+    static const bool reg_views = !(getenv("E3DGS_SH_ADAM_SLICED") && atoi(getenv("E3DGS_SH_ADAM_SLICED")) != 0);   // (A/B switch)
+    if (reg_views && nranks * views_per_rank <= E3_SH_REG_VIEWS && M % E3_SH_SLICE == 0)
+        sh_adam_views_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
+                                                                          rank_stride, scale, sh,
+                                                                          (flags & E3_FLAG_SH_PLANAR) != 0, ad);
+    else
+        sh_adam_views_sliced_kernel<<<dim3((P + 255) / 256, M / E3_SH_SLICE), dim3(256), 0, s>>>(
+            P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, sh, (flags & E3_FLAG_SH_PLANAR) != 0, ad);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
