@@ -177,7 +177,7 @@ def install(tag):
     src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
     for f in ("kernel_stats.csv", "kernel_stats_top.txt", "pmc_traffic_all_kernels.txt", "sq_instruction_mix.txt", "summary.json",
-              "ubench.txt"):
+              "ubench.txt", "ubench_valu_rate.txt", "ubench_mixed_issue.txt"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     shutil.copy(os.path.join(src, "summary.json"), os.path.join(ROOT, "profiles", "traffic.json"))
