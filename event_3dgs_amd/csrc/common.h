@@ -176,7 +176,10 @@ static inline T* carve(char*& p, size_t count) {
 
 // ---------------------------------------------------------------- radix sort / scan
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;                       // keys per thread
+#ifndef E3_SORT_ITEMS
+#define E3_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = E3_SORT_ITEMS;            // keys per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
