@@ -291,7 +291,8 @@ __global__ __launch_bounds__(EV_THREADS) void event_reduce_kernel(
 // scalars (float[8]): 0 loss, 1 dL/dc, 2 rho, 3 L1 event, 4 L1 intensity, 5 L1 blur, 6 kE, 7 kI
 __global__ __launch_bounds__(EV_THREADS) void event_finalize_kernel(int nblocks, size_t HW, const double* __restrict__ partials,
                                                                     const float* __restrict__ c_ptr, int has_blur,
-                                                                    float* __restrict__ scalars, float* __restrict__ dc_out) {
+                                                                    float* __restrict__ scalars, float* __restrict__ dc_out,
+                                                                    double* __restrict__ nz_out) {
     // one workgroup (a single wave walked the ~2 000 partial rows in 12 us of dependent loads); fixed order: deterministic
     __shared__ double sfin[EV_NSUM][EV_THREADS / WAVE];
     double acc[EV_NSUM] = {0, 0, 0, 0, 0};
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_finalize_kernel(int nblocks,
         scalars[2] = (float)rho; scalars[3] = (float)L1E; scalars[4] = (float)L1I; scalars[5] = (float)L1B;
         scalars[6] = (float)(outer * 0.9 * rho / n);
         scalars[7] = (float)(outer * 0.1 * (1.0 - rho) / (3.0 * n));
+        if (nz_out) *nz_out = acc[1];          // count(D* != 0): a property of the ground-truth pair (event_fused_kernel)
     }
 }
 
@@ -432,6 +434,139 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     }
 }
 
+
+// One pass instead of two.  The gradient pass needs two numbers of the reduction, kE and kI -- and both depend on rho =
+// count(D* != 0) / n alone, which is a property of the GROUND-TRUTH pair (D* is the contrast of gt_now / gt_next): a caller
+// that has seen the pair before hands the count back (`nz_count`, written by event_finalize_kernel the first time), and the
+// partial sums of the loss and the three pixel gradients come out of ONE sweep over the seven images -- the planes are
+// read once, the four logarithms evaluated once.  Same per-pixel arithmetic, same accumulation order, same block / thread
+// -> pixel mapping as event_reduce_kernel + event_grad_kernel: bit-identical results.
+__global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
+    size_t HW, const float* __restrict__ image, const float* __restrict__ now, const float* __restrict__ next,
+    const float* __restrict__ gt_int, const float* __restrict__ gt_now, const float* __restrict__ gt_next,
+    const float* __restrict__ gt_blur, const float* __restrict__ c_ptr, float gt_c, const double* __restrict__ nz_count,
+    double* __restrict__ partials, float* d_image, float* d_now /* may alias d_image: the SUM is stored */,
+    float* __restrict__ d_next) {
+    __shared__ double sred[EV_NSUM][EV_THREADS / WAVE];
+    const bool shared = d_now == d_image;
+    const bool total_in_now = !shared && image == now;
+    const float c = c_ptr[0];
+    float kE, kI;
+    {   // event_finalize_kernel's expressions on the handed-back count
+        const double n = (double)HW, rho = nz_count[0] / n, outer = gt_blur ? 0.5 : 1.0;
+        kE = (float)(outer * 0.9 * rho / n);
+        kI = (float)(outer * 0.1 * (1.0 - rho) / (3.0 * n));
+    }
+    const float kB = 0.5f / (3.0f * (float)HW);
+    const float wch[3] = {0.4124f, 0.35758f, 0.1804f};
+    double acc[EV_NSUM] = {0, 0, 0, 0, 0};
+    auto pixel = [&](const float nx[3], const float nw[3], const float gx[3], const float gw[3], const float im[3],
+                     const float gi[3], const float gb[3], float dn[3], float dw[3], float di[3]) {
+        auto lum = [](const float v[3]) { return FMA(0.1804f, v[2], FMA(0.35758f, v[1], 0.4124f * v[0])); };
+        const float yn = lum(nx) + 1e-8f, yo = lum(nw) + 1e-8f;
+        const float D = (logf(yn) - logf(yo)) / c;
+        const float Dg = (logf(lum(gx) + 1e-8f) - logf(lum(gw) + 1e-8f)) / gt_c;
+        const float e = D - Dg;
+        const float sg = (float)((e > 0.0f) - (e < 0.0f));
+        acc[0] += fabsf(e);
+        acc[1] += (Dg != 0.0f) ? 1.0 : 0.0;
+        acc[2] += (double)((e > 0.0f) - (e < 0.0f)) * (double)D;
+        const float k = kE * sg / c;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            acc[3] += fabsf(im[ch] - gi[ch]);
+            if (gt_blur) acc[4] += fabsf(im[ch] - gb[ch]);
+            dn[ch] = k * wch[ch] / yn;
+            dw[ch] = -(k * wch[ch]) / yo;
+            const float ei = im[ch] - gi[ch];
+            float g = kI * (float)((ei > 0.0f) - (ei < 0.0f));
+            if (gt_blur) {
+                const float eb = im[ch] - gb[ch];
+                g += kB * (float)((eb > 0.0f) - (eb < 0.0f));
+            }
+            di[ch] = g;
+        }
+    };
+    const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(now) |
+                                        reinterpret_cast<uintptr_t>(next) | reinterpret_cast<uintptr_t>(gt_int) |
+                                        reinterpret_cast<uintptr_t>(gt_now) | reinterpret_cast<uintptr_t>(gt_next) |
+                                        reinterpret_cast<uintptr_t>(gt_blur) | reinterpret_cast<uintptr_t>(d_image) |
+                                        reinterpret_cast<uintptr_t>(d_now) | reinterpret_cast<uintptr_t>(d_next)) & 15) == 0;
+    if (vec) {
+        const size_t HW4 = HW >> 2;
+        for (size_t q = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; q < HW4; q += (size_t)gridDim.x * EV_THREADS) {
+            float4 vn[3], vw[3], vgx[3], vgw[3], vim[3], vgi[3], vgb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                vn[ch] = reinterpret_cast<const float4*>(next + ch * HW)[q];
+                vw[ch] = reinterpret_cast<const float4*>(now + ch * HW)[q];
+                vgx[ch] = reinterpret_cast<const float4*>(gt_next + ch * HW)[q];
+                vgw[ch] = reinterpret_cast<const float4*>(gt_now + ch * HW)[q];
+                vim[ch] = reinterpret_cast<const float4*>(image + ch * HW)[q];
+                vgi[ch] = reinterpret_cast<const float4*>(gt_int + ch * HW)[q];
+                vgb[ch] = gt_blur ? reinterpret_cast<const float4*>(gt_blur + ch * HW)[q] : make_float4(0, 0, 0, 0);
+            }
+            float on[3][4], ow[3][4], oi[3][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                auto comp = [u](const float4& v) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); };
+                const float nx[3] = {comp(vn[0]), comp(vn[1]), comp(vn[2])}, nw[3] = {comp(vw[0]), comp(vw[1]), comp(vw[2])};
+                const float gx[3] = {comp(vgx[0]), comp(vgx[1]), comp(vgx[2])}, gw[3] = {comp(vgw[0]), comp(vgw[1]), comp(vgw[2])};
+                const float im[3] = {comp(vim[0]), comp(vim[1]), comp(vim[2])}, gi[3] = {comp(vgi[0]), comp(vgi[1]), comp(vgi[2])};
+                const float gb[3] = {comp(vgb[0]), comp(vgb[1]), comp(vgb[2])};
+                float dn[3], dw[3], di[3];
+                pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { on[ch][u] = dn[ch]; ow[ch][u] = dw[ch]; oi[ch][u] = di[ch]; }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                reinterpret_cast<float4*>(d_next + ch * HW)[q] = make_float4(on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
+                if (shared) {
+                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1],
+                                                                                  oi[ch][2] + ow[ch][2], oi[ch][3] + ow[ch][3]);
+                } else {
+                    if (total_in_now) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ow[ch][u] = oi[ch][u] + ow[ch][u];
+                    }
+                    reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
+                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
+                }
+            }
+        }
+    } else {
+        for (size_t p = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * EV_THREADS) {
+            float nx[3], nw[3], gx[3], gw[3], im[3], gi[3], gb[3], dn[3], dw[3], di[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                nx[ch] = next[ch * HW + p]; nw[ch] = now[ch * HW + p]; gx[ch] = gt_next[ch * HW + p];
+                gw[ch] = gt_now[ch * HW + p]; im[ch] = image[ch * HW + p]; gi[ch] = gt_int[ch * HW + p];
+                gb[ch] = gt_blur ? gt_blur[ch * HW + p] : 0.0f;
+            }
+            pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                d_next[ch * HW + p] = dn[ch];
+                if (shared) d_image[ch * HW + p] = di[ch] + dw[ch];
+                else { d_now[ch * HW + p] = total_in_now ? di[ch] + dw[ch] : dw[ch]; d_image[ch * HW + p] = di[ch]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EV_NSUM; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        if ((threadIdx.x & 63) == 0) sred[k][threadIdx.x >> 6] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < EV_NSUM) {
+        double s = 0;
+        for (int w = 0; w < EV_THREADS / WAVE; ++w) s += sred[threadIdx.x][w];
+        partials[(size_t)blockIdx.x * EV_NSUM + threadIdx.x] = s;
+    }
+}
+
 static inline int ev_blocks(size_t HW) {
     size_t b = (HW + EV_THREADS - 1) / EV_THREADS;
     return (int)(b < 2048 ? b : 2048);
@@ -441,16 +576,25 @@ size_t e3_event_scratch_bytes(int W, int H) { return (size_t)ev_blocks((size_t)W
 int e3_event_loss_impl(int W, int H, const float* image, const float* now, const float* next, const float* gt_int,
                        const float* gt_now, const float* gt_next, const float* gt_blur, const float* c, float gt_c,
                        float* d_image, float* d_now, float* d_next, float* scalars, char* scratch, hipStream_t s,
-                       float* dc_out) {
+                       float* dc_out, double* nz_count, int nz_valid) {
     size_t HW = (size_t)W * H;
     if (HW == 0) return 0;
     int nb = ev_blocks(HW);
     double* partials = reinterpret_cast<double*>(scratch);
-    event_reduce_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
-                                                              gt_c, partials);
-    event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars, dc_out);
-    event_grad_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
-                                                            gt_c, scalars, d_image, d_now, d_next);
+    if (nz_count && nz_valid) {
+        // the ground-truth pair's count is known: one sweep (partial sums + the three pixel gradients), then the scalars
+        event_fused_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
+                                                                 gt_c, nz_count, partials, d_image, d_now, d_next);
+        event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars, dc_out,
+                                                                   nullptr);
+    } else {
+        event_reduce_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
+                                                                  gt_c, partials);
+        event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars, dc_out,
+                                                                   nz_count);
+        event_grad_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
+                                                                gt_c, scalars, d_image, d_now, d_next);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "event loss kernels");
 }

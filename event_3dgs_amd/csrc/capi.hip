@@ -74,7 +74,8 @@ size_t e3_knn_scratch_bytes(int);
 int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
 size_t e3_event_scratch_bytes(int, int);
 int e3_event_loss_impl(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
-                       const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t, float*);
+                       const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t, float*, double*,
+                       int);
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_segments_impl(size_t, float*, const float*, float*, float*, int, const size_t*, const float*, const float*, float,
@@ -93,7 +94,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 13; }
+int e3dgs_abi_version(void) { return 14; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -522,7 +523,16 @@ int e3dgs_event_loss(int width, int height, const float* image, const float* img
                      float* dc_out, char* scratch, void* stream) {
     g_err[0] = 0;
     return e3_event_loss_impl(width, height, image, img_now, img_next, gt_int, gt_now, gt_next, gt_blur, c, gt_c,
-                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream, dc_out);
+                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream, dc_out, nullptr, 0);
+}
+int e3dgs_event_loss_cached(int width, int height, const float* image, const float* img_now, const float* img_next,
+                            const float* gt_int, const float* gt_now, const float* gt_next, const float* gt_blur,
+                            const float* c, float gt_c, float* d_image, float* d_now, float* d_next, float* scalars_out,
+                            float* dc_out, double* nz_count, int nz_valid, char* scratch, void* stream) {
+    g_err[0] = 0;
+    if (!nz_count) return e3_fail(hipErrorInvalidValue, "e3dgs_event_loss_cached: nz_count is NULL");
+    return e3_event_loss_impl(width, height, image, img_now, img_next, gt_int, gt_now, gt_next, gt_blur, c, gt_c,
+                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream, dc_out, nz_count, nz_valid);
 }
 
 size_t e3dgs_ssim_scratch_bytes(int channels, int height, int width) { return e3_ssim_scratch_bytes(channels, height, width); }

@@ -44,8 +44,42 @@ class _EventLoss(torch.autograd.Function):
                 None)
 
 
-def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17, out=None, dc_out=None):
-    """Direct call of e3dgs_event_loss (no autograd).  Returns (scalars[8], d_image, d_now, d_next):
+class PairCounts:
+    """count(D* != 0) of the ground-truth pairs an event loop has met (e3dgs_event_loss_cached): one device double per
+    (gt_now, gt_next) pair, written by the first iteration that sees the pair and handed back afterwards, so that the loss
+    sweeps the images once instead of twice.  Entries are matched by tensor IDENTITY (weak references: an address can be
+    reused by another tensor) and in-place version; at most `capacity` pairs are remembered (oldest dropped).  All calls
+    that share an instance must be enqueued on one stream (the count is produced and consumed in stream order)."""
+
+    def __init__(self, capacity=4096):
+        self.capacity = int(capacity)
+        self._entries = {}
+
+    @staticmethod
+    def _sig(gt_now, gt_next, gt_c):
+        return (gt_now._version, gt_next._version, float(gt_c), tuple(gt_now.shape))
+
+    def lookup(self, gt_now, gt_next, gt_c):
+        """The pair's count tensor, or None when the pair is new (or was modified in place since)."""
+        e = self._entries.get((id(gt_now), id(gt_next)))
+        if e is not None and e[0]() is gt_now and e[1]() is gt_next and e[2] == self._sig(gt_now, gt_next, gt_c):
+            return e[3]
+        return None
+
+    def remember(self, gt_now, gt_next, gt_c, count):
+        """`count`: the device double an ENQUEUED e3dgs_event_loss_cached(nz_valid = 0) call fills."""
+        import weakref
+        key = (id(gt_now), id(gt_next))
+        self._entries.pop(key, None)
+        while len(self._entries) >= self.capacity:
+            self._entries.pop(next(iter(self._entries)))
+        self._entries[key] = (weakref.ref(gt_now), weakref.ref(gt_next), self._sig(gt_now, gt_next, gt_c), count)
+
+
+def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17, out=None, dc_out=None,
+                   pair_counts=None):
+    """Direct call of e3dgs_event_loss (no autograd; pair_counts: a PairCounts instance -> e3dgs_event_loss_cached, one
+    sweep over the images from the second time a ground-truth pair is met, bit-identical results).  Returns (scalars[8], d_image, d_now, d_next):
     scalars[0] = loss, [1] = dL/dc, [2] = rho, [3..5] = L1 event / intensity / blur.  `out` may carry
     preallocated (scalars, d_image, d_now, d_next, scratch) tensors to reuse across steps; `dc_out`: a one-element
     device tensor that also receives dL/dc (the threshold's slot of a flat gradient buffer).
@@ -62,11 +96,20 @@ def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur
                torch.empty_like(image),
                torch.empty(L.e3dgs_event_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev))
     scalars, d_image, d_now, d_next, scratch = out
+    head = (W, H, _lib.ptr(image), _lib.ptr(img_now), _lib.ptr(img_next), _lib.ptr(gt_int), _lib.ptr(gt_now),
+            _lib.ptr(gt_next), _lib.ptr(gt_blur), _lib.ptr(c), float(gt_c), _lib.ptr(d_image), _lib.ptr(d_now),
+            _lib.ptr(d_next), _lib.ptr(scalars), _lib.ptr(dc_out))
     with torch.cuda.device(dev):
-        rc = L.e3dgs_event_loss(W, H, _lib.ptr(image), _lib.ptr(img_now), _lib.ptr(img_next), _lib.ptr(gt_int),
-                                _lib.ptr(gt_now), _lib.ptr(gt_next), _lib.ptr(gt_blur), _lib.ptr(c), float(gt_c),
-                                _lib.ptr(d_image), _lib.ptr(d_now), _lib.ptr(d_next), _lib.ptr(scalars),
-                                _lib.ptr(dc_out), _lib.ptr(scratch), _lib.current_stream())
+        if pair_counts is None:
+            rc = L.e3dgs_event_loss(*head, _lib.ptr(scratch), _lib.current_stream())
+        else:
+            cnt = pair_counts.lookup(gt_now, gt_next, gt_c)
+            valid = cnt is not None
+            if not valid:
+                cnt = torch.zeros(1, dtype=torch.float64, device=dev)
+            rc = L.e3dgs_event_loss_cached(*head, _lib.ptr(cnt), int(valid), _lib.ptr(scratch), _lib.current_stream())
+            if rc == 0 and not valid:
+                pair_counts.remember(gt_now, gt_next, gt_c, cnt)
     _lib.check(rc, "e3dgs_event_loss")
     return scalars, d_image, d_now, d_next
 

@@ -225,6 +225,9 @@ class EventTrainer:
         # scratch that depends on N
         self.viewspace_grad = torch.zeros(N, 3, dtype=torch.float32, device=self.device) if self.track_stats else None
         self._loss_bufs = None
+        # count(D* != 0) of the ground-truth pairs met so far: the event loss sweeps the images once from the second time a
+        # pair comes up (losses.PairCounts; E3DGS_EVENT_LOSS_CACHED=0: always the three-launch form)
+        self._pair_counts = losses.PairCounts() if os.environ.get("E3DGS_EVENT_LOSS_CACHED", "1") != "0" else None
         self._counts = None
         # scratch of the rasteriser calls of step(): persistent, grows geometrically (no allocator traffic per step);
         # it survives densification (the buffers are sized by bytes, not by N)
@@ -691,7 +694,7 @@ class EventTrainer:
             d_int = self._dstat
         scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[i_now], imgs[i_next], self.c, gt_int, gt_now, gt_next, gt_blur,
                                                  out=(sc, d_int, dpix[i_now], dpix[i_next], scratch),
-                                                 dc_out=self.c_grad)                                                   # train.py:165-203
+                                                 dc_out=self.c_grad, pair_counts=self._pair_counts)                    # train.py:165-203
         # (image and img_now are the same tensor, the outputs are not: the kernel stored the sum in dpix[0], d_int alone)
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads

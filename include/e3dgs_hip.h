@@ -461,6 +461,23 @@ int e3dgs_event_loss(
                                gradient buffer: saves the caller a copy kernel per iteration) */
     char* scratch,
     void* stream);
+/*
+ * The same loss in ONE sweep over the images for a ground-truth pair the caller has met before (ABI 14).  The gradient
+ * pass needs two numbers of the reduction pass, and both depend on rho = count(D* != 0) / (W H) alone -- a property of
+ * (gt_now, gt_next), not of the renders (utils/loss_utils.py:234-249 on the ground-truth pair, train.py:170-176).
+ * `nz_count` is one device double owned by the caller, one per ground-truth pair:
+ *   nz_valid == 0: the three launches of e3dgs_event_loss; *nz_count receives the pair's count;
+ *   nz_valid != 0: *nz_count is read; partial sums and the three pixel gradients come out of one pass (every plane read
+ *                  once), followed by the scalars.  Same arithmetic in the same order: bit-identical outputs.
+ * A caller that changes a ground-truth frame in place starts over with nz_valid = 0.
+ */
+int e3dgs_event_loss_cached(
+    int width, int height, const float* image, const float* img_now, const float* img_next, const float* gt_int,
+    const float* gt_now, const float* gt_next, const float* gt_blur, const float* c, float gt_c, float* d_image,
+    float* d_now, float* d_next, float* scalars_out, float* dc_out,
+    double* nz_count,       /* (1) device: count of pixels with a non-zero contrast target of this ground-truth pair */
+    int nz_valid,
+    char* scratch, void* stream);
 
 /*
  * Mean SSIM of two (C,H,W) images and (optionally) its gradient w.r.t. img1.

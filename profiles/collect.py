@@ -40,7 +40,7 @@ STAGES = {          # bench.py stage -> kernel-name prefixes (rocprof names; tem
     "render_bwd": ["render_bwd_kernel"],
     "geom_bwd": ["run_reduce_kernel", "geom_bwd_multi_kernel"],
     "optimizer": ["sh_adam_views_kernel", "adam_segments_kernel"],
-    "event_loss": ["event_reduce_kernel", "event_finalize_kernel", "event_grad_kernel"],
+    "event_loss": ["event_reduce_kernel", "event_finalize_kernel", "event_grad_kernel", "event_fused_kernel"],
 }
 SQ_PASSES = [
     ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",

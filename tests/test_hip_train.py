@@ -1154,6 +1154,52 @@ def test_event_loss_kernel_shared_render_conventions():
     assert torch.allclose(leaf.grad, di0 + dn0, rtol=0, atol=0)
 
 
+def test_event_loss_one_sweep_for_a_known_ground_truth_pair():
+    """e3dgs_event_loss_cached: the first call on a ground-truth pair runs the three launches and leaves the pair's
+    count(D* != 0); later calls sweep the images ONCE (event_fused_kernel) -- scalars and the three pixel gradients bit for
+    bit those of e3dgs_event_loss, for odd frame sizes (scalar path), 16-byte friendly ones (vector path), the deblur term
+    and both shared-render conventions; a frame changed in place starts over."""
+    from event_3dgs_amd import losses
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for H, W, blur in ((37, 53, False), (64, 96, False), (64, 96, True)):
+        img, now, nxt, gi, gn, gx, gb = (torch.rand(3, H, W, device=DEV, generator=g) * 0.8 + 0.1 for _ in range(7))
+        gx[:, : H // 3] = gn[:, : H // 3]                       # a third of the contrast targets exactly zero: rho < 1
+        c = torch.tensor([0.19], device=DEV)
+        blur_t = gb if blur else None
+        ref = [t.clone() for t in losses.event_loss_raw(img, now, nxt, c, gi, gn, gx, blur_t)]
+        pc = losses.PairCounts()
+        first = [t.clone() for t in losses.event_loss_raw(img, now, nxt, c, gi, gn, gx, blur_t, pair_counts=pc)]
+        cnt = pc.lookup(gn, gx, 0.17)
+        assert cnt is not None and float(cnt) == H * W - (H // 3) * W   # (random targets elsewhere: non-zero)
+        dc = torch.zeros(1, device=DEV)
+        second = [t.clone() for t in losses.event_loss_raw(img, now, nxt, c, gi, gn, gx, blur_t, pair_counts=pc, dc_out=dc)]
+        for a, b, e in zip(ref, first, second):
+            assert torch.equal(a, b) and torch.equal(a, e)
+        assert float(dc) == float(ref[0][1])
+        # other renders, same pair: still one sweep, still identical to the three-launch form
+        img2, now2, nxt2 = (torch.rand(3, H, W, device=DEV, generator=g) * 0.8 + 0.1 for _ in range(3))
+        ref2 = [t.clone() for t in losses.event_loss_raw(img2, now2, nxt2, c, gi, gn, gx, blur_t)]
+        got2 = losses.event_loss_raw(img2, now2, nxt2, c, gi, gn, gx, blur_t, pair_counts=pc)
+        assert all(torch.equal(a, b) for a, b in zip(ref2, got2))
+        # shared render: aliased outputs (the sum) and separate outputs (sum + intensity part)
+        sh_ref = [t.clone() for t in losses.event_loss_raw(img2, img2, nxt2, c, gi, gn, gx, blur_t)]
+        sh_got = losses.event_loss_raw(img2, img2, nxt2, c, gi, gn, gx, blur_t, pair_counts=pc)
+        assert all(torch.equal(a, b) for a, b in zip(sh_ref, sh_got))
+        buf = torch.empty_like(img2)
+        scr = torch.empty(_lib_scratch(W, H), dtype=torch.uint8, device=DEV)
+        _, _, _, dxa = losses.event_loss_raw(img2, img2, nxt2, c, gi, gn, gx, blur_t, pair_counts=pc,
+                                             out=(torch.empty(8, device=DEV), buf, buf, torch.empty_like(img2), scr))
+        assert torch.equal(buf, sh_ref[2])                              # (separate outputs: d_now holds the same sum)
+        assert torch.equal(dxa, sh_ref[3])
+        # a ground-truth frame modified in place is a new pair
+        gx.mul_(0.5)
+        assert pc.lookup(gn, gx, 0.17) is None
+        ref3 = [t.clone() for t in losses.event_loss_raw(img, now, nxt, c, gi, gn, gx, blur_t)]
+        got3 = [t.clone() for t in losses.event_loss_raw(img, now, nxt, c, gi, gn, gx, blur_t, pair_counts=pc)]
+        got4 = losses.event_loss_raw(img, now, nxt, c, gi, gn, gx, blur_t, pair_counts=pc)
+        assert all(torch.equal(a, b) and torch.equal(a, e) for a, b, e in zip(ref3, got3, got4))
+
+
 def _lib_scratch(W, H):
     from event_3dgs_amd import _lib
     return _lib.lib().e3dgs_event_loss_scratch_bytes(W, H)
