@@ -59,6 +59,16 @@ def check_event(seed):
     ref = c_oracle.event_loss(img[0], img[1], img[2], gts[0], gts[1], gts[2], c, gt_blur=blur)
     s = scal.cpu().numpy()
     problems = []
+    # the one-sweep form (e3dgs_event_loss_cached) on the same pair: first call fills the pair's count, second call uses
+    # it; both must equal the three-launch form bit for bit
+    pc = losses.PairCounts()
+    ti, tg = [t(a) for a in img], [t(a) for a in gts]
+    tb = t(blur)
+    for rep in range(2):
+        got = losses.event_loss_raw(ti[0], ti[1], ti[2], cc, tg[0], tg[1], tg[2], gt_blur=tb, pair_counts=pc)
+        for name, a, b in zip(("scalars", "d_image", "d_now", "d_next"), got, (scal, d0, d1, d2)):
+            if not torch.equal(a, b):
+                problems.append("cached call %d: %s differs from the three-launch form" % (rep, name))
     rel = lambda a, b: abs(a - b) / max(abs(b), 1e-6)
     if rel(float(s[0]), ref["loss"]) > 2e-5:
         problems.append("loss %.7g vs %.7g" % (s[0], ref["loss"]))
