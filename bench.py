@@ -145,15 +145,21 @@ def main():
             dp_fallback = True
         else:
             warm = max(0, warm - 1)       # the probe step was the first warm-up step
-    for _ in range(warm):
-        loss = one_step()
-    torch.cuda.synchronize()
     # Python's cyclic garbage collector is kept out of the measurements (as timeit does): a generation-2 pass of this
     # process takes 30-60 ms -- measured: it landed inside a 20-step window in two runs of three and turned 2.0 ms per
     # step into 4 -- and nothing the iteration allocates needs it (no reference cycles; tensors are freed by refcount).
+    # Collected BEFORE the warm-up steps: between warm-up and timed region the GPU then idles only for the contract's
+    # barrier + synchronize.  A 30-60 ms pause there lets the clocks drop and the timed iterations pay the ramp: same-box
+    # A/B of a 20-step window (E3DGS_BENCH_GC_LATE=1 = collection between warm-up and timed region, as before round 4):
+    # 2.53-2.55 ms per step against 2.43-2.44, render_bwd_kernel 0.863 against 0.823 ms.
     import gc
     gc.collect()
     gc.disable()
+    for _ in range(warm):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if os.environ.get("E3DGS_BENCH_GC_LATE") == "1":      # (A/B hook: the old placement of the collection)
+        gc.enable(); gc.collect(); gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
