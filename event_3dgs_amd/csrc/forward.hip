@@ -894,6 +894,9 @@ __device__ __forceinline__ void strip_pretest(const float4 ra, const float4 rb, 
     }
 }
 
+#ifndef E3_FWD_ASM
+#define E3_FWD_ASM 1
+#endif
 #ifndef E3_FWD_GUARDS
 #define E3_FWD_GUARDS 1
 #endif
@@ -990,6 +993,8 @@ __device__ __forceinline__ void render_fwd_body(
         // composited nothing there.  Bit j of sm[k] (an SGPR pair per strip) = entry j of this round evaluated strip k:
         // one scalar bit-set per evaluated strip, and one byte per entry stored per round.
         unsigned long long sm[4] = {0ull, 0ull, 0ull, 0ull};
+        float exp_k1 = 0.009671698324382305f;       // second coefficient of exp_det's polynomial, in a VGPR for v_fmamk (asm strip)
+        asm volatile("" : "+v"(exp_k1));
         // 1-based list position of the entry, kept in a VECTOR register on purpose: the select that records a pixel's
         // last contributor needs it there, and a scalar copy is re-materialised with a v_mov in every live strip
         uint32_t contributor = (uint32_t)base;
@@ -1047,8 +1052,85 @@ __device__ __forceinline__ void render_fwd_body(
                 asm("s_andn2_b64 %0, %0, %2\n\ts_cselect_b64 %1, %1, 0" : "+s"(alive[k]), "+s"(gm[k]) : "s"(stop) : "scc");  \
             }                                                                                                               \
             skip##k:;
-            E3_FWD_STRIP(0) E3_FWD_STRIP(1) E3_FWD_STRIP(2) E3_FWD_STRIP(3)
+            // The same strip, instruction for instruction, as ONE asm block for the exact (polynomial exp) kernel.  The
+            // forward is bound by the CU's single scalar unit (bench.py: scalar_unit_frac 0.99; +2 dummy SALU per strip:
+            // +4.3 %), and hipcc cannot branch on the SCC an s_and / s_andn2 has just produced (it re-compares: s_and +
+            // s_cmp + s_cbranch; `asm goto` is dropped in device code).  Hand-placed branches take SCC directly and the
+            // common "no pixel of the strip stops here" case skips the stop bookkeeping: 7 scalar instructions per live
+            // strip instead of 12-13, 2 per skipped strip instead of 3: -2 % on the kernel.  The strip's instructions run
+            // with EXEC = alive[k] (the pixels that have finished are inactive lanes; results are the same -- their
+            // compares come out 0 -- and two more SALU instructions per strip buy another -2 %, measured: the kernel runs
+            // power-limited at ~1.8 GHz, and inactive lanes draw none).  Same VALU operations in the same order as the C
+            // form above (which stays as the tolerance-mode kernel's body and as the readable statement of the algorithm).
+#define E3_FWD_STRIP_ASM(k)                                                                                                 \
+            {                                                                                                               \
+                float t0_, t1_, t2_, t3_;                                                                                   \
+                unsigned long long s0_, s1_, s2_;                                                                           \
+                asm volatile(                                                                                               \
+                    "s_and_b64 %[s0], %[gm], %[jb]\n\t"                                                                     \
+                    "s_cbranch_scc0 .Lskip_%=\n\t"                                                                          \
+                    "s_mov_b64 exec, %[al]\n\t"                     /* pixels that have finished: out of EXEC (below) */   \
+                    "v_sub_f32 %[t0], %[ay], %[pfy]\n\t"              /* dy */                                               \
+                    "v_mul_f32 %[t1], %[bx], %[t0]\n\t"                                                                     \
+                    "v_fma_f32 %[t1], %[t1], %[t0], %[qx]\n\t"        /* q = fma(b.x dy, dy, qx) */                          \
+                    "v_mul_f32 %[t2], %[cydx], %[t0]\n\t"                                                                   \
+                    "v_fma_f32 %[t2], -0.5, %[t1], -%[t2]\n\t"        /* power = fma(-0.5, q, -(cydx dy)) */                 \
+                    "v_mul_f32 %[t1], 0x3fb8aa3b, %[t2]\n\t"          /* exp_det_noclamp(power): t = power log2 e */         \
+                    "v_rndne_f32 %[t0], %[t1]\n\t"                                                                          \
+                    "v_sub_f32 %[t1], %[t1], %[t0]\n\t"                                                                     \
+                    "v_fmamk_f32 %[t3], %[t1], 0x3aad4281, %[k1]\n\t"                                                       \
+                    "v_fmaak_f32 %[t3], %[t3], %[t1], 0x3d635d55\n\t"                                                       \
+                    "v_cvt_i32_f32 %[t0], %[t0]\n\t"                                                                        \
+                    "v_fmaak_f32 %[t3], %[t3], %[t1], 0x3e75fcdb\n\t"                                                       \
+                    "v_fmaak_f32 %[t3], %[t3], %[t1], 0x3f317213\n\t"                                                       \
+                    "v_fma_f32 %[t3], %[t3], %[t1], 1.0\n\t"                                                                \
+                    "v_ldexp_f32 %[t3], %[t3], %[t0]\n\t"             /* G */                                                \
+                    "v_mul_f32 %[t3], %[by], %[t3]\n\t"               /* alpha = o G */                                      \
+                    "s_and_b64 %[s0], %[um], %[jb]\n\t"               /* guards only for the entries that need them */      \
+                    "s_cbranch_scc0 .Lsafe_%=\n\t"                                                                          \
+                    "v_cmp_nlt_f32 vcc, 0, %[t2]\n\t"                 /* !(power > 0) */                                     \
+                    "s_and_b64 %[s1], vcc, %[al]\n\t"                                                                       \
+                    "v_max_f32 %[t3], %[t3], %[t3]\n\t"                                                                     \
+                    "v_min_f32 %[t3], 0x3f7d70a4, %[t3]\n\t"          /* min(0.99, alpha) */                                 \
+                    "v_cmp_ngt_f32 vcc, 0x3b808081, %[t3]\n\t"        /* !(alpha < 1/255) */                                 \
+                    "s_and_b64 %[s1], %[s1], vcc\n\t"                                                                       \
+                    "s_branch .Ljoin_%=\n"                                                                                  \
+                    ".Lsafe_%=:\n\t"                                                                                        \
+                    "v_cmp_ngt_f32 vcc, 0x3b808081, %[t3]\n\t"                                                              \
+                    "s_and_b64 %[s1], vcc, %[al]\n"                   /* valid; SCC = valid != 0 */                          \
+                    ".Ljoin_%=:\n\t"                                                                                        \
+                    "s_cselect_b64 %[s0], %[jb], 0\n\t"               /* strip-mask bit if no pixel stops below */           \
+                    "v_mul_f32 %[t0], %[T], %[t3]\n\t"                /* w = alpha T */                                      \
+                    "v_sub_f32 %[t1], %[T], %[t0]\n\t"                /* test_T */                                           \
+                    "v_cmp_gt_f32 vcc, 0x38d1b717, %[t1]\n\t"         /* test_T < 1e-4 */                                    \
+                    "s_and_b64 %[s2], vcc, %[s1]\n\t"                 /* stop; SCC = stop != 0 */                            \
+                    "s_cbranch_scc0 .Lnostop_%=\n\t"                                                                        \
+                    "s_andn2_b64 %[s1], %[s1], %[s2]\n\t"             /* app = valid & ~stop */                              \
+                    "s_cselect_b64 %[s0], %[jb], 0\n\t"                                                                     \
+                    "s_andn2_b64 %[al], %[al], %[s2]\n\t"             /* alive &= ~stop */                                   \
+                    "s_cselect_b64 %[gm], %[gm], 0\n"                 /* strip finished: no entry evaluates it again */     \
+                    ".Lnostop_%=:\n\t"                                                                                      \
+                    "s_or_b64 %[sm], %[sm], %[s0]\n\t"                                                                      \
+                    "v_cndmask_b32_e64 %[t0], 0, %[t0], %[s1]\n\t"    /* we = app ? w : 0 */                                 \
+                    "v_fmac_f32 %[c0], %[bz], %[t0]\n\t"                                                                    \
+                    "v_fmac_f32 %[c1], %[bw], %[t0]\n\t"                                                                    \
+                    "v_fmac_f32 %[c2], %[cx], %[t0]\n\t"                                                                    \
+                    "v_cndmask_b32_e64 %[la], %[la], %[co], %[s1]\n\t"                                                      \
+                    "v_sub_f32 %[T], %[T], %[t0]\n\t"                                                                      \
+                    "s_mov_b64 exec, -1\n"                                                                                  \
+                    ".Lskip_%=:"                                                                                            \
+                    : [gm] "+s"(gm[k]), [al] "+s"(alive[k]), [sm] "+s"(sm[k]), [T] "+v"(T[k]), [c0] "+v"(C0[k]),            \
+                      [c1] "+v"(C1[k]), [c2] "+v"(C2[k]), [la] "+v"(last[k]), [t0] "=&v"(t0_), [t1] "=&v"(t1_),             \
+                      [t2] "=&v"(t2_), [t3] "=&v"(t3_), [s0] "=&s"(s0_), [s1] "=&s"(s1_), [s2] "=&s"(s2_)                   \
+                    : [ay] "v"(a.y), [pfy] "v"(pfy[k]), [bx] "v"(b.x), [qx] "v"(qx), [cydx] "v"(cydx), [by] "v"(b.y),       \
+                      [bz] "v"(b.z), [bw] "v"(b.w), [cx] "v"(c_x), [co] "v"(contributor), [k1] "v"(exp_k1),                 \
+                      [jb] "s"(jbit), [um] "s"(um)                                                                          \
+                    : "vcc", "scc");                                                                                        \
+            }
+            if (!FAST && E3_FWD_ASM) { E3_FWD_STRIP_ASM(0) E3_FWD_STRIP_ASM(1) E3_FWD_STRIP_ASM(2) E3_FWD_STRIP_ASM(3) }
+            else { E3_FWD_STRIP(0) E3_FWD_STRIP(1) E3_FWD_STRIP(2) E3_FWD_STRIP(3) }
 #undef E3_FWD_STRIP
+#undef E3_FWD_STRIP_ASM
             jbit <<= 1;
         };
         // two entries per trip: halves the loop bookkeeping (counter, LDS address, branch) of an issue-bound loop
