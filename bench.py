@@ -118,7 +118,9 @@ def main():
     trainer = EventTrainer(params, dev)
 
     def one_step():
-        return trainer.step(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+        # (step_nocopy: the returned scalars are a view of one of two alternating blocks -- valid until the step after the
+        # next one, and read once after the loops; step() would add a copy kernel per iteration for a value nobody reads)
+        return trainer.step_nocopy(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
 
     # Several ranks: the overlapped / factorised gradient exchange has only ever run over gloo (the development boxes
     # have one GPU).  If its first step raises on this backend, every rank falls back to the plain schedule (one
@@ -165,11 +167,15 @@ def main():
     torch.cuda.synchronize()
     # inside the timed region only the dominant kernel (slot 6, render_bwd_kernel) is bracketed with HIP events:
     # every timed slot costs two event packets per launch on the queue
+    # ... and only on every fourth timed iteration: the two event packets around the launch leave the GPU idle for ~6 us
+    # each (kernel trace: the only two gaps of an iteration), i.e. bracketing every launch costs the iteration 0.5 %
     DOMINANT_SLOT = 6
-    L.e3dgs_profile_enable(1 << DOMINANT_SLOT)
+    EVENT_EVERY = max(1, int(os.environ.get("E3DGS_BENCH_EVENT_EVERY", "4")))
+    L.e3dgs_profile_enable(1 << DOMINANT_SLOT)          # (resets the counters)
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it_ in range(args.steps):
+        L.e3dgs_profile_select((1 << DOMINANT_SLOT) if it_ % EVENT_EVERY == 0 else 0)
         loss = one_step()
     torch.cuda.synchronize()
     if world > 1:

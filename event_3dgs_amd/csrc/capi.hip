@@ -652,6 +652,11 @@ void e3dgs_profile_enable(int slot_mask) {
     g_prof_on = slot_mask != 0;
     if (g_ps) for (int i = 0; i < PS_COUNT; ++i) { g_ps->used[i] = 0; g_ps->open[i] = false; }
 }
+void e3dgs_profile_select(int slot_mask) {
+    if (slot_mask != 0 && !g_ps) g_ps = new ProfState();
+    g_prof_mask = (unsigned)slot_mask;
+    g_prof_on = slot_mask != 0;
+}
 int e3dgs_profile_query(int slot, double* total_ms, int* launches) {
     if (slot < 0 || slot >= PS_COUNT) return -1;
     double t = 0.0;

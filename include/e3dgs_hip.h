@@ -596,8 +596,11 @@ int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys
  * the kernel it reports inside its timed region); query() synchronises the recorded events and returns the
  * accumulated milliseconds and the number of launches.  The profiler's state belongs to the CALLING HOST THREAD: enable,
  * the calls to be timed and query are made from one thread; calls of other threads are never timed and never race.
+ * select(mask) changes the set of timed slots WITHOUT resetting what has been recorded (a benchmark that brackets its
+ * kernel on every n-th iteration only: the two event packets cost the launch ~6 us of GPU idle each).
  */
 void e3dgs_profile_enable(int slot_mask);
+void e3dgs_profile_select(int slot_mask);
 int e3dgs_profile_query(int slot, double* total_ms, int* launches);
 const char* e3dgs_profile_slot_name(int slot);
 
