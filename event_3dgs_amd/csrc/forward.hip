@@ -365,10 +365,16 @@ struct BinTables {
     float4 A[WAVE];       // x, y, conic.x, conic.y
     float4 B[WAVE];       // conic.z, thr, xmin|ymin<<16, width
     float4 D[WAVE];       // -B/C, -B/A, 1/width, first tile id of the splat's view
-    uint32_t incl[WAVE];  // inclusive scan of the candidate counts
+    uint32_t excl[WAVE];  // exclusive scan of the candidate counts (first candidate item of the splat)
     uint32_t id[WAVE];    // splat ids
     uint32_t cnt[WAVE];   // kept instances per splat (emission)
+    uint32_t flag[WAVE];  // candidate walk: "a splat starts at this item of the round"
 };
+// The tables hold only the splats WITH candidates, in order (rank r = position among them): the walk finds the splat of
+// candidate item m as "number of splats that start at or before m", from start flags + a ballot, instead of a 6-step
+// binary search through LDS (6 dependent LDS round trips per 64 items: what bounded the walk).  WalkLane: what a lane
+// keeps of ITS splat for that (rank, first item, number of ranked splats).
+struct WalkLane { uint32_t rank, excl, nnz; bool nonempty; };
 
 // Gathers the records of the wave's splats (depth-sorted positions s of `order`), derives the candidate rectangles and
 // fills the wave's tables.  Returns the number of candidate (splat, tile) items of the wave (wave-uniform).
@@ -380,7 +386,7 @@ template <int MODE>
 __device__ __forceinline__ uint32_t bin_load_tables(BinTables& T, int lane, bool mine, int s, int nviews, int ntiles,
                                                     const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
                                                     int packed_rect, const float4* __restrict__ rec, int cull,
-                                                    float4* __restrict__ binrec) {
+                                                    float4* __restrict__ binrec, WalkLane& wl) {
     uint32_t n = 0, g = 0;
     float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
     if (MODE == 2) {
@@ -462,14 +468,16 @@ __device__ __forceinline__ uint32_t bin_load_tables(BinTables& T, int lane, bool
     }
     // (made scalar explicitly: a trip count that sits in a VGPR makes the candidate loop a divergent loop)
     const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
-    T.A[lane] = a; T.B[lane] = b; T.incl[lane] = incl; T.id[lane] = g;
-    {
+    const unsigned long long nzmask = __ballot(n != 0u);
+    const uint32_t r = (uint32_t)__popcll(nzmask & ((1ull << lane) - 1ull));
+    wl.rank = r; wl.excl = incl - n; wl.nnz = (uint32_t)__popcll(nzmask); wl.nonempty = n != 0u;
+    T.cnt[lane] = 0;
+    if (n != 0u) {
         const uint32_t tbase = nviews > 1 ? (g % (uint32_t)nviews) * (uint32_t)ntiles : 0u;
         const float fw = (float)__float_as_uint(b.w);
-        T.D[lane] = n ? make_float4(-a.w / b.x, -a.w / a.z, 1.0f / fw, __uint_as_float(tbase))
-                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        T.A[r] = a; T.B[r] = b; T.excl[r] = incl - n; T.id[r] = g;
+        T.D[r] = make_float4(-a.w / b.x, -a.w / a.z, 1.0f / fw, __uint_as_float(tbase));
     }
-    T.cnt[lane] = 0;
     wave_sync();
     return total;
 }
@@ -480,23 +488,30 @@ __device__ __forceinline__ uint32_t bin_load_tables(BinTables& T, int lane, bool
 // rectangle -- exactly the order the reference's per-Gaussian loop produces, so a stable sort on the tile id alone
 // finishes the job.  Returns the number of kept items (wave-uniform).
 template <bool EMIT>
-__device__ __forceinline__ uint32_t bin_walk(BinTables& T, int lane, uint32_t total, int gx, int cull, uint32_t out_base,
-                                             void* __restrict__ keys, int keys16, uint32_t* __restrict__ emit_gid,
-                                             uint8_t* __restrict__ touched) {
+__device__ __forceinline__ uint32_t bin_walk(BinTables& T, const WalkLane& wl, int lane, uint32_t total, int gx, int cull,
+                                             uint32_t out_base, void* __restrict__ keys, int keys16,
+                                             uint32_t* __restrict__ emit_gid, uint8_t* __restrict__ touched) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint64_t le_mask = lt_mask | (1ull << lane);
     uint32_t count = 0;
+    uint32_t started = 0;                       // (scalar) ranked splats whose first item lies before this round
     for (uint32_t m0 = 0; m0 < total; m0 += WAVE) {
         const uint32_t m = m0 + lane;
         const bool active = m < total;
-        // smallest j with incl[j] > m
-        int lo = 0, hi = 63;
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            int mid = (lo + hi) >> 1;
-            if (T.incl[mid] > m) hi = mid; else lo = mid + 1;
+        // the splat of item m = (number of ranked splats that start at or before m) - 1: lane r flags the item its splat
+        // starts at when that item belongs to this round; one ballot of the flags, one popcount per lane.  (DS operations
+        // of a wave retire in order: clear, set and read need no waits in between.)
+        T.flag[lane] = 0u;
+        wave_sync();
+        {
+            const uint32_t p = wl.excl - m0;    // (unsigned: a start before the round wraps to a large number)
+            if (wl.nonempty && p < (uint32_t)WAVE) T.flag[p] = 1u;
         }
-        const int j = lo;
-        const uint32_t excl = j ? T.incl[j - 1] : 0u;
+        wave_sync();
+        const unsigned long long starts = __ballot(T.flag[lane] != 0u);
+        const int j = (int)(started + (uint32_t)__popcll(starts & le_mask)) - 1;
+        started += (uint32_t)__popcll(starts);
+        const uint32_t excl = T.excl[j];
         const float4 A4 = T.A[j], B4 = T.B[j], D4 = T.D[j];
         const uint32_t k = m - excl, w = __float_as_uint(B4.w), xy0 = __float_as_uint(B4.z);
         uint32_t row = (uint32_t)(((float)k + 0.5f) * D4.z);       // w, k < 2^24: exact after the fix-up
@@ -523,10 +538,10 @@ __device__ __forceinline__ uint32_t bin_walk(BinTables& T, int lane, uint32_t to
 }
 
 // run of each splat of the wave, stored at its DEPTH-SORTED position: (first slot, kept instances)
-__device__ __forceinline__ void bin_store_runs(BinTables& T, int lane, bool mine, int s, uint32_t out_base,
-                                               uint2* __restrict__ run_sorted) {
+__device__ __forceinline__ void bin_store_runs(BinTables& T, const WalkLane& wl, int lane, bool mine, int s,
+                                               uint32_t out_base, uint2* __restrict__ run_sorted) {
     wave_sync();
-    const uint32_t c = T.cnt[lane];
+    const uint32_t c = wl.nonempty ? T.cnt[wl.rank] : 0u;      // (the tables are indexed by rank)
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -572,14 +587,15 @@ __global__ __launch_bounds__(BIN_WAVES * WAVE) void bin_kernel(int P, int gshift
     const bool mine = lane < (1 << gshift) && s < nv;
     BinTables& T = tabs[wave];
     uint32_t total;
-    if (!binrec) total = bin_load_tables<0>(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull, nullptr);
-    else total = bin_load_tables<EMIT ? 2 : 1>(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull, binrec);
+    WalkLane wl;
+    if (!binrec) total = bin_load_tables<0>(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull, nullptr, wl);
+    else total = bin_load_tables<EMIT ? 2 : 1>(T, lane, mine, s, nviews, ntiles, order, rect, packed_rect, rec, cull, binrec, wl);
     const uint32_t out_base = EMIT ? __builtin_amdgcn_readfirstlane(wave_offsets[gw]) : 0u;
-    const uint32_t count = bin_walk<EMIT>(T, lane, total, gx, cull, out_base, keys, keys16, emit_gid, touched);
+    const uint32_t count = bin_walk<EMIT>(T, wl, lane, total, gx, cull, out_base, keys, keys16, emit_gid, touched);
     if (!EMIT) {
         if (lane == 0) wave_counts[gw] = count;
     } else {
-        bin_store_runs(T, lane, mine, s, out_base, run_sorted);
+        bin_store_runs(T, wl, lane, mine, s, out_base, run_sorted);
     }
 }
 
