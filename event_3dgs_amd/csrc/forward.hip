@@ -1078,6 +1078,8 @@ __device__ __forceinline__ void render_fwd_body(
             // compares come out 0 -- and two more SALU instructions per strip buy another -2 %, measured: the kernel runs
             // power-limited at ~1.8 GHz, and inactive lanes draw none).  Same VALU operations in the same order as the C
             // form above (which stays as the tolerance-mode kernel's body and as the readable statement of the algorithm).
+            // (EXEC is all ones on entry -- the entry loop runs in wave-uniform control flow, every lane of the 128-thread
+            // workgroup alive -- and the block leaves it all ones.)
 #define E3_FWD_STRIP_ASM(k)                                                                                                 \
             {                                                                                                               \
                 float t0_, t1_, t2_, t3_;                                                                                   \
