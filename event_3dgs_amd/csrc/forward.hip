@@ -1129,12 +1129,12 @@ __device__ __forceinline__ void render_fwd_body(
                     "s_cselect_b64 %[gm], %[gm], 0\n"                 /* strip finished: no entry evaluates it again */     \
                     ".Lnostop_%=:\n\t"                                                                                      \
                     "s_or_b64 %[sm], %[sm], %[s0]\n\t"                                                                      \
-                    "v_cndmask_b32_e64 %[t0], 0, %[t0], %[s1]\n\t"    /* we = app ? w : 0 */                                 \
-                    "v_fmac_f32 %[c0], %[bz], %[t0]\n\t"                                                                    \
-                    "v_fmac_f32 %[c1], %[bw], %[t0]\n\t"                                                                    \
-                    "v_fmac_f32 %[c2], %[cx], %[t0]\n\t"                                                                    \
-                    "v_cndmask_b32_e64 %[la], %[la], %[co], %[s1]\n\t"                                                      \
-                    "v_sub_f32 %[T], %[T], %[t0]\n\t"                                                                      \
+                    "s_mov_b64 exec, %[s1]\n\t"                       /* the five updates on the pixels the entry is */     \
+                    "v_fmac_f32 %[c0], %[bz], %[t0]\n\t"              /* composited on: plain full-rate instructions */     \
+                    "v_fmac_f32 %[c1], %[bw], %[t0]\n\t"              /* under EXEC = app instead of two v_cndmask   */     \
+                    "v_fmac_f32 %[c2], %[cx], %[t0]\n\t"              /* selects (-1.7 % on the kernel)               */     \
+                    "v_mov_b32 %[la], %[co]\n\t"                                                                            \
+                    "v_mov_b32 %[T], %[t1]\n\t"                       /* T - w (= test_T) */                                \
                     "s_mov_b64 exec, -1\n"                                                                                  \
                     ".Lskip_%=:"                                                                                            \
                     : [gm] "+s"(gm[k]), [al] "+s"(alive[k]), [sm] "+s"(sm[k]), [T] "+v"(T[k]), [c0] "+v"(C0[k]),            \
