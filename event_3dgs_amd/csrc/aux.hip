@@ -657,13 +657,15 @@ int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float l
 // learning rate and eps (xyz | f_dc | f_rest | opacity | scaling | rotation | c).  Same arithmetic as adam_kernel.
 constexpr int ADAM_MAX_SEG = 8;
 struct AdamSegs { size_t end[ADAM_MAX_SEG]; float step_size[ADAM_MAX_SEG]; float eps[ADAM_MAX_SEG];
-                  float bc2_sqrt[ADAM_MAX_SEG]; int n; unsigned skip; };
+                  float bc2_sqrt[ADAM_MAX_SEG]; int n; unsigned skip;
+                  size_t gap_begin, gap_len; };   // elements [gap_begin, gap_begin + gap_len) belong to nobody (no thread visits them)
 __global__ __launch_bounds__(256) void adam_segments_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, AdamSegs sg,
                                                             float b1, float b2) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
+    for (; t < n - sg.gap_len; t += stride) {
+        const size_t i = t >= sg.gap_begin ? t + sg.gap_len : t;      // (the launch covers the elements outside the gap only)
         int k = 0;
 #pragma unroll
         for (int j = 0; j < ADAM_MAX_SEG - 1; ++j) k += (j < sg.n - 1 && i >= sg.end[j]) ? 1 : 0;
@@ -678,10 +680,15 @@ __global__ __launch_bounds__(256) void adam_segments_kernel(size_t n, float* __r
 }
 // steps[k]: the 1-based Adam step of segment k (torch keeps one `step` per parameter; groups that were skipped on some
 // iterations lag behind), <= 0: skip the segment (parameter and moments untouched).  steps == NULL: `step` for all.
+// gap_len > 0: the elements [gap_begin, gap_begin + gap_len) are left alone AND cost nothing -- the launch is sized for the
+// rest (a skipped segment still costs its grid-stride iterations).  The trainer's buffer is xyz | SH | opacity | scaling |
+// rotation | c with the SH coefficients updated by their own kernel: one launch for everything around them.
 int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v, int nseg, const size_t* seg_end,
                           const float* lr, const float* eps, float b1, float b2, int step, const int* steps,
-                          hipStream_t s) {
+                          hipStream_t s, size_t gap_begin, size_t gap_len) {
     if (n == 0) return 0;
+    if (gap_len > n || gap_begin > n - gap_len) return e3_fail(hipErrorInvalidValue, "the gap must lie inside the buffer");
+    if (gap_len == n) return 0;
     if (nseg < 1 || nseg > ADAM_MAX_SEG) return e3_fail(hipErrorInvalidValue, "1..8 segments");
     AdamSegs sg;
     sg.skip = 0u;
@@ -698,7 +705,8 @@ int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v
     }
     if (seg_end[nseg - 1] != n) return e3_fail(hipErrorInvalidValue, "last segment must end at n");
     sg.n = nseg;
-    size_t nb = (n + 255) / 256;
+    sg.gap_begin = gap_begin; sg.gap_len = gap_len;
+    size_t nb = (n - gap_len + 255) / 256;
     if (nb > 65536) nb = 65536;      // measured at 59 M floats: 8192 -> 4.8 TB/s, 65536 -> 5.85 TB/s, no cap 5.7
     adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, sg, b1, b2);
     hipError_t e = hipGetLastError();

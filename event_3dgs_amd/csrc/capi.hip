@@ -79,7 +79,7 @@ int e3_event_loss_impl(int, int, const float*, const float*, const float*, const
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_segments_impl(size_t, float*, const float*, float*, float*, int, const size_t*, const float*, const float*, float,
-                          float, int, const int*, hipStream_t);
+                          float, int, const int*, hipStream_t, size_t gap_begin = 0, size_t gap_len = 0);
 int e3_densify_stats_impl(int, const float*, const int*, float*, float*, float*, hipStream_t);
 size_t e3_image_loss_scratch_bytes(int, int, int);
 int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t);
@@ -94,7 +94,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 14; }
+int e3dgs_abi_version(void) { return 15; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -559,6 +559,15 @@ int e3dgs_adam_step_groups(size_t n, float* param, const float* grad, float* exp
     if (!seg_end || !lr || !eps || !steps) return e3_fail(hipErrorInvalidValue, "segment tables are required");
     return e3_adam_segments_impl(n, param, grad, exp_avg, exp_avg_sq, nseg, seg_end, lr, eps, beta1, beta2, 0, steps,
                                  (hipStream_t)stream);
+}
+
+int e3dgs_adam_step_groups_gap(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int nseg,
+                               const size_t* seg_end, const float* lr, const float* eps, float beta1, float beta2,
+                               const int* steps, size_t gap_begin, size_t gap_len, void* stream) {
+    g_err[0] = 0;
+    if (!seg_end || !lr || !eps || !steps) return e3_fail(hipErrorInvalidValue, "segment tables are required");
+    return e3_adam_segments_impl(n, param, grad, exp_avg, exp_avg_sq, nseg, seg_end, lr, eps, beta1, beta2, 0, steps,
+                                 (hipStream_t)stream, gap_begin, gap_len);
 }
 
 int e3dgs_densify_stats_update(int P, const float* viewspace_grad, const int* radii, float* max_radii2D,

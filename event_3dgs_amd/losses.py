@@ -134,11 +134,12 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.99
     _lib.check(rc, "e3dgs_adam_step")
 
 
-def adam_step_segments_(param, grad, exp_avg, exp_avg_sq, seg_end, lrs, eps, step, beta1=0.9, beta2=0.999):
+def adam_step_segments_(param, grad, exp_avg, exp_avg_sq, seg_end, lrs, eps, step, beta1=0.9, beta2=0.999, gap=None):
     """In-place fused Adam over consecutive segments of one flat fp32 tensor, each with its own learning rate and eps, in
     one launch.  seg_end: ascending element offsets, the last one == param.numel().  `step`: one int for all segments
     (e3dgs_adam_step_segments) or one per segment, <= 0 = leave that segment untouched (e3dgs_adam_step_groups: torch's
-    per-parameter step counts and its skipping of parameters without a gradient)."""
+    per-parameter step counts and its skipping of parameters without a gradient).  gap = (begin, length): elements the
+    launch does not visit at all (e3dgs_adam_step_groups_gap; needs one step count per segment)."""
     import ctypes as C
     for t in (param, grad, exp_avg, exp_avg_sq):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
@@ -151,7 +152,13 @@ def adam_step_segments_(param, grad, exp_avg, exp_avg_sq, seg_end, lrs, eps, ste
         if isinstance(step, (tuple, list)):
             if len(step) != k:
                 raise ValueError("one step count per segment")
-            rc = _lib.lib().e3dgs_adam_step_groups(*common, (C.c_int * k)(*[int(x) for x in step]), _lib.current_stream())
+            steps = (C.c_int * k)(*[int(x) for x in step])
+            if gap is not None:
+                rc = _lib.lib().e3dgs_adam_step_groups_gap(*common, steps, int(gap[0]), int(gap[1]), _lib.current_stream())
+            else:
+                rc = _lib.lib().e3dgs_adam_step_groups(*common, steps, _lib.current_stream())
+        elif gap is not None:
+            raise ValueError("a gap needs one step count per segment")
         else:
             rc = _lib.lib().e3dgs_adam_step_segments(*common, int(step), _lib.current_stream())
     _lib.check(rc, "e3dgs_adam_step_segments")

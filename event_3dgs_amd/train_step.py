@@ -884,14 +884,22 @@ class EventTrainer:
                                        self.exp_avg[f_off:f_off + f_n], self.exp_avg_sq[f_off:f_off + f_n],
                                        self.lrs["features"], self.lrs["features_rest"], st["gauss"])
         self._packed_views = 0
-        sl = slice(0, f_off)                                     # xyz
+        g, o, c = st["gauss"], st["opacity"], st["c"]
+        if os.environ.get("E3DGS_ADAM_GAP", "1") != "0":
+            # everything around the SH segment in ONE launch (the segment is a gap the launch does not visit): xyz, then
+            # opacity | scaling | rotation | c
+            ends = (f_off + f_n,) + tuple(sum(self.seg[n]) for n in ("opacity", "scaling", "rotation", "c"))
+            lrs = (self.xyz_lr(it), self.lrs["opacity"], self.lrs["scaling"], self.lrs["rotation"], self.c_lr)
+            losses.adam_step_segments_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, ends, lrs,
+                                       (1e-15,) * 4 + (1e-8,), (g, o, g, g, c), gap=(f_off, f_n))
+            return
+        sl = slice(0, f_off)                                     # xyz (A/B switch: one launch per contiguous range)
         losses.adam_step_segments_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], (f_off,),
                                    (self.xyz_lr(it),), (1e-15,), st["gauss"])
         t0 = f_off + f_n                                         # opacity | scaling | rotation | c
         sl = slice(t0, self.flat.numel())
         ends = tuple(sum(self.seg[n]) - t0 for n in ("opacity", "scaling", "rotation", "c"))
         lrs = (self.lrs["opacity"], self.lrs["scaling"], self.lrs["rotation"], self.c_lr)
-        g, o, c = st["gauss"], st["opacity"], st["c"]
         losses.adam_step_segments_(self.flat[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], ends, lrs,
                                    (1e-15,) * 3 + (1e-8,), (o, g, g, c))
 

@@ -542,6 +542,18 @@ int e3dgs_adam_step_groups(size_t n, float* param, const float* grad, float* exp
                            const int* steps, void* stream);
 
 /*
+ * As e3dgs_adam_step_groups, with a GAP: the elements [gap_begin, gap_begin + gap_len) of the buffer are not visited at all
+ * (a skipped segment still costs its grid-stride iterations; the gap costs nothing -- the launch is sized for the n -
+ * gap_len elements around it).  The trainer's flat buffer is xyz | SH | opacity | scaling | rotation | c and its SH
+ * coefficients are stepped by e3dgs_sh_adam_from_colour: everything around them (scene/gaussian_model.py:154-163 groups
+ * xyz, opacity, scaling, rotation + train.py:71-73 `c`) is ONE launch instead of one per contiguous range.  seg_end are
+ * offsets in the WHOLE buffer (segments may contain the gap).  Same arithmetic per element: bit-identical.
+ */
+int e3dgs_adam_step_groups_gap(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int nseg,
+                               const size_t* seg_end, const float* lr, const float* eps, float beta1, float beta2,
+                               const int* steps, size_t gap_begin, size_t gap_len, void* stream);
+
+/*
  * Adaptive density control on the device: GaussianModel.densify_and_prune (scene/gaussian_model.py:389-403 = clone
  * :374-387 + split :349-372 + prune :273-305,396-402; schedule train.py:317-327) as ONE plan pass and ONE apply pass over
  * the flat training buffers -- parameters and both Adam moments compacted together, clones and split children appended

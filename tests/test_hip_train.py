@@ -669,6 +669,34 @@ def test_segmented_adam_equals_per_group_adam():
         losses.adam_step_segments_(a[0], grad, a[1], a[2], ends[:-1], lrs[:-1], eps[:-1], 1)
 
 
+def test_adam_with_a_gap_equals_one_launch_per_range():
+    """e3dgs_adam_step_groups_gap (everything around the SH segment in one launch, per-group step counts, the gap never
+    visited) == one e3dgs_adam_step_groups launch per contiguous range, bit for bit; the gap stays untouched."""
+    from event_3dgs_amd import _lib, losses
+    g = torch.Generator().manual_seed(4)
+    n = 120_001
+    gap = (3000, 96_000)                                    # xyz | [SH] | opacity | scaling | rotation | c
+    ends = (99_000, 100_000, 103_000, 120_000, 120_001)
+    lrs = (1.6e-4, 0.05, 5e-3, 1e-3, 0.1)
+    eps = (1e-15,) * 4 + (1e-8,)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-3
+    a = [t.clone().to(DEV) for t in (p0, torch.rand(n, generator=g), torch.rand(n, generator=g))]
+    b = [t.clone() for t in a]
+    grad = gr.to(DEV)
+    t0 = gap[0] + gap[1]
+    for steps in ((1, 1, 1, 1, 1), (2, 0, 2, 2, 2), (3, 1, 3, 3, 0)):
+        losses.adam_step_segments_(a[0], grad, a[1], a[2], ends, lrs, eps, steps, gap=gap)
+        losses.adam_step_segments_(b[0][:gap[0]], grad[:gap[0]], b[1][:gap[0]], b[2][:gap[0]], (gap[0],), lrs[:1], eps[:1],
+                                   steps[:1])
+        losses.adam_step_segments_(b[0][t0:], grad[t0:], b[1][t0:], b[2][t0:], tuple(e - t0 for e in ends[1:]), lrs[1:],
+                                   eps[1:], steps[1:])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(a[0][gap[0]:t0].cpu(), p0[gap[0]:t0])
+    with pytest.raises(_lib.HipLibraryError, match="gap"):
+        losses.adam_step_segments_(a[0], grad, a[1], a[2], ends, lrs, eps, (1,) * 5, gap=(n - 5, 10))
+
+
 def test_event_mask_on_quantised_ground_truth_matches_torch():
     """rho = count(D* != 0) and sign(D - D*) hinge on exact zeros: on 8-bit ground-truth frames the kernel's mask must be
     the torch formula's (utils/loss_utils.py:234-249 + train.py:165-175), pixel for pixel in the count."""
