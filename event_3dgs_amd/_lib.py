@@ -84,6 +84,8 @@ def lib():
     L.e3dgs_sh_adam_from_colour.restype = C.c_int
     L.e3dgs_sh_adam_from_colour.argtypes = ([C.c_int] * 5 + [_fp, _fp, C.c_size_t, C.c_float, _fp, _fp, _fp]
                                             + [C.c_float] * 5 + [C.c_int, C.c_int, _vp])
+    L.e3dgs_sh_adam_from_colour_mean.restype = C.c_int
+    L.e3dgs_sh_adam_from_colour_mean.argtypes = L.e3dgs_sh_adam_from_colour.argtypes[:-1] + [_fp, _vp]
     L.e3dgs_set_tile_cull.restype = None
     L.e3dgs_set_tile_cull.argtypes = [C.c_int]
     L.e3dgs_get_tile_cull.restype = C.c_int
@@ -183,6 +185,7 @@ FLAG_BWD_ONLY_GEOM = 16
 FLAG_COUNT_MAPPED = 64
 FLAG_DEFER_COLOR = 128
 FLAG_COUNT_DEVICE = 256
+FLAG_DEFER_SH_MEAN = 512
 # per-call options (include/e3dgs_hip.h): with FLAG_OPTIONS the bits describe the call and no process-wide default is read
 FLAG_OPTIONS = 0x0800
 FLAG_CULL_RECT = 0x1000
@@ -215,7 +218,7 @@ EXPORTED_SYMBOLS = [
     "e3dgs_abi_version", "e3dgs_last_error", "e3dgs_rasterize_forward", "e3dgs_rasterize_forward_begin", "e3dgs_rasterize_forward_finish",
     "e3dgs_rasterize_backward", "e3dgs_rasterize_forward_multi", "e3dgs_rasterize_forward_multi_begin",
     "e3dgs_rasterize_forward_multi_finish", "e3dgs_rasterize_forward_multi_finish_colour", "e3dgs_rasterize_backward_multi", "e3dgs_rasterize_backward_multi_stats",
-    "e3dgs_sh_grad_from_colour", "e3dgs_sh_adam_from_colour",
+    "e3dgs_sh_grad_from_colour", "e3dgs_sh_adam_from_colour", "e3dgs_sh_adam_from_colour_mean",
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offsets_multi", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_event_loss_cached", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step_groups_gap", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_select", "e3dgs_profile_query", "e3dgs_profile_slot_name",
     "e3dgs_sort_scratch_bytes", "e3dgs_sort_pairs", "e3dgs_rasterize_forward_multi_capacity",

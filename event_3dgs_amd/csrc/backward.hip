@@ -893,7 +893,12 @@ __device__ __forceinline__ void sh_basis(int k, float x, float y, float z, float
     }
 }
 
-__global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
+// DEFER: E3_FLAG_DEFER_SH_MEAN without dL_dsh -- no SH part at all (fewer registers, no LDS slice)
+#ifndef E3_GEOM_DEFER_OCC
+#define E3_GEOM_DEFER_OCC 4
+#endif
+template <bool DEFER>
+__global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_multi_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
     MultiViews mv, int flags, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
@@ -902,7 +907,7 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
     // per-view (unit direction, 1/len, masked colour gradient) of this thread's Gaussian.  The view loop of the
     // geometry part is NOT unrolled (one copy of a ~90-register body); its per-view results go through this
     // LDS slice so that the SH part can hold them in statically indexed registers.
-    __shared__ float sV[7][E3_MAX_VIEWS][256];
+    __shared__ float sV[DEFER ? 1 : 7][DEFER ? 1 : E3_MAX_VIEWS][DEFER ? 1 : 256];
     const int tid = threadIdx.x;
     int i = blockIdx.x * blockDim.x + tid;
     if (i >= P) return;
@@ -965,13 +970,17 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
             o_g0 = (cl & 1u) ? 0.0f : g12[6];
             o_g1 = (cl & 2u) ? 0.0f : g12[7];
             o_g2 = (cl & 4u) ? 0.0f : g12[8];
-            const float ox = mx - vp.campos[0], oy = my - vp.campos[1], oz = mz - vp.campos[2];
-            const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
-            o_dx = ox / len; o_dy = oy / len; o_dz = oz / len;
-            o_il = 1.0f / len;
+            if (!DEFER) {
+                const float ox = mx - vp.campos[0], oy = my - vp.campos[1], oz = mz - vp.campos[2];
+                const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
+                o_dx = ox / len; o_dy = oy / len; o_dz = oz / len;
+                o_il = 1.0f / len;
+            }
         }
-        sV[0][v][tid] = o_dx; sV[1][v][tid] = o_dy; sV[2][v][tid] = o_dz; sV[3][v][tid] = o_il;
-        sV[4][v][tid] = o_g0; sV[5][v][tid] = o_g1; sV[6][v][tid] = o_g2;
+        if (!DEFER) {
+            sV[0][v][tid] = o_dx; sV[1][v][tid] = o_dy; sV[2][v][tid] = o_dz; sV[3][v][tid] = o_il;
+            sV[4][v][tid] = o_g0; sV[5][v][tid] = o_g1; sV[6][v][tid] = o_g2;
+        }
         if (gcol) {
             float* gp = gcol + ((size_t)v * P + i) * 3;
             gp[0] = o_g0; gp[1] = o_g1; gp[2] = o_g2;
@@ -989,6 +998,15 @@ __global__ __launch_bounds__(256) void geom_bwd_multi_kernel(
         for (int k = 0; k < 3; ++k) dL_dscale[3 * (size_t)i + k] = seen ? ds[k] : 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) dL_drot[4 * (size_t)i + k] = seen ? dq[k] : 0.0f;
+    }
+    // E3_FLAG_DEFER_SH_MEAN (only without dL_dsh): the part of dL/dmean that comes through the view directions of the SH
+    // colours needs all 48 coefficients -- a third of this kernel's fetches -- and sh_adam_views_kernel streams over
+    // exactly those coefficients right afterwards with the same directions and colour gradients in registers: it adds
+    // the term there (same operations in the same order: bit-identical), this kernel stores the geometric part only.
+    if (DEFER) {
+        dL_dmean3D[3 * (size_t)i] = seen ? gmean[0] : 0.0f; dL_dmean3D[3 * (size_t)i + 1] = seen ? gmean[1] : 0.0f;
+        dL_dmean3D[3 * (size_t)i + 2] = seen ? gmean[2] : 0.0f;
+        return;
     }
     // ---- SH coefficients: each written once; direction gradients collected per view
     float dx[E3_MAX_VIEWS], dy[E3_MAX_VIEWS], dz[E3_MAX_VIEWS], gc[E3_MAX_VIEWS][3];
@@ -1157,22 +1175,29 @@ __global__ __launch_bounds__(256) void sh_adam_views_sliced_kernel(int P, int nr
 // itself -- the sliced kernel above re-reads the colour gradients and means once per slice (8 x 48 MB of its 960 MB of
 // fetches at 1 M Gaussians).  Each slice is the same 18 streams per thread; same arithmetic per element: bit-identical.
 constexpr int E3_SH_REG_VIEWS = 4;
-__global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
+#ifndef E3_SH_MEAN_OCC
+#define E3_SH_MEAN_OCC 2      // workgroups per CU of the MEAN variant: 3 = 168 VGPRs + 80 B of scratch (optimizer stage +28 us), 2 = no scratch (+8 us)
+#endif
+template <bool MEAN, int NV>
+__global__ __launch_bounds__(256, MEAN ? E3_SH_MEAN_OCC : 3) void sh_adam_views_kernel(int P, int nranks, int views_per_rank, int D, int M,
                                                             const float* __restrict__ means,
                                                             const float* __restrict__ packed, size_t rank_stride,
-                                                            float scale, float* __restrict__ sh, int planar, ShAdam ad) {
+                                                            float scale, float* __restrict__ sh, int planar, ShAdam ad,
+                                                            float* __restrict__ dmean /* or null: E3_FLAG_DEFER_SH_MEAN */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    constexpr int CS = E3_SH_SLICE, NE = 3 * CS, NV = E3_SH_REG_VIEWS;
+    constexpr int CS = E3_SH_SLICE, NE = 3 * CS;
     const size_t st = planar ? (size_t)P : (size_t)1;
     const size_t ebase = planar ? (size_t)i : (size_t)i * M * 3;
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     float vx[NV], vy[NV], vz[NV], vg[NV][3];
+    float vil[NV], ddx[NV], ddy[NV], ddz[NV];       // dmean: 1 / |mean - camera|, dL/d(unit direction) (geom_bwd_multi_kernel's SH part)
     bool von[NV];
     const int nvt = nranks * views_per_rank;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         von[t] = false; vx[t] = vy[t] = vz[t] = vg[t][0] = vg[t][1] = vg[t][2] = 0.0f;
+        vil[t] = ddx[t] = ddy[t] = ddz[t] = 0.0f;
         if (t < nvt) {
             const int r = t / views_per_rank, v = t - r * views_per_rank;
             const float* blk = packed + (size_t)r * rank_stride;
@@ -1183,11 +1208,13 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
             const float ox = mx - cams[3 * v], oy = my - cams[3 * v + 1], oz = mz - cams[3 * v + 2];
             const float len = __builtin_sqrtf(ox * ox + oy * oy + oz * oz);
             vx[t] = ox / len; vy[t] = oy / len; vz[t] = oz / len;
+            vil[t] = 1.0f / len;
         }
     }
     const int nk = (D + 1) * (D + 1);
     const int nslices = M / CS;
-#pragma unroll 2
+    constexpr int SLICE_UNROLL = MEAN ? 1 : 2;
+#pragma unroll SLICE_UNROLL
     for (int sl = 0; sl < nslices; ++sl) {
         const int k0 = CS * sl;
         const size_t e0 = ebase + (size_t)(3 * k0) * st;
@@ -1207,6 +1234,10 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
                         sh_basis(k0 + kk, vx[t], vy[t], vz[t], Y, Yx, Yy, Yz);
                         acc[kk][0] = FMA(Y, vg[t][0], acc[kk][0]); acc[kk][1] = FMA(Y, vg[t][1], acc[kk][1]);
                         acc[kk][2] = FMA(Y, vg[t][2], acc[kk][2]);
+                        if (MEAN) {              // the coefficients as the backward saw them: p0, not yet stepped
+                            const float sgn = FMA(p0[3 * kk], vg[t][0], FMA(p0[3 * kk + 1], vg[t][1], p0[3 * kk + 2] * vg[t][2]));
+                            ddx[t] = FMA(Yx, sgn, ddx[t]); ddy[t] = FMA(Yy, sgn, ddy[t]); ddz[t] = FMA(Yz, sgn, ddz[t]);
+                        }
                     }
                 }
             }
@@ -1220,21 +1251,36 @@ __global__ __launch_bounds__(256) void sh_adam_views_kernel(int P, int nranks, i
             sh[e0 + j * st] = p0[j] - ((k0 == 0 && j < 3) ? ad.ss_dc : ad.ss_rest) * (mi / (__builtin_sqrtf(vi) / ad.bc2s + ad.eps));
         }
     }
+    if (MEAN) {
+        // direction gradient -> position, view by view on top of the geometric part (the order of geom_bwd_multi_kernel)
+        float g0 = dmean[3 * (size_t)i], g1 = dmean[3 * (size_t)i + 1], g2 = dmean[3 * (size_t)i + 2];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (von[t]) {
+                const float dot = vx[t] * ddx[t] + vy[t] * ddy[t] + vz[t] * ddz[t];
+                g0 += (ddx[t] - vx[t] * dot) * vil[t];
+                g1 += (ddy[t] - vy[t] * dot) * vil[t];
+                g2 += (ddz[t] - vz[t] * dot) * vil[t];
+            }
+        }
+        dmean[3 * (size_t)i] = g0; dmean[3 * (size_t)i + 1] = g1; dmean[3 * (size_t)i + 2] = g2;
+    }
 }
 
 int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
-                          float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s) {
+                          float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s, float* dmean) {
     if (P <= 0) return 0;
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     ShAdam ad;
     ad.m = exp_avg; ad.v = exp_avg_sq; ad.ss_dc = (float)((double)lr_dc / bc1); ad.ss_rest = (float)((double)lr_rest / bc1);
     ad.bc2s = (float)sqrt(bc2); ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
     static const bool reg_views = !(getenv("E3DGS_SH_ADAM_SLICED") && atoi(getenv("E3DGS_SH_ADAM_SLICED")) != 0);   // (A/B switch)
-    if (reg_views && nranks * views_per_rank <= E3_SH_REG_VIEWS && M % E3_SH_SLICE == 0)
-        sh_adam_views_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, nranks, views_per_rank, D, M, means3D, packed,
-                                                                          rank_stride, scale, sh,
-                                                                          (flags & E3_FLAG_SH_PLANAR) != 0, ad);
+    if (dmean && !(nranks * views_per_rank <= E3_SH_REG_VIEWS && M % E3_SH_SLICE == 0)) return (int)hipErrorInvalidValue;
+    if ((reg_views || dmean) && nranks * views_per_rank <= E3_SH_REG_VIEWS && M % E3_SH_SLICE == 0)
+        (dmean ? (nranks * views_per_rank <= 3 ? sh_adam_views_kernel<true, 3> : sh_adam_views_kernel<true, E3_SH_REG_VIEWS>)
+               : sh_adam_views_kernel<false, E3_SH_REG_VIEWS>)<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, sh, (flags & E3_FLAG_SH_PLANAR) != 0, ad, dmean);
     else
         sh_adam_views_sliced_kernel<<<dim3((P + 255) / 256, M / E3_SH_SLICE), dim3(256), 0, s>>>(
             P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, sh, (flags & E3_FLAG_SH_PLANAR) != 0, ad);
@@ -1367,7 +1413,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         MultiViews mv;
         mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.gsum = gsum;
         mv.stats = (dL_dpix_stats && num_rendered > 0) ? 1 : 0;
-        geom_bwd_multi_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+        ((flags & E3_FLAG_DEFER_SH_MEAN) != 0 && !dL_dsh && dL_dcolour_views ? geom_bwd_multi_kernel<true> : geom_bwd_multi_kernel<false>)<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
             dL_dscale, dL_drot, dL_dcolour_views);
     }

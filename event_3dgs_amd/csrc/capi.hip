@@ -469,6 +469,24 @@ int e3dgs_sh_adam_from_colour(int P, int nranks, int views_per_rank, int D, int 
     return rc ? e3_fail((hipError_t)rc, "sh_grad_views_kernel<adam>") : 0;
 }
 
+int e3dgs_sh_adam_from_colour_mean(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
+                                   const float* packed, size_t rank_stride, float scale, float* sh, float* exp_avg,
+                                   float* exp_avg_sq, float lr_f_dc, float lr_f_rest, float beta1, float beta2, float eps,
+                                   int step, int flags, float* dL_dmean3D, void* stream) {
+    g_err[0] = 0;
+    if (P < 0 || nranks < 1 || views_per_rank < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || step < 1)
+        return e3_fail(hipErrorInvalidValue, "bad sizes");
+    if (M % 2 != 0 || M > 64) return e3_fail(hipErrorInvalidValue, "M must be even (the optimizer kernel works on two coefficients per slice)");
+    if (nranks * views_per_rank > 4) return e3_fail(hipErrorInvalidValue, "the deferred position term needs at most 4 views in all");
+    if (P > 0 && (!means3D || !packed || !sh || !exp_avg || !exp_avg_sq || !dL_dmean3D)) return e3_fail(hipErrorInvalidValue, "null pointer");
+    if (rank_stride < (size_t)views_per_rank * ((size_t)P * 3 + 3))
+        return e3_fail(hipErrorInvalidValue, "rank_stride smaller than one rank block");
+    int rc = e3_sh_adam_views_impl(P, nranks, views_per_rank, D, M, means3D, packed, rank_stride, scale, sh, exp_avg,
+                                   exp_avg_sq, lr_f_dc, lr_f_rest, beta1, beta2, eps, step, flags, (hipStream_t)stream,
+                                   dL_dmean3D);
+    return rc ? e3_fail((hipError_t)rc, "sh_adam_views_kernel<mean>") : 0;
+}
+
 size_t e3dgs_state_offset_emit_gid(int num_rendered) {
     char* p = nullptr;
     BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));

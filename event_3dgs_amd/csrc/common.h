@@ -28,6 +28,7 @@
 #define E3_FLAG_COUNT_MAPPED 64     // begin: num_rendered_host is pinned + device-mapped; the GPU stores the count there
 #define E3_FLAG_DEFER_COLOR 128     // multi begin: no SH evaluation in preprocess; finish runs colour_kernel
 #define E3_FLAG_COUNT_DEVICE 256    // backward: num_rendered is the CAPACITY of a forward_multi_capacity call
+#define E3_FLAG_DEFER_SH_MEAN 512   // backward_multi without dL_dsh: dL_dmean3D lacks the SH view-direction term (sh_adam_views_kernel adds it)
 // per-call options (include/e3dgs_hip.h: E3DGS_FLAG_OPTIONS ...): with E3_FLAG_OPTIONS the bits below describe the call;
 // without it the process-wide defaults apply (environment at load time / the deprecated e3dgs_set_* setters)
 #define E3_FLAG_OPTIONS 0x0800
@@ -435,7 +436,7 @@ int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
 
 int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
-                          float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s);
+                          float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s, float* dmean = nullptr);
 
 // launchers implemented in scan_sort.hip (0 or a hipError_t code; the text is in e3dgs_last_error())
 int launch_scan_chained_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* desc_zeroed, bool inclusive,

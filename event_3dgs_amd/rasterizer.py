@@ -702,18 +702,26 @@ def sh_grad_from_colour(means3D, packed, nranks, views_per_rank, sh_degree, M, d
 
 
 def sh_adam_from_colour(means3D, packed, nranks, views_per_rank, sh_degree, M, sh, exp_avg, exp_avg_sq, lr_dc, lr_rest,
-                        step, scale=1.0, beta1=0.9, beta2=0.999, eps=1e-15, planar=True):
+                        step, scale=1.0, beta1=0.9, beta2=0.999, eps=1e-15, planar=True, mean_grad=None):
     """e3dgs_sh_adam_from_colour: rebuild of the (mean) SH gradient from per-view colour gradients fused with the Adam
-    update of the SH coefficients `sh` (in place, with their moments).  `packed` as for sh_grad_from_colour."""
+    update of the SH coefficients `sh` (in place, with their moments).  `packed` as for sh_grad_from_colour.
+    mean_grad (P,3): e3dgs_sh_adam_from_colour_mean -- the position gradient of a backward_multi that ran with
+    FLAG_DEFER_SH_MEAN; the term through the SH view directions is added to it."""
     L = _lib.lib()
     P = means3D.shape[0]
     if packed.dim() != 2 or packed.shape[0] != nranks or not packed.is_contiguous():
         raise ValueError("packed must be a contiguous (nranks, block) tensor")
+    head = (P, nranks, views_per_rank, int(sh_degree), int(M), _lib.ptr(means3D), _lib.ptr(packed), packed.shape[1],
+            float(scale), _lib.ptr(sh), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), float(lr_dc), float(lr_rest), beta1, beta2,
+            eps, int(step), _lib.FLAG_SH_PLANAR if planar else 0)
     with torch.cuda.device(means3D.device):
-        rc = L.e3dgs_sh_adam_from_colour(P, nranks, views_per_rank, int(sh_degree), int(M), _lib.ptr(means3D),
-                                         _lib.ptr(packed), packed.shape[1], float(scale), _lib.ptr(sh), _lib.ptr(exp_avg),
-                                         _lib.ptr(exp_avg_sq), float(lr_dc), float(lr_rest), beta1, beta2, eps, int(step),
-                                         _lib.FLAG_SH_PLANAR if planar else 0, _lib.current_stream())
+        if mean_grad is None:
+            rc = L.e3dgs_sh_adam_from_colour(*head, _lib.current_stream())
+        else:
+            if not (mean_grad.is_cuda and mean_grad.dtype == torch.float32 and mean_grad.is_contiguous()
+                    and tuple(mean_grad.shape) == (P, 3)):
+                raise ValueError("mean_grad must be a contiguous fp32 (P,3) GPU tensor")
+            rc = L.e3dgs_sh_adam_from_colour_mean(*head, _lib.ptr(mean_grad), _lib.current_stream())
     _lib.check(rc, "e3dgs_sh_adam_from_colour")
 
 

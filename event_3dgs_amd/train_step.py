@@ -162,6 +162,8 @@ class EventTrainer:
         self._packed_store = None
         self._gathered_store = None
         self._packed_views = 0         # views whose colour gradients the last backward left in _packed (0: none)
+        self._mean_deferred = False    # the last backward left the SH view-direction term out of the xyz gradient
+        #                                (FLAG_DEFER_SH_MEAN); _adam_sh_from_colour() adds it inside the SH optimizer kernel
         self._packed_cams = None       # (camera-centre tensors, versions) whose values sit in the tail of _packed
         self._xyz_prev = None          # the means the gradients were computed with (Adam moves them meanwhile)
         self._side = None
@@ -413,6 +415,7 @@ class EventTrainer:
                 so, sn = self.seg["c"]
                 self._adam_range(so, sn, self.c_lr, st["c"], eps=1e-8)
             self._packed_views = 0
+            self._mean_deferred = False
         elif self.overlap_features or self.factorize_sh:
             self._update_overlapped(it, dist_on, st)
         elif dist_on:
@@ -630,6 +633,14 @@ class EventTrainer:
         self._coincide[key] = ((tensors, tuple(t._version for t in tensors)), same)
         return same
 
+    def _backward_flags(self, raw, sh_via_colour):
+        """One rank, SH gradient never stored (sh_via_colour): the backward also leaves out the part of the xyz gradient that
+        comes through the SH view directions -- it needs all 48 coefficients, which the SH optimizer kernel streams over
+        anyway (apply_update() -> _adam_sh_from_colour adds it, bit-identical).  Until then grads["xyz"] is incomplete."""
+        self._mean_deferred = bool(sh_via_colour and not self.multi and not self.factorize_sh and not self.overlap_features
+                                   and self._packed_views <= 4 and os.environ.get("E3DGS_DEFER_SH_MEAN", "1") != "0")
+        return raw["flags"] | (_lib.FLAG_DEFER_SH_MEAN if self._mean_deferred else 0)
+
     def _colour_gradients_instead_of_sh(self, out, settings, pad_to=None):
         """The backward hands out the per-view colour gradients (3 floats per Gaussian and view) instead of the 48-float SH
         gradient, which is rebuilt after the exchange / inside the SH optimizer kernel.  _packed = [nv x P x 3 colour
@@ -705,7 +716,8 @@ class EventTrainer:
             self._colour_gradients_instead_of_sh(out, settings, pad_to=3 if self.multi else None)
         if want_vs:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
-        rasterizer.backward_multi(raw, dpix, out, stats_grad_view0=d_int if (shared and want_vs) else None)
+        rasterizer.backward_multi(raw, dpix, out, flags=self._backward_flags(raw, sh_via_colour),
+                                  stats_grad_view0=d_int if (shared and want_vs) else None)
         return scalars, raw
 
     def _compute_gradients_separate(self, settings, gt_int, gt_now, gt_next, gt_blur):
@@ -882,8 +894,10 @@ class EventTrainer:
         rasterizer.sh_adam_from_colour(self.views["xyz"], self._packed.view(1, -1), 1, self._packed_views,
                                        self.active_sh_degree, 16, self.views["features"],
                                        self.exp_avg[f_off:f_off + f_n], self.exp_avg_sq[f_off:f_off + f_n],
-                                       self.lrs["features"], self.lrs["features_rest"], st["gauss"])
+                                       self.lrs["features"], self.lrs["features_rest"], st["gauss"],
+                                       mean_grad=self.grads["xyz"] if self._mean_deferred else None)
         self._packed_views = 0
+        self._mean_deferred = False
         g, o, c = st["gauss"], st["opacity"], st["c"]
         if os.environ.get("E3DGS_ADAM_GAP", "1") != "0":
             # everything around the SH segment in ONE launch (the segment is a gap the launch does not visit): xyz, then
@@ -970,7 +984,7 @@ class EventTrainer:
         self._packed_views = 0
         if self.factorize_sh or sh_via_colour:     # as in the event iteration, with one view: 3 floats per Gaussian are
             self._colour_gradients_instead_of_sh(out, settings)      # exchanged / kept instead of the 48 of the SH gradient
-        rasterizer.backward_multi(raw, dpix, out)
+        rasterizer.backward_multi(raw, dpix, out, flags=self._backward_flags(raw, sh_via_colour))
         return loss, raw
 
     def step_image_autograd(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):

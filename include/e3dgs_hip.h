@@ -69,6 +69,9 @@ const char* e3dgs_last_error(void);
                                        another stream while this iteration projects, sorts and bins. */
 #define E3DGS_FLAG_COUNT_DEVICE 256   /* backward_multi: the forward was e3dgs_rasterize_forward_multi_capacity and
                                         num_rendered is its `capacity` (the count itself sits in the geometry scratch) */
+#define E3DGS_FLAG_DEFER_SH_MEAN 512  /* backward_multi with dL_dcolour_views and WITHOUT dL_dsh (ABI 15): dL_dmean3D
+                                        holds the geometric part only; the term through the SH view directions is added
+                                        by e3dgs_sh_adam_from_colour_mean, which reads the coefficients anyway */
 /* ---- per-call OPTIONS (ABI 13).  The library keeps no mutable process-wide state that a call reads when
  * E3DGS_FLAG_OPTIONS is set: calls with different settings may run concurrently from any number of host threads and
  * streams.  Every call of one forward / backward (begin, finish, backward) must be given the same option bits.
@@ -361,6 +364,20 @@ int e3dgs_sh_adam_from_colour(int P, int nranks, int views_per_rank, int D, int 
                               const float* packed, size_t rank_stride, float scale, float* sh, float* exp_avg,
                               float* exp_avg_sq, float lr_f_dc, float lr_f_rest, float beta1, float beta2, float eps,
                               int step, int flags, void* stream);
+
+/*
+ * The same, PLUS the part of dL/dmean3D that E3DGS_FLAG_DEFER_SH_MEAN left out of e3dgs_rasterize_backward_multi: the
+ * view-dependent SH colour makes the colour gradient act on the position through the unit view direction
+ * (d colour / d dir x d dir / d mean, [UPSTREAM] computeColorFromSH backward), a term that needs all the coefficients --
+ * a third of the per-Gaussian backward kernel's fetches -- while this kernel streams over those very coefficients with
+ * the directions and colour gradients already in registers.  It ADDS the term to dL_dmean3D (P,3), view by view on top
+ * of what the backward stored: the same operations in the same order as the undeferred backward, bit for bit.  At most 4
+ * views in all (one rank's triplet).  Call it before the optimizer step of the positions.
+ */
+int e3dgs_sh_adam_from_colour_mean(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
+                                   const float* packed, size_t rank_stride, float scale, float* sh, float* exp_avg,
+                                   float* exp_avg_sq, float lr_f_dc, float lr_f_rest, float beta1, float beta2, float eps,
+                                   int step, int flags, float* dL_dmean3D, void* stream);
 
 /*
  * DEPRECATED setters: they change the process-wide DEFAULT that calls without E3DGS_FLAG_OPTIONS fall back to (not
