@@ -669,6 +669,41 @@ def test_segmented_adam_equals_per_group_adam():
         losses.adam_step_segments_(a[0], grad, a[1], a[2], ends[:-1], lrs[:-1], eps[:-1], 1)
 
 
+def test_deferred_sh_position_term_is_bit_identical(monkeypatch):
+    """E3DGS_FLAG_DEFER_SH_MEAN + e3dgs_sh_adam_from_colour_mean (the per-Gaussian backward leaves the position-gradient
+    term through the SH view directions to the SH optimizer kernel) against the backward that computes it itself:
+    identical parameters and moments after every iteration, event and image mode; between compute_gradients() and
+    apply_update() the xyz gradient is the geometric part only."""
+    from event_3dgs_amd.train_step import EventTrainer
+    from event_3dgs_amd import _lib, rasterizer
+    params, cams = _scene(N=4000)
+    bg = torch.zeros(3, device=DEV)
+    gts = [t.contiguous() for t in _gts(params, cams, bg)]
+    a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
+    assert a.sh_via_colour
+    for it in range(4):
+        for t, flag in ((a, "1"), (b, "0")):
+            monkeypatch.setenv("E3DGS_DEFER_SH_MEAN", flag)
+            if it == 2:
+                t.compute_gradients_image(cams[0], gts[0], bg, mode="gray", sh_via_colour=True)
+            else:
+                t.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, sh_via_colour=True)
+            assert t._mean_deferred == (t is a)
+        gx_a, gx_b = a.grads["xyz"].clone(), b.grads["xyz"].clone()
+        assert not torch.equal(gx_a, gx_b)                              # (the view-dependent colour term is still missing)
+        for name in ("opacity", "scaling", "rotation"):
+            assert torch.equal(a.grads[name], b.grads[name])
+        for t in (a, b):
+            t.apply_update(skip=("c",) if it == 2 else ())
+        assert torch.equal(a.grads["xyz"], gx_b), it                   # completed inside the SH optimizer kernel
+        assert torch.equal(a.flat, b.flat) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq), it
+    with pytest.raises(_lib.HipLibraryError, match="at most 4 views"):
+        N = a.N
+        packed = torch.zeros(1, 5 * (N * 3 + 3), device=DEV)
+        rasterizer.sh_adam_from_colour(a.views["xyz"], packed, 1, 5, 3, 16, a.views["features"], a.exp_avg[:48 * N],
+                                       a.exp_avg_sq[:48 * N], 1e-3, 1e-4, 1, mean_grad=a.grads["xyz"])
+
+
 def test_adam_with_a_gap_equals_one_launch_per_range():
     """e3dgs_adam_step_groups_gap (everything around the SH segment in one launch, per-group step counts, the gap never
     visited) == one e3dgs_adam_step_groups launch per contiguous range, bit for bit; the gap stays untouched."""
