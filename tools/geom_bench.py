@@ -19,9 +19,9 @@ gts = [gt.render_raw(c, bg)["color"].clone() for c in cams]
 tr = EventTrainer(params, dev)
 cap = {}
 orig = rasterizer.backward_multi
-def spy(raw, dpix, out, flags=None, grad_acc=None):
+def spy(raw, dpix, out, flags=None, grad_acc=None, **kw):
     cap["a"] = (raw, dpix, out)
-    return orig(raw, dpix, out, flags, grad_acc)
+    return orig(raw, dpix, out, flags, grad_acc, **kw)
 rasterizer.backward_multi = spy
 tr.compute_gradients(*cams, *gts, bg, sh_via_colour=True)
 rasterizer.backward_multi = orig
