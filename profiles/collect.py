@@ -38,8 +38,8 @@ STAGES = {          # bench.py stage -> kernel-name prefixes (rocprof names; tem
     "tile_ranges": ["tile_order_reg_kernel", "void tile_ranges_kernel"],
     "render_fwd": ["render_fwd_kernel"],
     "render_bwd": ["render_bwd_kernel"],
-    "geom_bwd": ["run_reduce_kernel", "geom_bwd_multi_kernel"],
-    "optimizer": ["sh_adam_views_kernel", "adam_segments_kernel"],
+    "geom_bwd": ["run_reduce_kernel", "geom_bwd_multi_kernel", "void geom_bwd_multi_kernel"],
+    "optimizer": ["sh_adam_views_kernel", "void sh_adam_views_kernel", "adam_segments_kernel"],
     "event_loss": ["event_reduce_kernel", "event_finalize_kernel", "event_grad_kernel", "event_fused_kernel"],
 }
 SQ_PASSES = [

@@ -14,7 +14,8 @@ def test_committed_profile_summary_is_complete():
     per_iter = t["kernels_per_iteration"]
     assert len(per_iter) >= 20, sorted(per_iter)                       # one event iteration launches ~23 distinct kernels
     for name in ("render_bwd_kernel", "render_fwd_kernel", "run_reduce_kernel", "sh_adam_views_kernel"):
-        assert per_iter[name]["launches_per_iteration"] == 1, name
+        hits = [k for k in per_iter if name in k]          # (template instances: "void sh_adam_views_kernel<true, 3>")
+        assert len(hits) == 1 and per_iter[hits[0]]["launches_per_iteration"] == 1, (name, hits)
     tr = t["traffic_per_kernel"]["render_bwd_kernel"]
     assert tr["hbm_bytes_per_launch"] == tr["fetch_bytes"] + tr["write_bytes"] > 1e9
     assert set(t["stages"]) >= {"preprocess", "sort_depth", "scan_emit", "sort_tile", "render_fwd", "render_bwd", "geom_bwd",
