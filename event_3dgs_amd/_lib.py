@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 NOTIFY_FN = C.CFUNCTYPE(None, C.c_void_p)
@@ -79,6 +79,10 @@ def lib():
     L.e3dgs_rasterize_backward_multi_stats.argtypes = (
         [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
         + [_ip] + [_cp] * 3 + [_fp] * 10 + [C.c_int, C.c_int, _vp])
+    L.e3dgs_rasterize_backward_multi_rank1.restype = C.c_int
+    L.e3dgs_rasterize_backward_multi_rank1.argtypes = (
+        [C.c_int] * 5 + [_fp, C.c_int, C.c_int] + [_fp] * 4 + [C.c_float, _fp] + [_pp] * 3 + [_hf] * 2
+        + [_ip] + [_cp] * 3 + [_fp] * 2 + [_hf, C.c_uint] + [_fp] * 8 + [C.c_int, C.c_int, _vp])
     L.e3dgs_sh_grad_from_colour.restype = C.c_int
     L.e3dgs_sh_grad_from_colour.argtypes = [C.c_int] * 5 + [_fp, _fp, C.c_size_t, C.c_float, _fp, C.c_int, _vp]
     L.e3dgs_sh_adam_from_colour.restype = C.c_int
@@ -110,6 +114,10 @@ def lib():
     L.e3dgs_event_loss.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 5 + [_cp, _vp]
     L.e3dgs_event_loss_cached.restype = C.c_int
     L.e3dgs_event_loss_cached.argtypes = [C.c_int, C.c_int] + [_fp] * 8 + [C.c_float] + [_fp] * 5 + [_vp, C.c_int, _cp, _vp]
+    L.e3dgs_event_loss_rank1.restype = C.c_int
+    L.e3dgs_event_loss_rank1.argtypes = L.e3dgs_event_loss_cached.argtypes
+    L.e3dgs_image_loss_rank1.restype = C.c_int
+    L.e3dgs_image_loss_rank1.argtypes = [C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _cp, _vp]
     L.e3dgs_ssim_scratch_bytes.restype = C.c_size_t
     L.e3dgs_ssim_scratch_bytes.argtypes = [C.c_int] * 3
     L.e3dgs_ssim.restype = C.c_int
@@ -222,4 +230,5 @@ EXPORTED_SYMBOLS = [
     "e3dgs_set_tile_cull", "e3dgs_get_tile_cull", "e3dgs_set_small_scene_paths", "e3dgs_get_small_scene_paths", "e3dgs_state_offsets", "e3dgs_state_offsets_multi", "e3dgs_state_offset_emit_gid", "e3dgs_mark_visible", "e3dgs_knn_scratch_bytes", "e3dgs_dist_knn3", "e3dgs_event_loss_scratch_bytes",
     "e3dgs_event_loss", "e3dgs_event_loss_cached", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step_groups_gap", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_select", "e3dgs_profile_query", "e3dgs_profile_slot_name",
     "e3dgs_sort_scratch_bytes", "e3dgs_sort_pairs", "e3dgs_rasterize_forward_multi_capacity",
+    "e3dgs_rasterize_backward_multi_rank1", "e3dgs_event_loss_rank1", "e3dgs_image_loss_rank1",
 ]

@@ -1,7 +1,7 @@
 """Per-view matrices consumed by the rasteriser, in the reference's conventions.
 
-Mirrors scene/cameras.py:17-57 (Camera / MiniCam), utils/graphics_utils.py:38-49
-(getWorld2View2) and :51-71 (getProjectionMatrix).  Pinned by tests/golden/cameras.npz.
+The fields of scene/cameras.py:17-57 (Camera / MiniCam) with the matrices of utils/graphics_utils.py:38-49
+(getWorld2View2) and :51-71 (getProjectionMatrix) in closed form.  Pinned by tests/golden/cameras.npz.
 """
 import math
 
@@ -10,30 +10,27 @@ import torch
 
 
 def getWorld2View2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    """utils/graphics_utils.py:38-49.  R is the camera-to-world rotation (stored transposed,
-    scene/dataset_readers.py:246), t the world-to-camera translation."""
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = np.asarray(R).transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    C2W[:3, 3] = (C2W[:3, 3] + translate) * scale
-    return np.float32(np.linalg.inv(C2W))
+    """World-to-view matrix of utils/graphics_utils.py:38-49 in closed form.  R is the camera-to-world rotation (stored
+    transposed, scene/dataset_readers.py:246) and t the world-to-camera translation, so the camera sits at c = -R t; the
+    reference's recentring moves it to (c + translate) * scale and keeps the orientation: x_view = R^T (x - c')."""
+    R = np.asarray(R, np.float64)
+    centre = (-R @ np.asarray(t, np.float64) + np.asarray(translate, np.float64)) * scale
+    w2v = np.eye(4)
+    w2v[:3, :3] = R.T
+    w2v[:3, 3] = -R.T @ centre
+    return w2v.astype(np.float32)
 
 
 def getProjectionMatrix(znear, zfar, fovX, fovY):
-    """utils/graphics_utils.py:51-71 (P[3,2] = 1 -> w_clip = z_view)."""
-    tanHalfFovY, tanHalfFovX = math.tan(fovY / 2), math.tan(fovX / 2)
-    top, right = tanHalfFovY * znear, tanHalfFovX * znear
-    bottom, left = -top, -right
+    """The symmetric-frustum projection of utils/graphics_utils.py:51-71: x, y scaled by the cotangents of the half
+    angles (the frustum is centred, so there is no shear term), z mapped to [0, 1] over [znear, zfar], w_clip = z_view."""
     P = torch.zeros(4, 4)
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
+    P[0, 0] = 1.0 / math.tan(0.5 * fovX)
+    P[1, 1] = 1.0 / math.tan(0.5 * fovY)
+    depth = zfar - znear
+    P[2, 2] = zfar / depth
+    P[2, 3] = -(zfar * znear) / depth
     P[3, 2] = 1.0
-    P[2, 2] = zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
     return P
 
 

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     const float* __restrict__ gt_int, const float* __restrict__ gt_now, const float* __restrict__ gt_next,
     const float* __restrict__ gt_blur, const float* __restrict__ c_ptr, float gt_c,
     const float* __restrict__ scalars, float* d_image, float* d_now /* may alias d_image: the SUM is stored */,
-    float* __restrict__ d_next) {
+    float* __restrict__ d_next, int rank1 /* d_next (and d_now when it is a render of its own) as scalar fields */) {
     // d_now == d_image: render #1 and render #2 are the same render (the reference's event camera `index` carries the
     // pose of its training camera `index`: scene/dataset_readers.py:157 reads both with the same extrinsics), so the
     // caller rendered it once and wants dL/d(that image) = intensity part + contrast part
@@ -346,13 +346,14 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     const float wch[3] = {0.4124f, 0.35758f, 0.1804f};
     // one pixel: inputs per channel -> the three gradient triples
     auto pixel = [&](const float nx[3], const float nw[3], const float gx[3], const float gw[3], const float im[3],
-                     const float gi[3], const float gb[3], float dn[3], float dw[3], float di[3]) {
+                     const float gi[3], const float gb[3], float dn[3], float dw[3], float di[3], float& sn, float& sw) {
         auto lum = [](const float v[3]) { return FMA(0.1804f, v[2], FMA(0.35758f, v[1], 0.4124f * v[0])); };
         float yn = lum(nx) + 1e-8f, yo = lum(nw) + 1e-8f;
         float D = (logf(yn) - logf(yo)) / c;
         float Dg = (logf(lum(gx) + 1e-8f) - logf(lum(gw) + 1e-8f)) / gt_c;
         float e = D - Dg;
         float k = kE * (float)((e > 0.0f) - (e < 0.0f)) / c;
+        sn = k / yn; sw = -(k / yo);         // rank-1 form: dL/dC = s * (0.4124, 0.35758, 0.1804)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             dn[ch] = k * wch[ch] / yn;
@@ -369,8 +370,16 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
     const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(now) |
                                         reinterpret_cast<uintptr_t>(next) | reinterpret_cast<uintptr_t>(gt_int) |
                                         reinterpret_cast<uintptr_t>(gt_now) | reinterpret_cast<uintptr_t>(gt_next) |
-                                        reinterpret_cast<uintptr_t>(gt_blur) | reinterpret_cast<uintptr_t>(d_image) |
-                                        reinterpret_cast<uintptr_t>(d_now) | reinterpret_cast<uintptr_t>(d_next)) & 15) == 0;
+                                        reinterpret_cast<uintptr_t>(gt_blur)) & 15) == 0;
+    // (the pixel -> thread mapping, i.e. the accumulation order of the partial sums, follows from the INPUTS alone, as in
+    // event_reduce_kernel: the loss scalars of this path stay bit-identical to the three-launch path whatever the alignment
+    // of the outputs; misaligned outputs only turn the 16-byte stores into dword stores)
+    const bool vec_out = ((reinterpret_cast<uintptr_t>(d_image) | reinterpret_cast<uintptr_t>(d_now) |
+                           reinterpret_cast<uintptr_t>(d_next)) & 15) == 0;
+    auto store4 = [vec_out](float* plane, size_t q, float a, float b, float c4, float d) {
+        if (vec_out) reinterpret_cast<float4*>(plane)[q] = make_float4(a, b, c4, d);
+        else { plane[4 * q] = a; plane[4 * q + 1] = b; plane[4 * q + 2] = c4; plane[4 * q + 3] = d; }
+    };
     if (vec) {
         const size_t HW4 = HW >> 2;                          // four pixels per thread and trip, 16-byte loads and stores
         for (size_t q = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; q < HW4; q += (size_t)gridDim.x * EV_THREADS) {
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
                 vgi[ch] = reinterpret_cast<const float4*>(gt_int + ch * HW)[q];
                 vgb[ch] = gt_blur ? reinterpret_cast<const float4*>(gt_blur + ch * HW)[q] : make_float4(0, 0, 0, 0);
             }
-            float on[3][4], ow[3][4], oi[3][4];
+            float on[3][4], ow[3][4], oi[3][4], osn[4], osw[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 auto comp = [u](const float4& v) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); };
@@ -394,23 +403,27 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
                 const float im[3] = {comp(vim[0]), comp(vim[1]), comp(vim[2])}, gi[3] = {comp(vgi[0]), comp(vgi[1]), comp(vgi[2])};
                 const float gb[3] = {comp(vgb[0]), comp(vgb[1]), comp(vgb[2])};
                 float dn[3], dw[3], di[3];
-                pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+                pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di, osn[u], osw[u]);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) { on[ch][u] = dn[ch]; ow[ch][u] = dw[ch]; oi[ch][u] = di[ch]; }
             }
+            if (rank1) {                     // the contrast renders' gradients as scalar fields (plane 0 only)
+                store4(d_next, q, osn[0], osn[1], osn[2], osn[3]);
+                if (!shared && !total_in_now) store4(d_now, q, osw[0], osw[1], osw[2], osw[3]);
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                reinterpret_cast<float4*>(d_next + ch * HW)[q] = make_float4(on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
+                if (!rank1) store4(d_next + ch * HW, q, on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
                 if (shared) {
-                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1],
-                                                                                  oi[ch][2] + ow[ch][2], oi[ch][3] + ow[ch][3]);
+                    store4(d_image + ch * HW, q, oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1], oi[ch][2] + ow[ch][2],
+                           oi[ch][3] + ow[ch][3]);
                 } else {
                     if (total_in_now) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) ow[ch][u] = oi[ch][u] + ow[ch][u];
                     }
-                    reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
-                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
+                    if (!rank1 || total_in_now) store4(d_now + ch * HW, q, ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
+                    store4(d_image + ch * HW, q, oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
                 }
             }
         }
@@ -423,12 +436,20 @@ __global__ __launch_bounds__(EV_THREADS) void event_grad_kernel(
                 gw[ch] = gt_now[ch * HW + p]; im[ch] = image[ch * HW + p]; gi[ch] = gt_int[ch * HW + p];
                 gb[ch] = gt_blur ? gt_blur[ch * HW + p] : 0.0f;
             }
-            pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+            float sn, sw;
+            pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di, sn, sw);
+            if (rank1) {
+                d_next[p] = sn;
+                if (!shared && !total_in_now) d_now[p] = sw;
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                d_next[ch * HW + p] = dn[ch];
+                if (!rank1) d_next[ch * HW + p] = dn[ch];
                 if (shared) d_image[ch * HW + p] = di[ch] + dw[ch];
-                else { d_now[ch * HW + p] = total_in_now ? di[ch] + dw[ch] : dw[ch]; d_image[ch * HW + p] = di[ch]; }
+                else {
+                    if (!rank1 || total_in_now) d_now[ch * HW + p] = total_in_now ? di[ch] + dw[ch] : dw[ch];
+                    d_image[ch * HW + p] = di[ch];
+                }
             }
         }
     }
@@ -446,7 +467,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
     const float* __restrict__ gt_int, const float* __restrict__ gt_now, const float* __restrict__ gt_next,
     const float* __restrict__ gt_blur, const float* __restrict__ c_ptr, float gt_c, const double* __restrict__ nz_count,
     double* __restrict__ partials, float* d_image, float* d_now /* may alias d_image: the SUM is stored */,
-    float* __restrict__ d_next) {
+    float* __restrict__ d_next, int rank1) {
     __shared__ double sred[EV_NSUM][EV_THREADS / WAVE];
     const bool shared = d_now == d_image;
     const bool total_in_now = !shared && image == now;
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
     const float wch[3] = {0.4124f, 0.35758f, 0.1804f};
     double acc[EV_NSUM] = {0, 0, 0, 0, 0};
     auto pixel = [&](const float nx[3], const float nw[3], const float gx[3], const float gw[3], const float im[3],
-                     const float gi[3], const float gb[3], float dn[3], float dw[3], float di[3]) {
+                     const float gi[3], const float gb[3], float dn[3], float dw[3], float di[3], float& sn, float& sw) {
         auto lum = [](const float v[3]) { return FMA(0.1804f, v[2], FMA(0.35758f, v[1], 0.4124f * v[0])); };
         const float yn = lum(nx) + 1e-8f, yo = lum(nw) + 1e-8f;
         const float D = (logf(yn) - logf(yo)) / c;
@@ -472,6 +493,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
         acc[1] += (Dg != 0.0f) ? 1.0 : 0.0;
         acc[2] += (double)((e > 0.0f) - (e < 0.0f)) * (double)D;
         const float k = kE * sg / c;
+        sn = k / yn; sw = -(k / yo);         // rank-1 form: dL/dC = s * (0.4124, 0.35758, 0.1804)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             acc[3] += fabsf(im[ch] - gi[ch]);
@@ -490,8 +512,16 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
     const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(now) |
                                         reinterpret_cast<uintptr_t>(next) | reinterpret_cast<uintptr_t>(gt_int) |
                                         reinterpret_cast<uintptr_t>(gt_now) | reinterpret_cast<uintptr_t>(gt_next) |
-                                        reinterpret_cast<uintptr_t>(gt_blur) | reinterpret_cast<uintptr_t>(d_image) |
-                                        reinterpret_cast<uintptr_t>(d_now) | reinterpret_cast<uintptr_t>(d_next)) & 15) == 0;
+                                        reinterpret_cast<uintptr_t>(gt_blur)) & 15) == 0;
+    // (the pixel -> thread mapping, i.e. the accumulation order of the partial sums, follows from the INPUTS alone, as in
+    // event_reduce_kernel: the loss scalars of this path stay bit-identical to the three-launch path whatever the alignment
+    // of the outputs; misaligned outputs only turn the 16-byte stores into dword stores)
+    const bool vec_out = ((reinterpret_cast<uintptr_t>(d_image) | reinterpret_cast<uintptr_t>(d_now) |
+                           reinterpret_cast<uintptr_t>(d_next)) & 15) == 0;
+    auto store4 = [vec_out](float* plane, size_t q, float a, float b, float c4, float d) {
+        if (vec_out) reinterpret_cast<float4*>(plane)[q] = make_float4(a, b, c4, d);
+        else { plane[4 * q] = a; plane[4 * q + 1] = b; plane[4 * q + 2] = c4; plane[4 * q + 3] = d; }
+    };
     if (vec) {
         const size_t HW4 = HW >> 2;
         for (size_t q = (size_t)blockIdx.x * EV_THREADS + threadIdx.x; q < HW4; q += (size_t)gridDim.x * EV_THREADS) {
@@ -506,7 +536,7 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
                 vgi[ch] = reinterpret_cast<const float4*>(gt_int + ch * HW)[q];
                 vgb[ch] = gt_blur ? reinterpret_cast<const float4*>(gt_blur + ch * HW)[q] : make_float4(0, 0, 0, 0);
             }
-            float on[3][4], ow[3][4], oi[3][4];
+            float on[3][4], ow[3][4], oi[3][4], osn[4], osw[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 auto comp = [u](const float4& v) { return u == 0 ? v.x : (u == 1 ? v.y : (u == 2 ? v.z : v.w)); };
@@ -515,23 +545,27 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
                 const float im[3] = {comp(vim[0]), comp(vim[1]), comp(vim[2])}, gi[3] = {comp(vgi[0]), comp(vgi[1]), comp(vgi[2])};
                 const float gb[3] = {comp(vgb[0]), comp(vgb[1]), comp(vgb[2])};
                 float dn[3], dw[3], di[3];
-                pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+                pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di, osn[u], osw[u]);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) { on[ch][u] = dn[ch]; ow[ch][u] = dw[ch]; oi[ch][u] = di[ch]; }
             }
+            if (rank1) {                     // the contrast renders' gradients as scalar fields (plane 0 only)
+                store4(d_next, q, osn[0], osn[1], osn[2], osn[3]);
+                if (!shared && !total_in_now) store4(d_now, q, osw[0], osw[1], osw[2], osw[3]);
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                reinterpret_cast<float4*>(d_next + ch * HW)[q] = make_float4(on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
+                if (!rank1) store4(d_next + ch * HW, q, on[ch][0], on[ch][1], on[ch][2], on[ch][3]);
                 if (shared) {
-                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1],
-                                                                                  oi[ch][2] + ow[ch][2], oi[ch][3] + ow[ch][3]);
+                    store4(d_image + ch * HW, q, oi[ch][0] + ow[ch][0], oi[ch][1] + ow[ch][1], oi[ch][2] + ow[ch][2],
+                           oi[ch][3] + ow[ch][3]);
                 } else {
                     if (total_in_now) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) ow[ch][u] = oi[ch][u] + ow[ch][u];
                     }
-                    reinterpret_cast<float4*>(d_now + ch * HW)[q] = make_float4(ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
-                    reinterpret_cast<float4*>(d_image + ch * HW)[q] = make_float4(oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
+                    if (!rank1 || total_in_now) store4(d_now + ch * HW, q, ow[ch][0], ow[ch][1], ow[ch][2], ow[ch][3]);
+                    store4(d_image + ch * HW, q, oi[ch][0], oi[ch][1], oi[ch][2], oi[ch][3]);
                 }
             }
         }
@@ -544,12 +578,20 @@ __global__ __launch_bounds__(EV_THREADS) void event_fused_kernel(
                 gw[ch] = gt_now[ch * HW + p]; im[ch] = image[ch * HW + p]; gi[ch] = gt_int[ch * HW + p];
                 gb[ch] = gt_blur ? gt_blur[ch * HW + p] : 0.0f;
             }
-            pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di);
+            float sn, sw;
+            pixel(nx, nw, gx, gw, im, gi, gb, dn, dw, di, sn, sw);
+            if (rank1) {
+                d_next[p] = sn;
+                if (!shared && !total_in_now) d_now[p] = sw;
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                d_next[ch * HW + p] = dn[ch];
+                if (!rank1) d_next[ch * HW + p] = dn[ch];
                 if (shared) d_image[ch * HW + p] = di[ch] + dw[ch];
-                else { d_now[ch * HW + p] = total_in_now ? di[ch] + dw[ch] : dw[ch]; d_image[ch * HW + p] = di[ch]; }
+                else {
+                    if (!rank1 || total_in_now) d_now[ch * HW + p] = total_in_now ? di[ch] + dw[ch] : dw[ch];
+                    d_image[ch * HW + p] = di[ch];
+                }
             }
         }
     }
@@ -576,7 +618,7 @@ size_t e3_event_scratch_bytes(int W, int H) { return (size_t)ev_blocks((size_t)W
 int e3_event_loss_impl(int W, int H, const float* image, const float* now, const float* next, const float* gt_int,
                        const float* gt_now, const float* gt_next, const float* gt_blur, const float* c, float gt_c,
                        float* d_image, float* d_now, float* d_next, float* scalars, char* scratch, hipStream_t s,
-                       float* dc_out, double* nz_count, int nz_valid) {
+                       float* dc_out, double* nz_count, int nz_valid, int rank1) {
     size_t HW = (size_t)W * H;
     if (HW == 0) return 0;
     int nb = ev_blocks(HW);
@@ -584,7 +626,7 @@ int e3_event_loss_impl(int W, int H, const float* image, const float* now, const
     if (nz_count && nz_valid) {
         // the ground-truth pair's count is known: one sweep (partial sums + the three pixel gradients), then the scalars
         event_fused_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
-                                                                 gt_c, nz_count, partials, d_image, d_now, d_next);
+                                                                 gt_c, nz_count, partials, d_image, d_now, d_next, rank1);
         event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars, dc_out,
                                                                    nullptr);
     } else {
@@ -593,7 +635,7 @@ int e3_event_loss_impl(int W, int H, const float* image, const float* now, const
         event_finalize_kernel<<<dim3(1), dim3(EV_THREADS), 0, s>>>(nb, HW, partials, c, gt_blur != nullptr, scalars, dc_out,
                                                                    nz_count);
         event_grad_kernel<<<dim3(nb), dim3(EV_THREADS), 0, s>>>(HW, image, now, next, gt_int, gt_now, gt_next, gt_blur, c,
-                                                                gt_c, scalars, d_image, d_now, d_next);
+                                                                gt_c, scalars, d_image, d_now, d_next, rank1);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "event loss kernels");
@@ -883,7 +925,7 @@ __global__ __launch_bounds__(WAVE) void ssim_finalize_kernel(int nblocks, double
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWin win, int C, int H, int W, int to_gray, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, const float* __restrict__ partial3,
                                                        float scale, float* __restrict__ d_img1, float l1_scale,
-                                                       double* __restrict__ l1_sums) {
+                                                       double* __restrict__ l1_sums, int rank1) {
     // l1_sums != NULL (e3dgs_image_loss): d_img1 = scale * dSSIM/dimg + l1_scale * sign(img1 - img2) (per channel, or
     // on the gray values with the channel weights), and sum |img1 - img2| of the block goes to l1_sums[block]
     __shared__ float lds[3 * SS_INY * SS_SP];                    // patches, then (same LDS) the horizontal results
@@ -969,7 +1011,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimWin win, int C, int H
                 g += l1_scale * (float)((e > 0.0f) - (e < 0.0f));
             }
             size_t p = (size_t)y * W + x;
-            if (to_gray) { d_img1[p] = 0.299f * g; d_img1[HW + p] = 0.587f * g; d_img1[2 * HW + p] = 0.114f * g; }
+            if (to_gray && rank1) d_img1[p] = g;         // dL/dC = g * (0.299, 0.587, 0.114): the scalar field alone
+            else if (to_gray) { d_img1[p] = 0.299f * g; d_img1[HW + p] = 0.587f * g; d_img1[2 * HW + p] = 0.114f * g; }
             else d_img1[ch * HW + p] = g;
         }
     }
@@ -1030,7 +1073,7 @@ int e3_ssim_impl(int C, int H, int W, int to_gray, const float* img1, const floa
     ssim_finalize_kernel<<<dim3(1), dim3(WAVE), 0, s>>>((int)nb, (double)Ceff * H * W, sums, out_mean);
     if (d_img1)
         ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img1, img2, partial3, 1.0f / ((float)Ceff * H * W), d_img1,
-                                                   0.0f, nullptr);
+                                                   0.0f, nullptr, 0);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "ssim kernels");
 }
@@ -1041,8 +1084,9 @@ size_t e3_image_loss_scratch_bytes(int C, int H, int W) {
     return e3_ssim_scratch_bytes(C, H, W) + nb * sizeof(double) + 256;
 }
 int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, const float* img, const float* gt,
-                       float* scalars, float* d_img, char* scratch, hipStream_t s) {
+                       float* scalars, float* d_img, char* scratch, hipStream_t s, int rank1) {
     if (to_gray && C != 3) return e3_fail(hipErrorInvalidValue, "to_gray needs 3-channel inputs");
+    if (rank1 && !to_gray) return e3_fail(hipErrorInvalidValue, "a rank-1 pixel gradient needs the gray loss");
     if (!d_img || !scalars) return e3_fail(hipErrorInvalidValue, "scalars and d_img are required");
     const SsimWin win = ssim_window();
     const int Ceff = to_gray ? 1 : C;
@@ -1054,7 +1098,7 @@ int e3_image_loss_impl(int C, int H, int W, int to_gray, float lambda_dssim, con
     const float n = (float)Ceff * H * W;
     ssim_fwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img, gt, partial3, sums);
     ssim_bwd_kernel<<<grid, dim3(256), 0, s>>>(win, C, H, W, to_gray, img, gt, partial3, -lambda_dssim / n, d_img,
-                                               (1.0f - lambda_dssim) / n, l1_sums);
+                                               (1.0f - lambda_dssim) / n, l1_sums, rank1);
     image_loss_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>((int)nb, (double)n, lambda_dssim, sums, l1_sums, scalars);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "image loss kernels");

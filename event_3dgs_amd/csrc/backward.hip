@@ -11,6 +11,7 @@
 //                           (geom_bwd_multi_kernel: all views of an iteration in one pass).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef E3_BWD_WG_WAVES
 #define E3_BWD_WG_WAVES 4
@@ -35,22 +36,21 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 // FAST: the forward ran with E3DGS_FLAG_FAST_EXP -- its alpha is min(0.99, o v_exp_f32(power log2 e)), which this kernel
 // computes with the same instruction on the same bits: the forward's keep decisions are reproduced by one compare, without
 // the band logic the polynomial exp of the exact mode needs.
-template <bool STATS, bool FAST>
-__device__ __forceinline__ void render_bwd_body(
-    unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
-    int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
-    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
-    float* __restrict__ part /* (I,9) per-instance records at their SLOTS, packed: mx my A B C o c0 c1 c2 */,
-    const float* __restrict__ dL_dpix2 /* STATS: (3,H,W) second pixel gradient of view 0 */,
-    float* __restrict__ part2 /* STATS: (I,2) NDC-unit screen-space mean gradient under dL_dpix2, view-0 slots */,
-    const uint32_t* __restrict__ lpt_cnt /* order == NULL: the backward's per-class tile lists (ImageState::lpt_*) */,
-    const uint32_t* __restrict__ lpt_list, uint32_t lpt_cap) {
+// RANK1 (e3dgs_rasterize_backward_multi_rank1): the pixel gradient of this tile's view is s(pixel) * w with ONE weight
+// vector w per view -- what every loss on a luminance gives: the two contrast renders of an event iteration
+// (dL/dC = s (0.4124, 0.35758, 0.1804), utils/loss_utils.py:24-28,234-249) and every --gray loss (s (0.299, 0.587, 0.114),
+// :18-23,40-48).  Then c . dL/dC = (c . w) s, where c . w is per ENTRY (computed once at staging, lane-parallel), and the
+// three colour sums are w times ONE sum of alpha T s: one multiplication instead of three FMAs for the colour chain and
+// one FMA instead of three for the colour sums per evaluated (pixel, entry), seven values instead of nine through the
+// per-entry LDS transposition (no ninth-value chain: -2 ds_write, -1 ds_read, -3 DPP adds, -1 parked store per entry),
+// a third of the pixel-gradient loads.  Same record layout out (the commit lanes multiply the one sum by w).
+struct StagedRec { float4 a, b, c; };
+template <bool STATS>
+struct BwdShared {
     // the 64 staged records of a round, 48 B each: one LDS address per entry, the three 16-B broadcasts are immediate
     // offsets of it (three separate arrays cost two more address adds per entry); 48-B stride keeps the staging stores
     // conflict-free (8 lanes x 16 B per LDS cycle land on 32 distinct banks)
-    struct StagedRec { float4 a, b, c; };
-    __shared__ StagedRec sRec[BWD_WAVES][WAVE];
+    StagedRec sRec[BWD_WAVES][WAVE];
     // Gradient reduction through LDS.  DPP adds cost ~9 cycles per wave-instruction on this chip (plain adds 2.7),
     // so instead of a 54-op (or 26-op transposed) DPP butterfly the nine per-lane sums of an entry are transposed
     // through the wave's LDS slice: 9 conflict-free ds_write_b32, then lane (v,p) = (lane>>3, lane&7) reads the 8
@@ -58,9 +58,26 @@ __device__ __forceinline__ void render_bwd_body(
     // The LDS pipe is otherwise idle in this kernel.  Reduced sums are parked in sPart and committed every 16
     // entries by lanes 0..15 as three 16-byte stores into the instance's own record (no atomics: the per-Gaussian
     // sum over its instances happens in geom_bwd_kernel, in a fixed order -> deterministic gradients).
-    __shared__ __attribute__((aligned(16))) float sRed[BWD_WAVES][STATS ? 11 : 9][68];   // per-entry transpose buffer: [value][lane], rows padded to 68
-    __shared__ __attribute__((aligned(16))) float sPart[BWD_WAVES][16][16];     // [entry & 15][16 floats]: reduced sums parked until the commit
-    __shared__ float sPart2[STATS ? BWD_WAVES : 1][16][2];                      // STATS: the two extra sums of an entry
+    __attribute__((aligned(16))) float sRed[BWD_WAVES][STATS ? 11 : 9][68];   // per-entry transpose buffer: [value][lane], rows padded to 68
+    __attribute__((aligned(16))) float sPart[BWD_WAVES][16][16];     // [entry & 15][16 floats]: reduced sums parked until the commit
+    float sPart2[STATS ? BWD_WAVES : 1][16][2];                      // STATS: the two extra sums of an entry
+};
+// SLDS: the STATS flavour of the kernel's LDS block (a stats kernel runs the plain body in the tiles of its other views)
+template <bool SLDS, bool STATS, bool FAST, bool RANK1>
+__device__ __forceinline__ void render_bwd_body(
+    BwdShared<SLDS>& sh, const int tile,
+    unsigned long long* __restrict__ trace, int tiles_per_view, int gx,
+    int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
+    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
+    float* __restrict__ part /* (I,9) per-instance records at their SLOTS, packed: mx my A B C o c0 c1 c2 */,
+    const float* __restrict__ dL_dpix2 /* STATS: (3,H,W) second pixel gradient of view 0 */,
+    float* __restrict__ part2 /* STATS: (I,2) NDC-unit screen-space mean gradient under dL_dpix2, view-0 slots */,
+    const float rw0, const float rw1, const float rw2 /* RANK1: the view's weight vector (wave-uniform) */) {
+    auto& sRec = sh.sRec;
+    auto& sRed = sh.sRed;
+    auto& sPart = sh.sPart;
+    auto& sPart2 = sh.sPart2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4_t LdsF4;
@@ -70,11 +87,6 @@ __device__ __forceinline__ void render_bwd_body(
         (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)&sRec[wave][0].a.x);
     uint32_t recs_base_v = recs_base;
     asm volatile("" : "+v"(recs_base_v));       // the same address kept in a VGPR for the per-entry v_mad
-    const int unit = blockIdx.x * BWD_WAVES + wave;
-    if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
-    // global tile id (made scalar: see render_fwd_kernel)
-    const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[unit] : lpt_lookup(lpt_cnt, lpt_list, lpt_cap, (uint32_t)unit, lane));
-    if (tile < 0) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     const unsigned long long c_start = trace ? __builtin_readcyclecounter() : 0ull;     // s_memtime: shader cycles
     const int view = tile / tiles_per_view, ltile = tile - view * tiles_per_view;
@@ -107,10 +119,11 @@ __device__ __forceinline__ void render_bwd_body(
         size_t pix = (size_t)py * W + px;
         T[k] = inside ? final_T[pix] : 0.0f;
         last[k] = inside ? n_contrib[pix] : 0u;
-        dp0[k] = inside ? dL_dpix[pix] : 0.0f;
-        dp1[k] = inside ? dL_dpix[HW + pix] : 0.0f;
-        dp2[k] = inside ? dL_dpix[2 * HW + pix] : 0.0f;
-        Q[k] = T[k] * FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
+        dp0[k] = inside ? dL_dpix[pix] : 0.0f;              // RANK1: the scalar field s
+        dp1[k] = (!RANK1 && inside) ? dL_dpix[HW + pix] : 0.0f;
+        dp2[k] = (!RANK1 && inside) ? dL_dpix[2 * HW + pix] : 0.0f;
+        Q[k] = RANK1 ? T[k] * (FMA(bg0, rw0, FMA(bg1, rw1, bg2 * rw2)) * dp0[k])
+                     : T[k] * FMA(bg0, dp0[k], FMA(bg1, dp1[k], bg2 * dp2[k]));
         if (STATS) {
             dq0[k] = (sv && inside) ? dL_dpix2[pix] : 0.0f;
             dq1[k] = (sv && inside) ? dL_dpix2[HW + pix] : 0.0f;
@@ -150,6 +163,7 @@ __device__ __forceinline__ void render_bwd_body(
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
         rc.w = __uint_as_float(re);                 // the record's spare word carries the emission index (where its gradient record goes)
+        if (RANK1) rb.z = FMA(rb.z, rw0, FMA(rb.w, rw1, rc.x * rw2));      // colour . w of the entry, in the red slot
         sRec[wave][lane].a = ra; sRec[wave][lane].b = rb; sRec[wave][lane].c = rc;
         const uint32_t mvec = lane < cnt ? rm : 0u;
         wave_sync();
@@ -240,13 +254,15 @@ __device__ __forceinline__ void render_bwd_body(
                             // 1-ulp v_rcp_f32
                             const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
                             T[k] = T[k] * inv_one_m;                        // transmittance in front of this entry
-                            const float cd = FMA(b.z, dp0[k], FMA(b.w, dp1[k], c.x * dp2[k]));
+                            const float cd = RANK1 ? b.z * dp0[k] : FMA(b.z, dp0[k], FMA(b.w, dp1[k], c.x * dp2[k]));
                             const float w = alpha * T[k];
                             const float dL_dalpha = FMA(T[k], cd, -(Q[k] * inv_one_m));
                             Q[k] = FMA(w, cd, Q[k]);
-                            Sc0 = FMA(w, dp0[k], Sc0);
-                            Sc1 = FMA(w, dp1[k], Sc1);
-                            Sc2 = FMA(w, dp2[k], Sc2);
+                            Sc0 = FMA(w, dp0[k], Sc0);                      // RANK1: sum alpha T s (x w at the commit)
+                            if (!RANK1) {
+                                Sc1 = FMA(w, dp1[k], Sc1);
+                                Sc2 = FMA(w, dp2[k], Sc2);
+                            }
                             const float u = G * dL_dalpha;                  // straight-through min(0.99, .)
                             const float uy = u * dy;
                             So += u; Uy += uy;
@@ -268,7 +284,8 @@ __device__ __forceinline__ void render_bwd_body(
                     const float Sx = dx * So;                  // all of these still lack the factor o (commit)
                     r[0 * 68 + lane] = Sx;  r[1 * 68 + lane] = Uy;  r[2 * 68 + lane] = dx * Sx;
                     r[3 * 68 + lane] = dx * Uy; r[4 * 68 + lane] = Uyy; r[5 * 68 + lane] = So;
-                    r[6 * 68 + lane] = Sc0; r[7 * 68 + lane] = Sc1; r[8 * 68 + lane] = Sc2;
+                    r[6 * 68 + lane] = Sc0;
+                    if (!RANK1) { r[7 * 68 + lane] = Sc1; r[8 * 68 + lane] = Sc2; }
                     if (STATS && sv) { r[9 * 68 + lane] = dx * So2; r[10 * 68 + lane] = Uy2; }
                     wave_sync();
                     // lane (v, p) = (lane >> 3, lane & 7) adds the 8 floats [8p, 8p + 8) of value v (two ds_read_b128) and ONE
@@ -279,15 +296,18 @@ __device__ __forceinline__ void render_bwd_body(
                     const int rv = lane >> 3, rp = lane & 7;
                     const float4 q0 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp);
                     const float4 q1 = *reinterpret_cast<const float4*>(r + rv * 68 + 8 * rp + 4);
-                    float s8 = r[8 * 68 + lane];
+                    // (RANK1: seven values -- the lanes of rv == 7 add a stale row nobody reads, and there is no ninth value)
+                    float s8 = RANK1 ? 0.0f : r[8 * 68 + lane];
                     float s = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
-                    s += dpp_f<DPP_QUAD_XOR1>(s);  s8 += dpp_f<DPP_QUAD_XOR1>(s8);
-                    s += dpp_f<DPP_QUAD_XOR2>(s);  s8 += dpp_f<DPP_QUAD_XOR2>(s8);
-                    s += dpp_bc_f<DPP_ROW_SHL4>(s); s8 += dpp_bc_f<DPP_ROW_SHL4>(s8);  // lanes 0-3 / 8-11 of a row: + the next quad
-                    asm volatile("" : "+v"(s), "+v"(s8));     // keep the adds here (fused v_add_f32_dpp) instead of sunk behind the branch
+                    s += dpp_f<DPP_QUAD_XOR1>(s);  if (!RANK1) s8 += dpp_f<DPP_QUAD_XOR1>(s8);
+                    s += dpp_f<DPP_QUAD_XOR2>(s);  if (!RANK1) s8 += dpp_f<DPP_QUAD_XOR2>(s8);
+                    s += dpp_bc_f<DPP_ROW_SHL4>(s); if (!RANK1) s8 += dpp_bc_f<DPP_ROW_SHL4>(s8);  // lanes 0-3 / 8-11 of a row: + the next quad
+                    if (RANK1) asm volatile("" : "+v"(s));
+                    else asm volatile("" : "+v"(s), "+v"(s8));     // keep the adds here (fused v_add_f32_dpp) instead of sunk behind the branch
                     if (rp == 0) {                           // slots 0..7 = Sx Sy Sxx Sxy Syy So Sc0 Sc1, 8..15 = partials of Sc2
                         float* pe = reinterpret_cast<float*>(part_base_ptr + (size_t)(j & 15) * 16);
-                        pe[rv] = s; pe[8 + rv] = s8;
+                        pe[rv] = s;
+                        if (!RANK1) pe[8 + rv] = s8;
                     }
                     if (STATS && sv) {                       // rows 9, 10 (Sx', Sy'): the same 8-float reads + three DPP adds
                         const int rr = 9 + (rv & 1);
@@ -312,8 +332,11 @@ __device__ __forceinline__ void render_bwd_body(
                     const int e = jb + lane;
                     const float4* pp = reinterpret_cast<const float4*>(&sPart[wave][lane][0]);
                     float4 p0 = pp[0], p1 = pp[1];
-                    const float4 c0 = pp[2], c1 = pp[3];
-                    const float p2 = ((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w));
+                    float p2 = 0.0f;
+                    if (!RANK1) {
+                        const float4 c0 = pp[2], c1 = pp[3];
+                        p2 = ((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w));
+                    }
                     // p0 = (Sx, Sy, Sxx, Sxy) / o   p1 = (Syy / o, So, Sc0, Sc1)   p2 = Sc2
                     const float4 ea = sRec[wave][e].a;
                     const float4 eb = sRec[wave][e].b;
@@ -322,7 +345,7 @@ __device__ __forceinline__ void render_bwd_body(
                     // dG/d(delta) = -G (A dx + B dy, C dy + B dx); d(delta)/d(ndc) = (W/2, H/2)
                     g[0] = F3{-(ea.z * p0.x + ea.w * p0.y) * ddelx_dx, -(eb.x * p0.y + ea.w * p0.x) * ddely_dy, -0.5f * p0.z};
                     g[1] = F3{-p0.w, -0.5f * p1.x, p1.y};
-                    g[2] = F3{p1.z, p1.w, p2};
+                    g[2] = RANK1 ? F3{rw0 * p1.z, rw1 * p1.z, rw2 * p1.z} : F3{p1.z, p1.w, p2};
                     if (STATS && sv) {                       // the same mean2D formula on the second chain's sums
                         const float sx = sPart2[wave][lane][0] * eb.y, sy = sPart2[wave][lane][1] * eb.y;
                         float* g2 = part2 + 2 * (size_t)__float_as_uint(sRec[wave][e].c.w);
@@ -363,23 +386,59 @@ __device__ __forceinline__ void render_bwd_body(
         const float4 *__restrict__ rec, const float *__restrict__ bg, const float *__restrict__ final_T,                 \
         const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ perm,                                       \
         const uint8_t *__restrict__ strip_mask, const float *__restrict__ dL_dpix, float *__restrict__ part,             \
-        const uint32_t *__restrict__ lpt_cnt, const uint32_t *__restrict__ lpt_list, uint32_t lpt_cap
+        const uint32_t *__restrict__ lpt_cnt, const uint32_t *__restrict__ lpt_list, uint32_t lpt_cap, Rank1Views r1
 #define E3_RENDER_BWD_ARGS \
     trace, ntiles, tiles_per_view, order, gx, W, H, ranges, emit_gid, rec, bg, final_T, n_contrib, perm, strip_mask, dL_dpix, part
-// (two plain kernels around the one body: the profiles, the bench line and the reviews name `render_bwd_kernel`)
+// One wave = one tile: find it, then run the body its VIEW asks for (wave-uniform): the rank-1 body where the view's pixel
+// gradient is a scalar field times a weight vector, the general (STATS: second-chain) body otherwise.  Both share the LDS block.
+template <bool STATS, bool FAST, bool ANY_RANK1>
+__device__ __forceinline__ void render_bwd_dispatch(
+    unsigned long long* __restrict__ trace, int ntiles, int tiles_per_view, const uint32_t* __restrict__ order, int gx,
+    int W, int H, const uint2* __restrict__ ranges, const uint32_t* __restrict__ emit_gid,
+    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const uint32_t* __restrict__ perm, const uint8_t* __restrict__ strip_mask, const float* __restrict__ dL_dpix,
+    float* __restrict__ part, const float* __restrict__ dL_dpix2, float* __restrict__ part2,
+    const uint32_t* __restrict__ lpt_cnt, const uint32_t* __restrict__ lpt_list, uint32_t lpt_cap, const Rank1Views& r1) {
+    __shared__ BwdShared<STATS> sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * BWD_WAVES + wave;
+    if (unit >= ntiles) return;                 // ntiles = launch slots (see render_fwd_kernel)
+    // global tile id (made scalar: see render_fwd_kernel)
+    const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[unit] : lpt_lookup(lpt_cnt, lpt_list, lpt_cap, (uint32_t)unit, lane));
+    if (tile < 0) return;
+    if (ANY_RANK1) {
+        const int view = tile / tiles_per_view;
+        if ((r1.mask >> view) & 1u) {
+            render_bwd_body<STATS, false, FAST, true>(sh, tile, trace, tiles_per_view, gx, W, H, ranges, emit_gid, rec, bg, final_T,
+                                                      n_contrib, perm, strip_mask, dL_dpix, part, nullptr, nullptr,
+                                                      r1.w[view][0], r1.w[view][1], r1.w[view][2]);
+            return;
+        }
+    }
+    render_bwd_body<STATS, STATS, FAST, false>(sh, tile, trace, tiles_per_view, gx, W, H, ranges, emit_gid, rec, bg, final_T,
+                                               n_contrib, perm, strip_mask, dL_dpix, part, dL_dpix2, part2, 0.0f, 0.0f, 0.0f);
+}
+// (plain kernels around the one body: the profiles, the bench line and the reviews name `render_bwd_kernel`; the *_r1
+// variants are launched when some view of the call carries a rank-1 pixel gradient)
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(E3_RENDER_BWD_PARAMS) {
-    render_bwd_body<false, false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap);
+    render_bwd_dispatch<false, false, false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
 }
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_fast_kernel(E3_RENDER_BWD_PARAMS) {
-    render_bwd_body<false, true>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap);
+    render_bwd_dispatch<false, true, false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
+}
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_r1_kernel(E3_RENDER_BWD_PARAMS) {
+    render_bwd_dispatch<false, false, true>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
+}
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_r1_fast_kernel(E3_RENDER_BWD_PARAMS) {
+    render_bwd_dispatch<false, true, true>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
 }
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_kernel(
     E3_RENDER_BWD_PARAMS, const float* __restrict__ dL_dpix2, float* __restrict__ part2) {
-    render_bwd_body<true, false>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap);
+    render_bwd_dispatch<true, false, true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap, r1);
 }
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_fast_kernel(
     E3_RENDER_BWD_PARAMS, const float* __restrict__ dL_dpix2, float* __restrict__ part2) {
-    render_bwd_body<true, true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap);
+    render_bwd_dispatch<true, true, true>(E3_RENDER_BWD_ARGS, dL_dpix2, part2, lpt_cnt, lpt_list, lpt_cap, r1);
 }
 
 // ------------------------------------------------------------------------------------ per-Gaussian backward
@@ -1317,7 +1376,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                      const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                      float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s, float* dL_dcolour_views,
-                     const float* dL_dpix_stats) {
+                     const float* dL_dpix_stats, const Rank1Views* rank1) {
     (void)colors;
     if (P <= 0) return 0;
     const ViewSet vs = make_view_set(views, W, H, scale_modifier);
@@ -1345,15 +1404,23 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         // the caller provides E3_ACC_STRIDE = 12 floats per instance)
         float* part2 = grad_acc + E3_REC_FLOATS * (size_t)num_rendered;
         const bool fast = e3_call_opts(flags).fast_exp != 0;
+        Rank1Views r1;
+        memset(&r1, 0, sizeof r1);
+        if (rank1) r1 = *rank1;
+        r1.mask &= (1u << nv) - 1u;
         if (dL_dpix_stats)
             (fast ? render_bwd_stats_fast_kernel : render_bwd_stats_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
                 background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles,
-                dL_dpix_stats, part2);
+                r1, dL_dpix_stats, part2);
+        else if (r1.mask != 0u)
+            (fast ? render_bwd_r1_fast_kernel : render_bwd_r1_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
+                g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles, r1);
         else
             (fast ? render_bwd_fast_kernel : render_bwd_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles);
+                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles, r1);
     }
     KERNEL_OK("render_bwd_kernel");
     if (flags & E3_FLAG_BWD_ONLY_RENDER) return 0;

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 thread_local char g_err[512] = "";
 
@@ -33,40 +35,45 @@ CallOpts e3_call_opts(int flags) {
     return o;
 }
 
-// ---- event profiler.  State per HOST THREAD (enable / the timed calls / query belong to one thread; the event table is
-// allocated on that thread's first enable): a profiled trainer cannot race with calls another thread makes.
-thread_local bool g_prof_on = false;
-thread_local unsigned g_prof_mask = 0;
+// ---- event profiler.  PROCESS-WIDE state behind a mutex: torch runs the autograd nodes of a backward pass on its own
+// per-device worker thread, so a profiler enabled on the caller's thread must also time the kernels that thread
+// launches (round 4 kept the state per host thread and silently dropped render_bwd / geom_bwd under loss.backward()).
+// A scope reserves its event pair under the lock and closes exactly that pair, so scopes opened concurrently by several
+// threads (two trainers on two streams) cannot mix their events; the totals of a slot are then the sum over all threads.
+std::atomic<unsigned> g_prof_mask{0};
 namespace {
-struct ProfPair { hipEvent_t a, b; };
+struct ProfPair { hipEvent_t a, b; bool closed; };
 constexpr int PROF_MAX = 4096;
 struct ProfState {
     ProfPair pairs[PS_COUNT][PROF_MAX];
     int created[PS_COUNT] = {0}, used[PS_COUNT] = {0};
-    bool open[PS_COUNT] = {false};
 };
-thread_local ProfState* g_ps = nullptr;
+std::mutex g_prof_mu;
+ProfState* g_ps = nullptr;
 const char* g_names[PS_COUNT] = {"preprocess", "sort_depth", "scan_emit", "sort_tile", "tile_ranges", "render_fwd",
                                  "render_bwd", "geom_bwd"};
 }  // namespace
-void prof_begin(int slot, hipStream_t s) {
+int prof_begin(int slot, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     ProfState* P = g_ps;
-    if (!P) return;
-    int k = P->used[slot];
-    if (k >= PROF_MAX) return;
+    if (!P) return -1;
+    const int k = P->used[slot];
+    if (k >= PROF_MAX) return -1;
     if (k >= P->created[slot]) {
-        if (hipEventCreate(&P->pairs[slot][k].a) != hipSuccess || hipEventCreate(&P->pairs[slot][k].b) != hipSuccess) return;
+        if (hipEventCreate(&P->pairs[slot][k].a) != hipSuccess) return -1;
+        if (hipEventCreate(&P->pairs[slot][k].b) != hipSuccess) { (void)hipEventDestroy(P->pairs[slot][k].a); return -1; }
         P->created[slot] = k + 1;
     }
-    (void)hipEventRecord(P->pairs[slot][k].a, s);
-    P->open[slot] = true;
+    P->pairs[slot][k].closed = false;
+    if (hipEventRecord(P->pairs[slot][k].a, s) != hipSuccess) return -1;
+    P->used[slot] = k + 1;
+    return k;
 }
-void prof_end(int slot, hipStream_t s) {
+void prof_end(int slot, int k, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     ProfState* P = g_ps;
-    if (!P || !P->open[slot]) return;
-    (void)hipEventRecord(P->pairs[slot][P->used[slot]].b, s);
-    P->used[slot]++;
-    P->open[slot] = false;
+    if (!P || k < 0 || k >= P->used[slot]) return;      // (the profiler was reset while the scope was open)
+    if (hipEventRecord(P->pairs[slot][k].b, s) == hipSuccess) P->pairs[slot][k].closed = true;
 }
 
 int e3_mark_visible_impl(int, const float*, const float*, uint8_t*, hipStream_t);
@@ -75,14 +82,14 @@ int e3_knn_impl(int, const float*, float*, char*, hipStream_t);
 size_t e3_event_scratch_bytes(int, int);
 int e3_event_loss_impl(int, int, const float*, const float*, const float*, const float*, const float*, const float*,
                        const float*, const float*, float, float*, float*, float*, float*, char*, hipStream_t, float*, double*,
-                       int);
+                       int, int rank1 = 0);
 size_t e3_ssim_scratch_bytes(int, int, int);
 int e3_ssim_impl(int, int, int, int, const float*, const float*, float*, float*, char*, hipStream_t);
 int e3_adam_segments_impl(size_t, float*, const float*, float*, float*, int, const size_t*, const float*, const float*, float,
                           float, int, const int*, hipStream_t, size_t gap_begin = 0, size_t gap_len = 0);
 int e3_densify_stats_impl(int, const float*, const int*, float*, float*, float*, hipStream_t);
 size_t e3_image_loss_scratch_bytes(int, int, int);
-int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t);
+int e3_image_loss_impl(int, int, int, int, float, const float*, const float*, float*, float*, char*, hipStream_t, int rank1 = 0);
 int e3_adam_impl(size_t, float*, const float*, float*, float*, float, float, float, float, int, float, int, int,
                  hipStream_t);
 size_t e3_densify_scratch_bytes(int);
@@ -94,7 +101,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 15; }
+int e3dgs_abi_version(void) { return 16; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -381,9 +388,22 @@ static int backward_multi(int nviews, int P, int D, int M, int num_rendered, con
                           const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
                           float* grad_acc, float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D,
                           float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug,
-                          int flags, void* stream, const float* dL_dpix_view0_stats) {
+                          int flags, void* stream, const float* dL_dpix_view0_stats, const float* rank1_weights = nullptr,
+                          unsigned rank1_mask = 0u) {
     g_err[0] = 0;
     ViewBatch vb;
+    Rank1Views r1;
+    memset(&r1, 0, sizeof r1);
+    if (rank1_mask != 0u) {
+        if (!rank1_weights) return e3_fail(hipErrorInvalidValue, "rank1_mask without rank1_weights");
+        if (nviews >= 1 && nviews <= E3_MAX_VIEWS && (rank1_mask >> nviews) != 0u)
+            return e3_fail(hipErrorInvalidValue, "rank1_mask names a view beyond nviews");
+        if (dL_dpix_view0_stats && (rank1_mask & 1u))
+            return e3_fail(hipErrorInvalidValue, "view 0 carries the second gradient chain: it cannot be rank 1");
+        r1.mask = rank1_mask;
+        for (int v = 0; v < nviews && v < E3_MAX_VIEWS; ++v)
+            for (int k = 0; k < 3; ++k) r1.w[v][k] = rank1_weights[3 * v + k];
+    }
     int rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
     if (rc) return rc;
     if (P > 0 && (!shs || !scales || !rotations)) return e3_fail(hipErrorInvalidValue, "shs + scales + rotations are required");
@@ -402,7 +422,8 @@ static int backward_multi(int nviews, int P, int D, int M, int num_rendered, con
     return e3_backward_impl(vb, P, D, M, num_rendered, background, width, height, means3D, shs, nullptr, opacities,
                             scales, scale_modifier, rotations, nullptr, radii, geom_buffer, binning_buffer, image_buffer,
                             dL_dpix, grad_acc, dL_dmean2D, dL_dopacity, nullptr, dL_dmean3D, nullptr, dL_dsh, dL_dscale,
-                            dL_drot, debug, flags, (hipStream_t)stream, dL_dcolour_views, dL_dpix_view0_stats);
+                            dL_drot, debug, flags, (hipStream_t)stream, dL_dcolour_views, dL_dpix_view0_stats,
+                            rank1_mask != 0u ? &r1 : nullptr);
 }
 
 int e3dgs_rasterize_backward_multi(int nviews, int P, int D, int M, int num_rendered, const float* background,
@@ -437,6 +458,25 @@ int e3dgs_rasterize_backward_multi_stats(int nviews, int P, int D, int M, int nu
                           geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D, dL_dopacity,
                           dL_dmean3D, dL_dsh, dL_dscale, dL_drot, dL_dcolour_views, debug, flags, stream,
                           dL_dpix_view0_stats);
+}
+
+int e3dgs_rasterize_backward_multi_rank1(int nviews, int P, int D, int M, int num_rendered, const float* background,
+                                         int width, int height, const float* means3D, const float* shs,
+                                         const float* opacities, const float* scales, float scale_modifier,
+                                         const float* rotations, const float* const* viewmatrix,
+                                         const float* const* projmatrix, const float* const* cam_pos,
+                                         const float* tan_fovx, const float* tan_fovy, const int* radii,
+                                         const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                                         const float* dL_dpix, const float* dL_dpix_view0_stats,
+                                         const float* rank1_weights, unsigned rank1_mask, float* grad_acc,
+                                         float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D, float* dL_dsh,
+                                         float* dL_dscale, float* dL_drot, float* dL_dcolour_views, int debug, int flags,
+                                         void* stream) {
+    return backward_multi(nviews, P, D, M, num_rendered, background, width, height, means3D, shs, opacities, scales,
+                          scale_modifier, rotations, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+                          geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_acc, dL_dmean2D, dL_dopacity,
+                          dL_dmean3D, dL_dsh, dL_dscale, dL_drot, dL_dcolour_views, debug, flags, stream,
+                          dL_dpix_view0_stats, rank1_weights, rank1_mask);
 }
 
 int e3dgs_sh_grad_from_colour(int P, int nranks, int views_per_rank, int D, int M, const float* means3D,
@@ -553,6 +593,16 @@ int e3dgs_event_loss_cached(int width, int height, const float* image, const flo
                               d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream, dc_out, nz_count, nz_valid);
 }
 
+int e3dgs_event_loss_rank1(int width, int height, const float* image, const float* img_now, const float* img_next,
+                           const float* gt_int, const float* gt_now, const float* gt_next, const float* gt_blur,
+                           const float* c, float gt_c, float* d_image, float* d_now, float* d_next, float* scalars_out,
+                           float* dc_out, double* nz_count, int nz_valid, char* scratch, void* stream) {
+    g_err[0] = 0;
+    return e3_event_loss_impl(width, height, image, img_now, img_next, gt_int, gt_now, gt_next, gt_blur, c, gt_c,
+                              d_image, d_now, d_next, scalars_out, scratch, (hipStream_t)stream, dc_out, nz_count,
+                              nz_count ? nz_valid : 0, 1);
+}
+
 size_t e3dgs_ssim_scratch_bytes(int channels, int height, int width) { return e3_ssim_scratch_bytes(channels, height, width); }
 int e3dgs_ssim(int channels, int height, int width, int to_gray, const float* img1, const float* img2, float* ssim_mean,
                float* d_img1, char* scratch, void* stream) {
@@ -604,6 +654,14 @@ int e3dgs_image_loss(int channels, int height, int width, int to_gray, float lam
     if (channels <= 0 || height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
     return e3_image_loss_impl(channels, height, width, to_gray, lambda_dssim, image, gt_image, scalars, d_image, scratch,
                               (hipStream_t)stream);
+}
+
+int e3dgs_image_loss_rank1(int height, int width, float lambda_dssim, const float* image, const float* gt_image,
+                           float* scalars, float* d_gray, char* scratch, void* stream) {
+    g_err[0] = 0;
+    if (height <= 0 || width <= 0) return e3_fail(hipErrorInvalidValue, "bad sizes");
+    return e3_image_loss_impl(3, height, width, 1, lambda_dssim, image, gt_image, scalars, d_gray, scratch,
+                              (hipStream_t)stream, 1);
 }
 
 int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
@@ -674,31 +732,35 @@ void e3dgs_set_small_scene_paths(int on) { g_small_scene_paths = on ? 1 : 0; }
 int e3dgs_get_small_scene_paths(void) { return g_small_scene_paths; }
 
 void e3dgs_profile_enable(int slot_mask) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (slot_mask != 0 && !g_ps) g_ps = new ProfState();
-    g_prof_mask = (unsigned)slot_mask;
-    g_prof_on = slot_mask != 0;
-    if (g_ps) for (int i = 0; i < PS_COUNT; ++i) { g_ps->used[i] = 0; g_ps->open[i] = false; }
+    if (g_ps) for (int i = 0; i < PS_COUNT; ++i) g_ps->used[i] = 0;
+    g_prof_mask.store((unsigned)slot_mask, std::memory_order_relaxed);
 }
 void e3dgs_profile_select(int slot_mask) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (slot_mask != 0 && !g_ps) g_ps = new ProfState();
-    g_prof_mask = (unsigned)slot_mask;
-    g_prof_on = slot_mask != 0;
+    g_prof_mask.store((unsigned)slot_mask, std::memory_order_relaxed);
 }
 int e3dgs_profile_query(int slot, double* total_ms, int* launches) {
     if (slot < 0 || slot >= PS_COUNT) return -1;
     double t = 0.0;
+    int n = 0;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     ProfState* P = g_ps;
     const int used = P ? P->used[slot] : 0;
     for (int k = 0; k < used; ++k) {
+        if (!P->pairs[slot][k].closed) continue;
         hipError_t e = hipEventSynchronize(P->pairs[slot][k].b);
         if (e != hipSuccess) return e3_fail(e, "profile event sync");
         float ms = 0.0f;
         e = hipEventElapsedTime(&ms, P->pairs[slot][k].a, P->pairs[slot][k].b);
         if (e != hipSuccess) return e3_fail(e, "profile elapsed");
         t += ms;
+        ++n;
     }
     *total_ms = t;
-    *launches = used;
+    *launches = n;
     return 0;
 }
 const char* e3dgs_profile_slot_name(int slot) { return (slot >= 0 && slot < PS_COUNT) ? g_names[slot] : ""; }

@@ -79,8 +79,10 @@ __device__ __forceinline__ float exp_det_noclamp(float x) {
 // rasteriser fed raw parameters is bit-identical to the oracle fed gso_activate()'s values (radii, lists, image), exactly
 // as the operator fed activated values is.  (libm-style expf differs from torch's by <= 1 ulp, which is enough to flip a
 // radius or an alpha threshold at a handful of Gaussians per million.)
-__device__ __forceinline__ float act_exp(float x) { return exp_det(x); }
-__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + exp_det(-x)); }
+// NaN in -> NaN out, as torch.exp / torch.sigmoid: exp_det()'s underflow clamp fmaxf(t, -126) would swallow a NaN (a
+// diverged opacity logit would render as opacity 1.0, a NaN log-scale as ~1e-38 -- finite values instead of a NaN loss).
+__device__ __forceinline__ float act_exp(float x) { const float r = exp_det(x); return x != x ? x : r; }
+__device__ __forceinline__ float act_sigmoid(float x) { const float r = 1.0f / (1.0f + exp_det(-x)); return x != x ? x : r; }
 __device__ __forceinline__ void act_load_scale_rot(const float* __restrict__ s3, const float* __restrict__ q4, bool preact,
                                                    float s[3], float q[4], float& qinv) {
     s[0] = s3[0]; s[1] = s3[1]; s[2] = s3[2];
@@ -396,6 +398,13 @@ static inline ViewSet make_view_set(const ViewBatch& b, int W, int H, float scal
     return vs;
 }
 
+// Views whose pixel gradient is rank 1: dL/dC(pixel) = s(pixel) * w with one weight vector per view (a loss on a luminance:
+// the contrast renders of an event iteration, every --gray loss).  render_bwd_body<RANK1> in backward.hip.
+struct Rank1Views {
+    float w[E3_MAX_VIEWS][3];   // weight vector of a rank-1 view
+    uint32_t mask;              // bit v: view v's pixel gradient is plane 0 of its (3, H, W) block times w[v]
+};
+
 // the options of one call, resolved from its flags word (capi.hip holds the process-wide defaults)
 struct CallOpts {
     int cull;          // 0: reference rectangle binning, 1: exact culling, 3: exact culling without the tight box
@@ -430,7 +439,8 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                      const char* image_buffer, const float* dL_dpix, float* grad_acc, float* dL_dmean2D,
                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                      float* dL_dscale, float* dL_drot, int debug, int flags, hipStream_t s,
-                     float* dL_dcolour_views = nullptr, const float* dL_dpix_stats = nullptr);
+                     float* dL_dcolour_views = nullptr, const float* dL_dpix_stats = nullptr,
+                     const struct Rank1Views* rank1 = nullptr);
 int e3_sh_grad_views_impl(int P, int nranks, int views_per_rank, int D, int M, const float* means3D, const float* packed,
                           size_t rank_stride, float scale, float* dL_dsh, int flags, hipStream_t s);
 
@@ -474,12 +484,14 @@ static inline int radix_passes(int nbits) { return (nbits + 7) / 8; }
 // ---------------------------------------------------------------- optional event profiler (capi.hip)
 enum ProfSlot { PS_PREPROCESS = 0, PS_SORT_DEPTH, PS_SCAN_EMIT, PS_SORT_TILE, PS_RANGES, PS_RENDER_FWD, PS_RENDER_BWD,
                 PS_GEOM_BWD, PS_COUNT };
-extern thread_local bool g_prof_on;        // (per host thread: a profiled trainer does not race with another thread's calls)
-extern thread_local unsigned g_prof_mask;
-void prof_begin(int slot, hipStream_t s);
-void prof_end(int slot, hipStream_t s);
+#include <atomic>
+extern std::atomic<unsigned> g_prof_mask;  // slots being timed (0: off); process-wide -- autograd's worker threads are timed too
+int prof_begin(int slot, hipStream_t s);   // -> index of the reserved event pair, or -1
+void prof_end(int slot, int pair, hipStream_t s);
 struct ProfScope {
-    int slot; hipStream_t s;
-    ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_) { if (g_prof_on && ((g_prof_mask >> slot) & 1u)) prof_begin(slot, s); }
-    ~ProfScope() { if (g_prof_on && ((g_prof_mask >> slot) & 1u)) prof_end(slot, s); }
+    int slot, pair; hipStream_t s;
+    ProfScope(int slot_, hipStream_t s_) : slot(slot_), pair(-1), s(s_) {
+        if ((g_prof_mask.load(std::memory_order_relaxed) >> slot) & 1u) pair = prof_begin(slot, s);
+    }
+    ~ProfScope() { if (pair >= 0) prof_end(slot, pair, s); }
 };

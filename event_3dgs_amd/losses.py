@@ -77,14 +77,17 @@ class PairCounts:
 
 
 def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur=None, gt_c=0.17, out=None, dc_out=None,
-                   pair_counts=None):
+                   pair_counts=None, rank1=False):
     """Direct call of e3dgs_event_loss (no autograd; pair_counts: a PairCounts instance -> e3dgs_event_loss_cached, one
     sweep over the images from the second time a ground-truth pair is met, bit-identical results).  Returns (scalars[8], d_image, d_now, d_next):
     scalars[0] = loss, [1] = dL/dc, [2] = rho, [3..5] = L1 event / intensity / blur.  `out` may carry
     preallocated (scalars, d_image, d_now, d_next, scratch) tensors to reuse across steps; `dc_out`: a one-element
     device tensor that also receives dL/dc (the threshold's slot of a flat gradient buffer).
     Shared render (image IS img_now): with d_now IS d_image the sum of the two gradients is stored; with separate
-    outputs d_now receives the sum and d_image the intensity term's part alone (include/e3dgs_hip.h)."""
+    outputs d_now receives the sum and d_image the intensity term's part alone (include/e3dgs_hip.h).
+    rank1: e3dgs_event_loss_rank1 -- d_next, and d_now when it is a render of its own, receive in plane 0 the scalar field
+    s with dL/dC = s * (0.4124, 0.35758, 0.1804) (rasterizer.LUV_WEIGHTS; the input of backward_multi(rank1=...)); their
+    planes 1 and 2 are left as they are."""
     L = _lib.lib()
     dev = image.device
     _, H, W = image.shape
@@ -101,13 +104,17 @@ def event_loss_raw(image, img_now, img_next, c, gt_int, gt_now, gt_next, gt_blur
             _lib.ptr(d_next), _lib.ptr(scalars), _lib.ptr(dc_out))
     with torch.cuda.device(dev):
         if pair_counts is None:
-            rc = L.e3dgs_event_loss(*head, _lib.ptr(scratch), _lib.current_stream())
+            if rank1:
+                rc = L.e3dgs_event_loss_rank1(*head, None, 0, _lib.ptr(scratch), _lib.current_stream())
+            else:
+                rc = L.e3dgs_event_loss(*head, _lib.ptr(scratch), _lib.current_stream())
         else:
             cnt = pair_counts.lookup(gt_now, gt_next, gt_c)
             valid = cnt is not None
             if not valid:
                 cnt = torch.zeros(1, dtype=torch.float64, device=dev)
-            rc = L.e3dgs_event_loss_cached(*head, _lib.ptr(cnt), int(valid), _lib.ptr(scratch), _lib.current_stream())
+            fn = L.e3dgs_event_loss_rank1 if rank1 else L.e3dgs_event_loss_cached
+            rc = fn(*head, _lib.ptr(cnt), int(valid), _lib.ptr(scratch), _lib.current_stream())
             if rc == 0 and not valid:
                 pair_counts.remember(gt_now, gt_next, gt_c, cnt)
     _lib.check(rc, "e3dgs_event_loss")
@@ -193,10 +200,12 @@ class _SSIM(torch.autograd.Function):
         return (d * g).reshape(ctx.shape) if d is not None else None, None, None
 
 
-def image_loss_raw(image, gt_image, gray, lambda_dssim=0.2, out=None):
+def image_loss_raw(image, gt_image, gray, lambda_dssim=0.2, out=None, rank1=False):
     """e3dgs_image_loss: (1 - lambda) L1 + lambda (1 - SSIM) of the --gray (train.py:213-223) or RGB (train.py:292-296)
     iteration and its gradient w.r.t. `image`, three launches, no autograd.  Returns (scalars[4], d_image): scalars[0] =
-    loss, [1] = L1, [2] = SSIM.  `out` may carry preallocated (scalars, d_image, scratch)."""
+    loss, [1] = L1, [2] = SSIM.  `out` may carry preallocated (scalars, d_image, scratch).
+    rank1 (gray only): e3dgs_image_loss_rank1 -- plane 0 of d_image receives the scalar field s with
+    d loss / d image = s * (0.299, 0.587, 0.114) (rasterizer.GRAY_WEIGHTS); planes 1 and 2 are left as they are."""
     L = _lib.lib()
     for t in (image, gt_image):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
@@ -206,9 +215,15 @@ def image_loss_raw(image, gt_image, gray, lambda_dssim=0.2, out=None):
         out = (torch.empty(4, dtype=torch.float32, device=image.device), torch.empty_like(image),
                torch.empty(L.e3dgs_image_loss_scratch_bytes(C_, H, W), dtype=torch.uint8, device=image.device))
     scalars, d_image, scratch = out
+    if rank1 and not (gray and C_ == 3):
+        raise ValueError("a rank-1 image gradient needs the gray loss of a 3-channel render")
     with torch.cuda.device(image.device):
-        rc = L.e3dgs_image_loss(C_, H, W, int(bool(gray)), float(lambda_dssim), _lib.ptr(image), _lib.ptr(gt_image),
-                                _lib.ptr(scalars), _lib.ptr(d_image), _lib.ptr(scratch), _lib.current_stream())
+        if rank1:
+            rc = L.e3dgs_image_loss_rank1(H, W, float(lambda_dssim), _lib.ptr(image), _lib.ptr(gt_image),
+                                          _lib.ptr(scalars), _lib.ptr(d_image), _lib.ptr(scratch), _lib.current_stream())
+        else:
+            rc = L.e3dgs_image_loss(C_, H, W, int(bool(gray)), float(lambda_dssim), _lib.ptr(image), _lib.ptr(gt_image),
+                                    _lib.ptr(scalars), _lib.ptr(d_image), _lib.ptr(scratch), _lib.current_stream())
     _lib.check(rc, "e3dgs_image_loss")
     return scalars, d_image
 

@@ -635,14 +635,20 @@ def forward_multi(means3D, sh, opacities, scales, rotations, settings_list, flag
     return forward_multi_finish(pend)
 
 
-def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None, stats_grad_view0=None):
+LUV_WEIGHTS = (0.4124, 0.35758, 0.1804)     # rgb_to_LUVscale, utils/loss_utils.py:24-28 (the event contrast renders)
+GRAY_WEIGHTS = (0.299, 0.587, 0.114)        # rgb_to_grayscale, utils/loss_utils.py:18-23 (the --gray losses)
+
+
+def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None, stats_grad_view0=None, rank1=None):
     """e3dgs_rasterize_backward_multi for a forward_multi result.  grad_out_color is (n,3,H,W); `out` maps
     means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are fully overwritten
     with the gradient summed over the views.  Optional `colour_views` (n,P,3): the per-view clamp-masked colour
     gradients (then `sh` may be omitted; see sh_grad_from_colour).
     stats_grad_view0 (3,H,W): e3dgs_rasterize_backward_multi_stats -- out["means2D"] is the screen-space gradient view 0
     has under THAT pixel gradient, everything else follows grad_out_color (shared-pose iterations that collect
-    densification statistics)."""
+    densification statistics).
+    rank1: {view index: (w0, w1, w2)} -- e3dgs_rasterize_backward_multi_rank1: the pixel gradient of those views is
+    grad_out_color[v, 0] * w (planes 1, 2 of the view are not read): a loss on a luminance of the render."""
     L = _lib.lib()
     rs = raw["settings"]
     sl = raw["settings_list"]
@@ -675,13 +681,24 @@ def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None, stats_gr
             _lib.ptr(out.get("means3D")), _lib.ptr(out.get("sh")), _lib.ptr(out.get("scales")),
             _lib.ptr(out.get("rots")), _lib.ptr(out.get("colour_views")), int(bool(rs.debug)), int(flags),
             _lib.current_stream())
+    g2 = stats_grad_view0
+    if g2 is not None and not (g2.is_cuda and g2.dtype == torch.float32 and g2.is_contiguous()
+                               and tuple(g2.shape) == (3, H, W)):
+        raise ValueError("stats_grad_view0 must be a contiguous fp32 (3,H,W) GPU tensor")
     with torch.cuda.device(dev):
-        if stats_grad_view0 is None:
+        if rank1:
+            import ctypes as C
+            wts = (C.c_float * (3 * len(sl)))()
+            mask = 0
+            for v, w in rank1.items():
+                if not 0 <= int(v) < len(sl):
+                    raise ValueError("rank1 names a view the call does not have")
+                mask |= 1 << int(v)
+                wts[3 * int(v)], wts[3 * int(v) + 1], wts[3 * int(v) + 2] = (float(x) for x in w)
+            rc = L.e3dgs_rasterize_backward_multi_rank1(*head, _lib.ptr(g), _lib.ptr(g2), wts, mask, *tail)
+        elif g2 is None:
             rc = L.e3dgs_rasterize_backward_multi(*head, _lib.ptr(g), *tail)
         else:
-            g2 = stats_grad_view0
-            if not (g2.is_cuda and g2.dtype == torch.float32 and g2.is_contiguous() and tuple(g2.shape) == (3, H, W)):
-                raise ValueError("stats_grad_view0 must be a contiguous fp32 (3,H,W) GPU tensor")
             rc = L.e3dgs_rasterize_backward_multi_stats(*head, _lib.ptr(g), _lib.ptr(g2), *tail)
     _lib.check(rc, "e3dgs_rasterize_backward_multi")
 

@@ -24,19 +24,31 @@ from . import _lib, losses, parallel, rasterizer
 from .rasterizer import GaussianRasterizationSettings, rasterize_gaussians
 
 
-def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
-    """utils/general_utils.py:29-62"""
-    def helper(step):
-        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+class ExponentialLR:
+    """The position learning-rate schedule (utils/general_utils.py:29-62 `get_expon_lr_func`; golden G7): geometric
+    interpolation lr_init -> lr_final over max_steps, times an optional warm-up factor that eases from delay_mult to 1
+    over delay_steps along a quarter sine.  Held as (log lr_init, log ratio), evaluated in float64 with math.*."""
+
+    def __init__(self, lr_init, lr_final, delay_steps=0, delay_mult=1.0, max_steps=1000000):
+        self.off = lr_init == 0.0 and lr_final == 0.0
+        self.log0 = math.log(lr_init) if lr_init > 0.0 else -math.inf
+        self.log1 = math.log(lr_final) if lr_final > 0.0 else -math.inf
+        self.delay_steps, self.delay_mult, self.max_steps = delay_steps, delay_mult, max_steps
+
+    def __call__(self, step):
+        if step < 0 or self.off:
             return 0.0
-        if lr_delay_steps > 0:
-            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-        else:
-            delay_rate = 1.0
-        t = np.clip(step / max_steps, 0, 1)
-        log_lerp = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
-        return delay_rate * log_lerp
-    return helper
+        frac = min(max(step / self.max_steps, 0.0), 1.0)
+        rate = math.exp(self.log0 * (1.0 - frac) + self.log1 * frac)
+        if self.delay_steps > 0:
+            ease = math.sin(0.5 * math.pi * min(max(step / self.delay_steps, 0.0), 1.0))
+            rate *= self.delay_mult + (1.0 - self.delay_mult) * ease
+        return rate
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """The reference's constructor name and keywords (utils/general_utils.py:47) for ExponentialLR."""
+    return ExponentialLR(lr_init, lr_final, lr_delay_steps, lr_delay_mult, max_steps)
 
 
 # (name, floats per Gaussian) in flat-buffer order
@@ -150,6 +162,11 @@ class EventTrainer:
         self.no_host_wait = os.environ.get("E3DGS_NO_HOST_WAIT", "1") != "0"
         # render #1 == render #2 of an event iteration (same pose) rendered once: see compute_gradients()
         self.share_coincident_views = os.environ.get("E3DGS_SHARE_VIEWS", "1") != "0"
+        # The pixel gradient of a render that only enters the loss through a luminance is rank 1: s(pixel) * w.  The two
+        # contrast renders of an event iteration (rgb_to_LUVscale) and the --gray iteration (rgb_to_grayscale) are: the loss
+        # kernels hand the scalar field s to the compositing backward, which then runs one colour chain and seven sums per
+        # (pixel, entry) instead of three and nine (e3dgs_rasterize_backward_multi_rank1).  E3DGS_RANK1=0: general form.
+        self.rank1 = os.environ.get("E3DGS_RANK1", "1") != "0"
         self.shared_pose_iterations = 0
         self._share_stats_on = False
         self._coincide = {}
@@ -705,7 +722,14 @@ class EventTrainer:
             d_int = self._dstat
         scalars, _, _, _ = losses.event_loss_raw(imgs[0], imgs[i_now], imgs[i_next], self.c, gt_int, gt_now, gt_next, gt_blur,
                                                  out=(sc, d_int, dpix[i_now], dpix[i_next], scratch),
-                                                 dc_out=self.c_grad, pair_counts=self._pair_counts)                    # train.py:165-203
+                                                 dc_out=self.c_grad, pair_counts=self._pair_counts,
+                                                 rank1=self.rank1)                                                     # train.py:165-203
+        # (rank 1: the contrast renders that are renders of their own -- `next`, and `now` unless it shares render #1's pose)
+        r1 = None
+        if self.rank1:
+            r1 = {i_next: rasterizer.LUV_WEIGHTS}
+            if not shared:
+                r1[i_now] = rasterizer.LUV_WEIGHTS
         # (image and img_now are the same tensor, the outputs are not: the kernel stored the sum in dpix[0], d_int alone)
         # ---- loss.backward() (train.py:211): every gradient element is written exactly once
         g = self.grads
@@ -717,7 +741,7 @@ class EventTrainer:
         if want_vs:
             out["means2D"] = self.viewspace_grad            # densification statistics use render #1 only (train.py:145)
         rasterizer.backward_multi(raw, dpix, out, flags=self._backward_flags(raw, sh_via_colour),
-                                  stats_grad_view0=d_int if (shared and want_vs) else None)
+                                  stats_grad_view0=d_int if (shared and want_vs) else None, rank1=r1)
         return scalars, raw
 
     def _compute_gradients_separate(self, settings, gt_int, gt_now, gt_next, gt_blur):
@@ -975,7 +999,8 @@ class EventTrainer:
         _, sc, dpix, scratch = self._loss_bufs
         # (1 - lambda) L1 + lambda (1 - SSIM) and its image gradient, fused (gray: both terms on rgb_to_grayscale,
         # utils/loss_utils.py:18-23,40-48,368-385; RGB: :270-271,388-396)
-        losses.image_loss_raw(img, gt, mode == "gray", lambda_dssim, out=(sc, dpix[0], scratch))
+        r1 = self.rank1 and mode == "gray" and C == 3
+        losses.image_loss_raw(img, gt, mode == "gray", lambda_dssim, out=(sc, dpix[0], scratch), rank1=r1)
         loss = sc[0]
         g = self.grads
         out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
@@ -984,7 +1009,8 @@ class EventTrainer:
         self._packed_views = 0
         if self.factorize_sh or sh_via_colour:     # as in the event iteration, with one view: 3 floats per Gaussian are
             self._colour_gradients_instead_of_sh(out, settings)      # exchanged / kept instead of the 48 of the SH gradient
-        rasterizer.backward_multi(raw, dpix, out, flags=self._backward_flags(raw, sh_via_colour))
+        rasterizer.backward_multi(raw, dpix, out, flags=self._backward_flags(raw, sh_via_colour),
+                                  rank1={0: rasterizer.GRAY_WEIGHTS} if r1 else None)
         return loss, raw
 
     def step_image_autograd(self, cam, gt_image, bg, mode="gray", lambda_dssim=0.2):

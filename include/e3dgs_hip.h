@@ -336,6 +336,36 @@ int e3dgs_rasterize_backward_multi_stats(
     int debug, int flags, void* stream);
 
 /*
+ * The same backward when the pixel gradient of some views is RANK 1 (ABI 16): dL/dC(pixel) = s(pixel) * w with one
+ * weight vector w per view.  That is what every loss on a luminance produces: the two contrast renders of an event
+ * iteration (differentialable_event_simu -> rgb_to_LUVscale: w = (0.4124, 0.35758, 0.1804), utils/loss_utils.py:24-28,
+ * 234-249, train.py:159-176) and the --gray losses (rgb_to_grayscale: w = (0.299, 0.587, 0.114), :18-23,40-48,
+ * train.py:213-223).  For a view v with bit v of rank1_mask set, only plane 0 of its (3,H,W) block of dL_dpix is read --
+ * the scalar field s -- and rank1_weights[3 v .. 3 v + 2] (HOST array, nviews x 3) is w.  The compositing backward then
+ * carries one colour chain and seven sums per (pixel, entry) instead of three and nine; outputs as for
+ * e3dgs_rasterize_backward_multi (equal to the general call on s * w up to fp32 summation order).
+ * dL_dpix_view0_stats may be NULL (then dL_dmean2D follows dL_dpix as in e3dgs_rasterize_backward_multi); with it, view 0
+ * carries the second gradient chain and cannot be rank 1.
+ */
+int e3dgs_rasterize_backward_multi_rank1(
+    int nviews, int P, int D, int M, int num_rendered,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations,
+    const float* const* viewmatrix, const float* const* projmatrix, const float* const* cam_pos,
+    const float* tan_fovx, const float* tan_fovy,
+    const int* radii,
+    const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    const float* dL_dpix,             /* (nviews,3,H,W); rank-1 views: plane 0 = s, planes 1-2 not read */
+    const float* dL_dpix_view0_stats, /* (3,H,W) or NULL */
+    const float* rank1_weights,       /* host (nviews,3) */
+    unsigned rank1_mask,
+    float* grad_acc,
+    float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    float* dL_dcolour_views,
+    int debug, int flags, void* stream);
+
+/*
  * SH gradient from per-view colour gradients:  dL/dsh[k][ch] = scale * sum over all views of
  * Y_k(direction from the view's camera centre to the Gaussian) * dL/dcolour_view[ch].
  * New capability for view-parallel data parallelism (north_star: train.py's loop sharded by camera with an
@@ -497,6 +527,19 @@ int e3dgs_event_loss_cached(
     char* scratch, void* stream);
 
 /*
+ * e3dgs_event_loss / e3dgs_event_loss_cached (nz_count may be NULL: the three-launch form) with the contrast renders'
+ * gradients in RANK-1 form (ABI 16), the input of e3dgs_rasterize_backward_multi_rank1: d_next -- and d_now when it is a
+ * render of its own (img_now != image) -- receive in their FIRST plane the scalar field s with
+ * dL/dC = s * (0.4124, 0.35758, 0.1804); their other two planes are not written.  d_image (and a d_now that carries the
+ * shared render's total) stay full (3,H,W) gradients.  Loss scalars and dL/dc are those of e3dgs_event_loss, bit for bit.
+ */
+int e3dgs_event_loss_rank1(
+    int width, int height, const float* image, const float* img_now, const float* img_next, const float* gt_int,
+    const float* gt_now, const float* gt_next, const float* gt_blur, const float* c, float gt_c, float* d_image,
+    float* d_now, float* d_next, float* scalars_out, float* dc_out, double* nz_count, int nz_valid, char* scratch,
+    void* stream);
+
+/*
  * Mean SSIM of two (C,H,W) images and (optionally) its gradient w.r.t. img1.
  * Replaces the torch conv2d chain of utils/loss_utils.py:359-418 (`ssim`, `_ssim`, `create_window`): 11x11
  * Gaussian window sigma 1.5, zero padding 5, C1 = 1e-4, C2 = 9e-4, mean over the map.  to_gray = 1 first applies
@@ -524,6 +567,12 @@ int e3dgs_densify_stats_update(int P, const float* viewspace_grad, const int* ra
 size_t e3dgs_image_loss_scratch_bytes(int channels, int height, int width);
 int e3dgs_image_loss(int channels, int height, int width, int to_gray, float lambda_dssim, const float* image,
                      const float* gt_image, float* scalars, float* d_image, char* scratch, void* stream);
+/* The --gray loss (to_gray = 1, 3-channel images) with its image gradient in rank-1 form (ABI 16): d_gray (H,W) receives
+ * the scalar field s with d loss / d image = s * (0.299, 0.587, 0.114) -- the input of
+ * e3dgs_rasterize_backward_multi_rank1.  Same scalars as e3dgs_image_loss; scratch of e3dgs_image_loss_scratch_bytes(3,H,W). */
+int e3dgs_image_loss_rank1(int height, int width, float lambda_dssim, const float* image, const float* gt_image,
+                           float* scalars, float* d_gray, char* scratch, void* stream);
+
 
 /*
  * Fused Adam step over one flat parameter tensor (train.py:330-332; groups
@@ -623,8 +672,9 @@ int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys
  *        6 render_bwd, 7 geom_bwd.  enable(mask) resets the counters and times the slots whose bit is set
  * (0 = off, 0xFF = all; every timed slot costs two event packets per launch group, so a benchmark times only
  * the kernel it reports inside its timed region); query() synchronises the recorded events and returns the
- * accumulated milliseconds and the number of launches.  The profiler's state belongs to the CALLING HOST THREAD: enable,
- * the calls to be timed and query are made from one thread; calls of other threads are never timed and never race.
+ * accumulated milliseconds and the number of launches.  The profiler's state is PROCESS-WIDE (behind a mutex): calls made by
+ * any host thread while a slot is enabled are timed -- including the backward calls torch's autograd engine makes from its
+ * per-device worker thread under loss.backward() -- and a slot's totals are the sum over all threads.
  * select(mask) changes the set of timed slots WITHOUT resetting what has been recorded (a benchmark that brackets its
  * kernel on every n-th iteration only: the two event packets cost the launch ~6 us of GPU idle each).
  */

@@ -86,7 +86,10 @@ void gso_activate(int P, const float *log_scales /*P,3*/, const float *raw_rots 
                   float *scales, float *rots, float *opac) {
     for (int i = 0; i < P; ++i) {
         if (log_scales) {
-            for (int k = 0; k < 3; ++k) scales[3 * i + k] = exp_det(log_scales[3 * i + k]);
+            for (int k = 0; k < 3; ++k) {       /* NaN in -> NaN out (torch.exp); exp_det's clamp would swallow it */
+                const float x = log_scales[3 * i + k];
+                scales[3 * i + k] = x != x ? x : exp_det(x);
+            }
         }
         if (raw_rots) {
             const float *q = raw_rots + 4 * i;
@@ -94,7 +97,7 @@ void gso_activate(int P, const float *log_scales /*P,3*/, const float *raw_rots 
             float qinv = 1.0f / fmaxf(nrm, 1e-12f);
             for (int k = 0; k < 4; ++k) rots[4 * i + k] = q[k] * qinv;
         }
-        if (logit_opac) opac[i] = 1.0f / (1.0f + exp_det(-logit_opac[i]));
+        if (logit_opac) opac[i] = logit_opac[i] != logit_opac[i] ? logit_opac[i] : 1.0f / (1.0f + exp_det(-logit_opac[i]));
     }
 }
 

@@ -123,7 +123,7 @@ def _n_contrib_equal_after_mapping(pl_h, rg_h, nc_h, pl_o, rg_o, nc_o, W, H, r0,
     return True
 
 
-def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
+def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11, rank1_views=()):
     """The path bench.py TIMES against the C oracle at full size: ONE multi-view pass (rasterizer.forward_multi /
     backward_multi) with the trainer's flags -- activations inside the kernels (E3DGS_FLAG_PREACT) on the raw parameters,
     coefficient-major SH (E3DGS_FLAG_SH_PLANAR) -- instead of single-view calls on activated AoS inputs (window_parity).
@@ -132,7 +132,11 @@ def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
     per view; the pixel gradients are supported on those windows; its gradients are summed over the views and taken
     through the activations' chain rule (c_oracle.activate_backward, float64) to the raw parameters.
 
-    Same contract as the operator path: radii, final_T and the image bit for bit, gradients <= 1e-3 per Gaussian."""
+    Same contract as the operator path: radii, final_T and the image bit for bit, gradients <= 1e-3 per Gaussian.
+
+    rank1_views: views whose pixel gradient is a scalar field times the event loss's luminance weights -- what the trainer
+    hands the compositing backward for the contrast renders (e3dgs_rasterize_backward_multi_rank1).  The oracle gets the
+    expanded (3, H, W) gradient s * w; the HIP call gets s in plane 0 and NaN in the two planes it must not read."""
     from event_3dgs_amd import rasterizer
     from oracle import c_oracle
     dev = trainer.device
@@ -147,12 +151,21 @@ def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
                                    flags=trainer.FWD_FLAGS)
     st = rasterizer.state_views_multi(hip, P, W, H) if hasattr(rasterizer, "state_views_multi") else None
     gw = np.zeros((len(cams), 3, H, W), np.float32)
+    gw_hip = np.zeros_like(gw)
     rng = np.random.default_rng(grad_seed)
     res = {"views": []}
     acc = {k: 0.0 for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     for k, (cam, (r0, r1)) in enumerate(zip(cams, rows_per_view)):
         y0, y1 = r0 * 16, min(H, r1 * 16)
-        gw[k, :, y0:y1] = rng.standard_normal((3, y1 - y0, W)).astype(np.float32)
+        if k in rank1_views:
+            sfield = rng.standard_normal((y1 - y0, W)).astype(np.float32)
+            for ch, wch in enumerate(rasterizer.LUV_WEIGHTS):
+                gw[k, ch, y0:y1] = sfield * np.float32(wch)
+            gw_hip[k, 0, y0:y1] = sfield
+            gw_hip[k, 1:] = np.nan
+        else:
+            gw[k, :, y0:y1] = rng.standard_normal((3, y1 - y0, W)).astype(np.float32)
+            gw_hip[k] = gw[k]
         f = c_oracle.Forward(means3D=raw_cpu["xyz"], opacities=opac_a,
                              viewmatrix=cam.world_view_transform.contiguous().cpu().numpy(),
                              projmatrix=cam.full_proj_transform.cpu().numpy(),
@@ -177,7 +190,8 @@ def trainer_path_parity(trainer, cams, bg, rows_per_view, grad_seed=11):
            "features": np.ascontiguousarray(acc["shs"].reshape(P, 48).T)}              # (P,16,3) -> (48,P) planar
     e = lambda like: torch.full_like(like, float("nan"))
     out = dict(means3D=e(v["xyz"]), sh=e(v["features"]), opacities=e(v["opacity"]), scales=e(v["scaling"]), rots=e(v["rotation"]))
-    rasterizer.backward_multi(hip, torch.from_numpy(gw).to(dev), out)
+    rasterizer.backward_multi(hip, torch.from_numpy(gw_hip).to(dev), out,
+                              rank1={k: rasterizer.LUV_WEIGHTS for k in rank1_views} or None)
     got = {"xyz": out["means3D"], "scaling": out["scales"], "rotation": out["rots"], "opacity": out["opacities"],
            "features": out["sh"]}
     res["grad"] = {}

@@ -115,15 +115,18 @@ def test_cfg3_full_size_gradient_parity_per_gaussian(cfg3, view, rows):
     assert res["visible"] > 600_000 and res["oracle_instances"] > 6_000_000
 
 
-def test_cfg3_the_path_the_benchmark_times_against_the_oracle(cfg3):
+@pytest.mark.parametrize("rank1_views", [(), (1, 2)], ids=["general", "rank1"])
+def test_cfg3_the_path_the_benchmark_times_against_the_oracle(cfg3, rank1_views):
     """helpers.trainer_path_parity: ONE multi-view pass with in-kernel activations and coefficient-major SH -- the
     calls EventTrainer.step (and bench.py) make -- for the three cfg3 cameras against the C oracle, not via the
     single-view operator.  The kernels' activations are the oracle's (gso_activate: deterministic exp / sigmoid /
     normalize, scene/gaussian_model.py:33-41), so the contract is the operator's: every radius equal, the image bit for
-    bit, every Gaussian's gradient within 1e-3 -- no exceptions."""
+    bit, every Gaussian's gradient within 1e-3 -- no exceptions.
+    rank1: the two contrast renders' pixel gradients in the rank-1 form EventTrainer.step hands the backward (a scalar
+    field times the luminance weights of utils/loss_utils.py:24-28), against the oracle fed the expanded gradient."""
     from helpers import assert_trainer_path_parity, trainer_path_parity
     tr, cams, bg, _ = cfg3
-    res = trainer_path_parity(tr, cams, bg, [(32, 34), (0, 2), (66, 68)])
+    res = trainer_path_parity(tr, cams, bg, [(32, 34), (0, 2), (66, 68)], rank1_views=rank1_views)
     print("cfg3 trainer path", res)
     for v in res["views"]:
         assert v["visible"] > 600_000

@@ -32,6 +32,10 @@ def test_activate_edge_cases():
     assert o[0, 0] == 0.0
     s, _, o = c_oracle.activate(np.array([[0.0, 1.0, -1.0]], np.float32), None, np.array([[0.0]], np.float32))
     assert o[0, 0] == 0.5 and abs(s[0, 1] - np.e) < 1e-6
+    # NaN in -> NaN out, as torch.exp / torch.sigmoid (the polynomial's underflow clamp must not swallow it: a diverged
+    # parameter has to surface in the loss, not render as opacity 1.0)
+    s, _, o = c_oracle.activate(np.array([[np.nan, 0.0, 0.0]], np.float32), None, np.array([[np.nan]], np.float32))
+    assert np.isnan(s[0, 0]) and s[0, 1] == 1.0 and np.isnan(o[0, 0])
 
 
 def test_activate_backward_is_the_chain_rule():
