@@ -59,6 +59,25 @@ def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback, sche
 
 
 @pytest.mark.gpu
+def test_bench_gpus8_dry_run_on_one_gpu():
+    """`bench.py --gpus 8` end to end before an 8-GPU node ever sees it: eight ranks share cuda:0 over gloo (the test hooks
+    above), tiny workload -- the launch, the world-8 exchange (factorised SH all-gather of 8 blocks, all-reduce of the
+    non-SH groups), the max-over-ranks timing and the one JSON line of rank 0."""
+    env = dict(os.environ, E3DGS_BENCH_BACKEND="gloo", E3DGS_BENCH_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "tiny", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["comm_backend"] == "gloo"
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["dp_fallback"] is False
+    assert out["comm"]["sh_exchange"] == "factorised"
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line_carries_the_contract():
     """`python bench.py` (N = 1; the tiny workload to keep the test short): one JSON line with the contract's keys, the
     `roofline` object of the dominant kernel measured with HIP events in the timed region, the `cpu_baseline` of the

@@ -20,31 +20,31 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _inputs(rank):
+def _inputs(rank, n=N):
     from event_3dgs_amd import synth
     from event_3dgs_amd.cameras import orbit_camera
     from event_3dgs_amd.train_step import EventTrainer
-    params = synth.make_scene(N, "trained", seed=0, device=DEV)
-    cams = [orbit_camera(3 * rank, 16, W, H, device=DEV, daz=d) for d in (0.0, 0.004, 0.012)]
+    params = synth.make_scene(n, "trained", seed=0, device=DEV)
+    cams = [orbit_camera(3 * rank, 32 if rank >= 5 else 16, W, H, device=DEV, daz=d) for d in (0.0, 0.004, 0.012)]
     bg = torch.zeros(3, device=DEV)
     gp = dict(params)
-    gp["xyz"] = params["xyz"] + 0.01 * torch.randn(N, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gp["xyz"] = params["xyz"] + 0.01 * torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
     gt = EventTrainer(gp, DEV)
     gts = [(torch.round(gt.render_raw(c, bg)["color"].clamp(0, 1) * 255.0) / 255.0).contiguous() for c in cams]
     return params, cams, gts, bg
 
 
-def _worker(rank, world, port, out, overlap, factorize, schedule="allreduce"):
+def _worker(rank, world, port, out, overlap, factorize, schedule="allreduce", n=N, steps=STEPS):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["E3DGS_FACTORIZE_SH"] = "1" if factorize else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from event_3dgs_amd.train_step import EventTrainer
-    params, cams, gts, bg = _inputs(rank)
+    params, cams, gts, bg = _inputs(rank, n)
     tr = EventTrainer(params, DEV, overlap_features=overlap, dp_schedule=schedule)
-    assert tr.world == 2 and tr.overlap_features == overlap and tr.factorize_sh == factorize
+    assert tr.world == world and tr.overlap_features == overlap and tr.factorize_sh == factorize
     assert tr.dp_schedule == schedule and tr.rank == rank
-    for _ in range(STEPS):
+    for _ in range(steps):
         tr.step(*cams, *gts, bg)
     if schedule == "rs_ag":
         # every rank only advanced the moments of its own shard of the non-SH groups ...
@@ -119,6 +119,53 @@ def test_reduce_scatter_allgather_schedule_equals_the_allreduce_schedule(tmp_pat
         assert torch.equal(res["allreduce"][k], res["rs_ag"][k]), k
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# World 4 and 8 on the one GPU of the box: what `bench.py --gpus 8` and an 8-GPU fit will execute -- the rs_ag shards of
+# ceil((11 N + 1) / 8) elements with a padded last shard (N not divisible by 8), the 8-block factorised SH all-gather, the
+# chunked all-reduce at world 8 -- so that the first real 8-GPU run exercises nothing new but the links.
+N_BIG = 20003
+
+
+@pytest.mark.parametrize("schedule,overlap,factorize", [("allreduce", True, True), ("rs_ag", True, True),
+                                                         ("allreduce", False, False), ("rs_ag", False, False)])
+@pytest.mark.parametrize("world", [4, 8])
+def test_world_4_and_8_replicas_identical_and_equal_to_the_mean_of_the_ranks(tmp_path, world, schedule, overlap, factorize):
+    """Every rank renders its own triplet of the 20 003-Gaussian scene; after two steps the replicas are bit-identical
+    (parameters and, after sync_optimizer_state, both moments) and track the single-process emulation: the mean of the
+    `world` gradient buffers, one Adam.  (gloo adds more than two numbers in its own order: fp32 rounding against the
+    emulation's sum, not bit equality.)"""
+    steps = 2
+    out = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(world, _free_port(), out, overlap, factorize, schedule, N_BIG, steps), nprocs=world, join=True)
+    rs = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in range(1, world):
+        for k in ("flat", "m", "v"):
+            assert torch.equal(rs[0][k], rs[r][k]), (r, k)
+    from event_3dgs_amd.train_step import EventTrainer
+    assert not dist.is_initialized()
+    ins = [_inputs(r, N_BIG) for r in range(world)]
+    bg = ins[0][3]
+    ts = [EventTrainer(i[0], DEV, overlap_features=False) for i in ins]
+    for _ in range(steps):
+        for t, (_, cams, gts, _) in zip(ts, ins):
+            t.compute_gradients(*cams, *gts, bg)
+        mean = torch.stack([t.flat_grad for t in ts]).sum(0).div_(world)
+        for t in ts:
+            t.flat_grad.copy_(mean)
+            t.apply_update()
+    torch.cuda.synchronize()
+    m_ref, m_got = ts[0].exp_avg.cpu(), rs[0]["m"]
+    assert float((m_got - m_ref).norm() / m_ref.norm()) < 1e-4
+    v_ref, v_got = ts[0].exp_avg_sq.cpu(), rs[0]["v"]
+    assert float((v_got - v_ref).norm() / v_ref.norm()) < 1e-4
+    assert float((rs[0]["flat"] - ts[0].flat.cpu()).abs().max()) <= 0.05
+    # every rank's views went into the update: rank 0 alone ends elsewhere
+    solo = EventTrainer(ins[0][0], DEV)
+    for _ in range(steps):
+        solo.step(*ins[0][1], *ins[0][2], bg)
+    assert not torch.equal(solo.flat.cpu(), rs[0]["flat"])
+
+
 def _fit_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -150,17 +197,19 @@ def _fit_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_fit_with_densification_keeps_replicas_identical(tmp_path):
-    """The event training loop on two ranks: per-rank camera draws, averaged gradients, densification statistics
-    combined over the ranks (sum / max) and an identically seeded split sampler -- after two densification steps the
-    replicas hold the same number of Gaussians and bit-identical parameters and optimizer state."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_fit_with_densification_keeps_replicas_identical(tmp_path, world):
+    """The event training loop on two / eight ranks: per-rank camera draws, averaged gradients, densification statistics
+    combined over the ranks (sum / max, DensifyStats.sync) and an identically seeded split sampler -- after two
+    densification steps the replicas hold the same number of Gaussians and bit-identical parameters and optimizer state."""
     out = str(tmp_path / "fit")
-    mp.spawn(_fit_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
-    assert r0["sizes"] == r1["sizes"]
-    assert r0["sizes"][0] == 1200 and r0["sizes"][-1] != 1200          # densification really changed the model
-    for k in ("xyz", "f_rest", "m"):
-        assert torch.equal(r0[k], r1[k]), k
+    mp.spawn(_fit_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rs = [torch.load(f"{out}.{r}") for r in range(world)]
+    assert rs[0]["sizes"][0] == 1200 and rs[0]["sizes"][-1] != 1200          # densification really changed the model
+    for r in range(1, world):
+        assert rs[0]["sizes"] == rs[r]["sizes"]
+        for k in ("xyz", "f_rest", "m"):
+            assert torch.equal(rs[0][k], rs[r][k]), (r, k)
 
 
 def _shared_pose_worker(rank, world, port, out):
