@@ -380,6 +380,99 @@ def main():
                        "what": "the full event iteration (loss on three images, backward, Adam) when render #1 and render #2 "
                                "share a pose, as in the reference's datasets: that view is rendered once"}
 
+    # ---- how to read the headline (after the timed region, never part of `value`):
+    #   sustained          >= 500 more iterations of the same trainer (the scene keeps training: its instance count drifts),
+    #                      with the board's power / clocks sampled meanwhile (rocm-smi) -- a 20-step window is 47 ms;
+    #   static_workload    the same iteration on FROZEN parameters (every learning rate 0: Adam runs, nothing moves), so that
+    #                      two runs time the same lists;
+    #   reference_binning  the iteration with the reference's rectangle binning (E3DGS_TILE_CULL=0: "identical tile
+    #                      assignment" read literally; the default drops the instances that provably touch no pixel) and
+    #                      its instance count -- what the exact tile culling is worth.
+    reading = None
+    if world == 1 and not args.no_substep:
+        reading = {}
+        n_sus = max(500, args.steps)
+        samples, stop = [], [False]
+
+        def sampler():
+            import subprocess
+            while not stop[0]:
+                try:
+                    r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp", "--json"], capture_output=True,
+                                       text=True, timeout=10)
+                    card = next(iter(json.loads(r.stdout).values()))
+                    samples.append({k: v for k, v in card.items() if any(
+                        t in k.lower() for t in ("power", "sclk", "mclk", "temperature (sensor junction)"))})
+                except Exception:           # noqa: BLE001 -- no rocm-smi, no JSON: the leg still reports its timing
+                    return
+        import threading
+        th = threading.Thread(target=sampler, daemon=True)
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        th.start()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            one_step()
+        torch.cuda.synchronize()
+        sus_ms = 1e3 * (time.perf_counter() - ts) / n_sus
+        stop[0] = True
+        th.join(timeout=15)
+
+        def num(v):
+            try:
+                return float(str(v).strip("()").lower().replace("mhz", "").replace("w", ""))
+            except ValueError:
+                return None
+        power = [num(v) for smp in samples for k, v in smp.items() if "power" in k.lower() and num(v) is not None]
+        sclk = [num(v) for smp in samples for k, v in smp.items() if "sclk" in k.lower() and num(v) is not None]
+        reading["sustained"] = {"steps": n_sus, "ms_per_step": round(sus_ms, 3), "per_s": round(1e3 / sus_ms, 1),
+                                "tile_instances_3views_after": int(sum(trainer.render_raw(c, bg)["num_rendered"] for c in
+                                                                       (cam_int, cam_now, cam_next))),
+                                "board_power_w_mean": round(sum(power) / len(power), 1) if power else None,
+                                "board_power_w_max": max(power) if power else None,
+                                "sclk_mhz_reported_mean": round(sum(sclk) / len(sclk), 1) if sclk else None,
+                                "rocm_smi_samples": len(samples), "last_sample": samples[-1] if samples else None,
+                                "in_kernel_clock_ghz": {k: (v.get("clock") or {}).get("ghz_median") for k, v in
+                                                        ((roofline or {}).get("kernels") or {}).items()}}
+        zero = dict(position_lr_init=0.0, position_lr_final=0.0, feature_lr=0.0, opacity_lr=0.0, scaling_lr=0.0,
+                    rotation_lr=0.0, c_lr=0.0)
+
+        def leg(tr, reps):
+            st = lambda: tr.step_nocopy(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+            for _ in range(4):
+                st()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                st()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t1) / reps
+        tz = EventTrainer(params, dev, **zero)
+        z_ms = leg(tz, 100)
+        moved = float((tz.flat - EventTrainer(params, dev, **zero).flat).abs().max())
+        reading["static_workload"] = {"steps": 100, "ms_per_step": round(z_ms, 3), "per_s": round(1e3 / z_ms, 1),
+                                      "parameters_moved_by": moved,
+                                      "what": "the event iteration with every learning rate 0 (same kernels, same traffic, "
+                                              "frozen lists): the figure to compare between runs / boxes / rounds"}
+        del tz
+        tr_ref = EventTrainer(params, dev, tile_cull=0, **zero)
+        r_ms = leg(tr_ref, 40)
+        I_ref1 = tr_ref.render_raw(cam_int, bg)["num_rendered"]
+        I_ref = sum(tr_ref.render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
+        I_cull = sum(EventTrainer(params, dev, **zero).render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
+        reading["reference_binning_iteration"] = {
+            "ms_per_step": round(r_ms, 3), "per_s": round(1e3 / r_ms, 1), "frozen_parameters": True,
+            "tile_instances_reference_binning": I_ref1, "tile_instances_reference_binning_3views": I_ref,
+            "tile_instances_exact_culling_3views": I_cull, "vs_static_workload": round(r_ms / z_ms, 3),
+            "what": "E3DGS_TILE_CULL=0: every (splat, tile) pair of the reference's rectangles is emitted, sorted, walked; "
+                    "images, radii and gradients are the default mode's (tests: bit-exact lists in this mode)"}
+        del tr_ref
+        if roofline and dominant:
+            b_ref = algorithmic_bytes(dominant, N * V, I_ref, T * V, npx * V)
+            roofline["frac_on_reference_instances"] = round(b_ref / 1e9 / (stages[dominant]["avg_ms"] / 1e3) / HBM_PEAK_GBS, 5)
+            roofline["alg_bytes_on_reference_instances"] = int(b_ref)
+
     # ---- TOLERANCE MODE, beside the headline and never instead of it: the same iteration with E3DGS_FLAG_FAST_EXP (hardware
     # exp2 in the compositing kernels; tests/test_hip_parity.py::test_fast_exp_mode_is_a_counted_tolerance_mode) -- what
     # the bit-exact forward costs.  A fresh trainer on the same parameters, after the timed region.
@@ -510,12 +603,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "gaussians": N, "width": W, "height": H, "visible": vis,
-                       "tile_instances": I1, "tile_instances_3views": I, "tiles": T, "renders_per_iter": 3, "deblur": deblur,
+                       "tile_instances": I1, "tile_instances_3views": I,
+                       "tile_instances_reference_binning": ((reading or {}).get("reference_binning_iteration") or {}).get(
+                           "tile_instances_reference_binning"),
+                       "tiles": T, "renders_per_iter": 3, "deblur": deblur,
                        "parallelism": f"view-dp{world}", "grad_allreduce_bytes": grad_ar_bytes,
                        "sh_colour_allgather_bytes_per_rank": grad_ag_bytes,
                        "sh_exchange_on_side_stream": bool(trainer.overlap_features), "dp_schedule": dp_schedule,
                        "loss": round(loss_val, 6)},
             "roofline": roofline, "stages": stages, "contrast_only_substep": contrast,
+            "sustained": (reading or {}).get("sustained"), "static_workload": (reading or {}).get("static_workload"),
+            "reference_binning_iteration": (reading or {}).get("reference_binning_iteration"),
             "dropin_autograd_step": dropin, "shared_pose_iteration": shared_pose, "fast_exp_iteration": fast_exp,
             "cfg5_per_rank_workload": cfg5, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
@@ -582,76 +680,81 @@ def measure_dropin(params, cams, gts, bg, dev, L, iters=8):
     -> :330-332 optimizer.step()): render() with its forced torch-SH branch (gaussian_renderer/__init__.py:71-81),
     torch activations (scene/gaussian_model.py:95-118), the GaussianRasterizer autograd operator through the compiled
     extension (_C_native), the loss formulas of utils/loss_utils.py in torch, torch.optim.Adam over the six groups
-    (scene/gaussian_model.py:154-163) + Adam([c]).  Reported next to -- never instead of -- the fused iteration."""
+    (scene/gaussian_model.py:154-163) + Adam([c]) -- and the ADOPTION LADDER above it (event_3dgs_amd/adopt.py): the same
+    loop with render(), then the loss block, then the two optimizers swapped for this repo's, one at a time, all still
+    inside torch autograd / torch.optim.  Reported next to -- never instead of -- the fused iteration."""
     import ctypes as C
     import torch
-    from event_3dgs_amd import rasterizer
-    from event_3dgs_amd.renderer import GaussianView, PipelineParams, render
-    P = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
-    lr = dict(xyz=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20.0, opacity=0.05, scaling=5e-3, rotation=1e-3)
-    opt = torch.optim.Adam([{"params": [P[k]], "lr": lr[k], "name": k} for k in
-                            ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")], lr=0.0, eps=1e-15)
-    c = torch.nn.Parameter(torch.tensor([0.17], device=dev))
-    opt_c = torch.optim.Adam([c], lr=0.1)
-    pc = GaussianView(P, active_sh_degree=3, max_sh_degree=3)
-    pipe = PipelineParams()
-    lum = lambda im: (0.4124 * im[0] + 0.35758 * im[1] + 0.1804 * im[2]).unsqueeze(0)      # utils/loss_utils.py:24-28
-    ev = lambda a, b, cc: (torch.log(lum(b) + 1e-8) - torch.log(lum(a) + 1e-8)) / cc       # :234-249
+    from event_3dgs_amd import adopt, rasterizer
 
-    python_sh = [True]
+    def timed(loop, n):
+        for _ in range(2):
+            loop.step(cams, gts, bg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loop.step(cams, gts, bg)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n
+        host = []
+        for _ in range(3):                   # host time of one iteration with the GPU idle at entry (enqueue cost)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            loop.step(cams, gts, bg)
+            host.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        return wall, sorted(host)[1]
 
-    def step():
-        imgs = [render(cam, pc, pipe, bg, force_python_sh=python_sh[0])["render"] for cam in cams]
-        img_diff, gt = ev(imgs[1], imgs[2], c), ev(gts[1], gts[2], 0.17)
-        loss1, loss2 = torch.abs(img_diff - gt).mean(), torch.abs(imgs[0] - gts[0]).mean()          # train.py:165-203
-        mask = (gt != 0).to(imgs[0].dtype)
-        loss = (0.9 * (loss1 * mask).sum() + 0.1 * (loss2 * (1 - mask)).sum()) / (mask.sum() + (1 - mask).sum())
-        loss.backward()
-        opt_c.step(); opt_c.zero_grad(set_to_none=True)
-        opt.step(); opt.zero_grad(set_to_none=True)
-        return loss
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / iters
-    host = []
-    for _ in range(3):                       # host time of one iteration with the GPU idle at entry (enqueue cost)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        step()
-        host.append(time.perf_counter() - t0)
-    torch.cuda.synchronize()
-    # rasteriser kernels of one iteration (HIP events around the library's stages)
-    L.e3dgs_profile_enable(0xFF)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    ras = 0.0
-    for slot in range(8):
-        ms, n = C.c_double(0), C.c_int(0)
-        L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
-        ras += ms.value
-    L.e3dgs_profile_enable(0)
-    # the same iteration with ONE line of the reference removed (gaussian_renderer/__init__.py:71, which forces the torch
-    # SH branch): SH evaluated inside the rasteriser, forward and backward, as upstream 3DGS does
-    python_sh[0] = False
-    pipe.convert_SHs_python = False
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-    wall_sh = (time.perf_counter() - t0) / iters
-    return {"ms": round(1e3 * wall, 3), "ms_with_sh_in_the_rasteriser": round(1e3 * wall_sh, 3), "per_s": round(1.0 / wall, 2), "host_enqueue_ms": round(1e3 * sorted(host)[1], 3),
-            "rasteriser_kernels_ms": round(ras / 2, 3), "torch_side_ms": round(1e3 * wall - ras / 2, 3),
+    def kernels_ms(loop):
+        # rasteriser kernels of one iteration (HIP events around the library's stages; the profiler is process-wide, so the
+        # backward calls autograd makes from its own thread are timed too)
+        L.e3dgs_profile_enable(0xFF)
+        for _ in range(2):
+            loop.step(cams, gts, bg)
+        torch.cuda.synchronize()
+        per = {}
+        for slot in range(8):
+            ms, n = C.c_double(0), C.c_int(0)
+            L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
+            per[L.e3dgs_profile_slot_name(slot).decode()] = ms.value / 2
+        L.e3dgs_profile_enable(0)
+        return per
+
+    ladder, loops = {}, {}
+    names = {0: "rung0_unmodified", 1: "rung1_render", 2: "rung2_render_loss", 3: "rung3_render_loss_optimizer",
+             4: "rung4_one_call_for_the_three_renders"}
+    what = {0: "the reference's train.py:144-212,330-332 unmodified on the two drop-in packages",
+            1: "+ render -> event_3dgs_amd.adopt.render (SH, activations and their chain rule inside the rasteriser, one C++ "
+               "autograd node per render; gaussian_renderer/__init__.py:20-104)",
+            2: "+ the loss block train.py:165-203 -> adopt.event_loss (fused event-loss kernels as one autograd node)",
+            3: "+ gaussians.optimizer / optimizer_c -> adopt.FusedAdam (torch.optim interface and state layout, one launch "
+               "per parameter; scene/gaussian_model.py:154-163, train.py:71-73)",
+            4: "+ the three render() calls train.py:144,159,161 -> one adopt.render_views(...) (one multi-view pass of the "
+               "rasteriser, forward and backward, in one autograd node)"}
+    for rung in (0, 1, 2, 3, 4):
+        loop = adopt.LadderLoop(rung, params, dev)
+        wall, host = timed(loop, iters if rung == 0 else 2 * iters)
+        ker = kernels_ms(loop)
+        ladder[names[rung]] = {"ms": round(1e3 * wall, 3), "per_s": round(1.0 / wall, 2), "host_enqueue_ms": round(1e3 * host, 3),
+                               "rasteriser_kernels_ms": round(sum(ker.values()), 3),
+                               "render_bwd_ms": round(ker.get("render_bwd", 0.0), 3), "geom_bwd_ms": round(ker.get("geom_bwd", 0.0), 3),
+                               "what": what[rung]}
+        if rung == 0:
+            # the same iteration with ONE line of the reference removed (gaussian_renderer/__init__.py:71, which forces the
+            # torch SH branch): SH evaluated inside the rasteriser, forward and backward, as upstream 3DGS does
+            loop.python_sh = False
+            loop.pipe.convert_SHs_python = False
+            wall_sh, _ = timed(loop, iters)
+        del loop
+        torch.cuda.empty_cache()
+    r0 = ladder[names[0]]
+    return {"ms": r0["ms"], "ms_with_sh_in_the_rasteriser": round(1e3 * wall_sh, 3), "per_s": r0["per_s"],
+            "host_enqueue_ms": r0["host_enqueue_ms"], "rasteriser_kernels_ms": r0["rasteriser_kernels_ms"],
+            "torch_side_ms": round(r0["ms"] - r0["rasteriser_kernels_ms"], 3),
             "native_extension": rasterizer.native_ext() is not None,
+            "cpp_autograd_node": rasterizer.cpp_autograd_ext() is not None,
             "what": "3 x render() (torch SH + activations, GaussianRasterizer via _C_native) + torch loss "
-                    "(train.py:165-203) + loss.backward() + torch.optim.Adam (6 groups) + Adam([c])"}
+                    "(train.py:165-203) + loss.backward() + torch.optim.Adam (6 groups) + Adam([c])",
+            "ladder": ladder}
 
 
 def source_fingerprint():

@@ -668,15 +668,15 @@ int e3_densify_stats_impl(int P, const float* viewspace_grad, const int* radii, 
 __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float step_size,
                                                    float b1, float b2, float bc2_sqrt, float eps, float step_size_b,
-                                                   int period, int split) {
+                                                   int period, int split, float omb1, float omb2 /* 1 - beta, as torch's fp32 */) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     const float step_a = step_size;
     for (; i < n; i += stride) {
         if (period > 0) step_size = ((int)(i % (size_t)period) < split) ? step_a : step_size_b;
         float gi = g[i];
-        float mi = m[i] + (1.0f - b1) * (gi - m[i]);
-        float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        float mi = m[i] + omb1 * (gi - m[i]);
+        float vi = v[i] * b2 + omb2 * gi * gi;
         m[i] = mi; v[i] = vi;
         float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (mi / denom);
@@ -686,11 +686,12 @@ __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__
 int e3_adam_impl(size_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                  int step, float lr_b, int period, int split, hipStream_t s) {
     if (n == 0) return 0;
-    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    double bc1 = 1.0 - pow(e3_beta_double(b1), step), bc2 = 1.0 - pow(e3_beta_double(b2), step);
     size_t nb = (n + 255) / 256;
     if (nb > 65536) nb = 65536;      // measured at 59 M floats: 8192 -> 4.8 TB/s, 65536 -> 5.85 TB/s, no cap 5.7
     adam_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(n, p, g, m, v, (float)(lr / bc1), b1, b2, (float)sqrt(bc2), eps,
-                                                         (float)(lr_b / bc1), period, split);
+                                                         (float)(lr_b / bc1), period, split, e3_one_minus_beta(b1),
+                                                         e3_one_minus_beta(b2));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "adam_kernel");
 }
@@ -707,7 +708,7 @@ struct AdamPieces { size_t begin[ADAM_MAX_PIECES]; size_t end[ADAM_MAX_PIECES]; 
                     float step_size[ADAM_MAX_PIECES]; float eps[ADAM_MAX_PIECES]; float bc2_sqrt[ADAM_MAX_PIECES]; int n; };
 __global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, AdamPieces pc,
-                                                            float b1, float b2) {
+                                                            float b1, float b2, float omb1, float omb2) {
     const unsigned nchunks = pc.chunk_first[pc.n];
     for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
         int k = 0;                               // (scalar: the chunk index is the workgroup's)
@@ -717,8 +718,8 @@ __global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ 
         if (i >= pc.end[k]) continue;
         const float bc2 = pc.bc2_sqrt[k], ep = pc.eps[k], ss = pc.step_size[k];
         float gi = g[i];
-        float mi = m[i] + (1.0f - b1) * (gi - m[i]);
-        float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        float mi = m[i] + omb1 * (gi - m[i]);
+        float vi = v[i] * b2 + omb2 * gi * gi;
         m[i] = mi; v[i] = vi;
         float denom = __builtin_sqrtf(vi) / bc2 + ep;
         p[i] = p[i] - ss * (mi / denom);
@@ -747,7 +748,7 @@ int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v
         const size_t b = prev, e = seg_end[k];
         prev = e;
         if (st <= 0 || b == e) continue;         // a group torch.optim.Adam would skip (its .grad is None): not in the launch
-        const double bc1 = 1.0 - pow((double)b1, st), bc2 = 1.0 - pow((double)b2, st);
+        const double bc1 = 1.0 - pow(e3_beta_double(b1), st), bc2 = 1.0 - pow(e3_beta_double(b2), st);
         // the segment minus the gap: up to two pieces
         const size_t lo[2] = {b, b > gap_end ? b : gap_end}, hi[2] = {e < gap_begin ? e : gap_begin, e};
         for (int h = 0; h < 2; ++h) {
@@ -766,7 +767,8 @@ int e3_adam_segments_impl(size_t n, float* p, const float* g, float* m, float* v
     if (chunks == 0) return 0;
     size_t nb = chunks;
     if (nb > 65536) nb = 65536;      // measured at 59 M floats: 8192 -> 4.8 TB/s, 65536 -> 5.85 TB/s, no cap 5.7
-    adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(p, g, m, v, pc, b1, b2);
+    adam_segments_kernel<<<dim3((unsigned)nb), dim3(256), 0, s>>>(p, g, m, v, pc, b1, b2, e3_one_minus_beta(b1),
+                                                                  e3_one_minus_beta(b2));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : e3_fail(e, "adam_segments_kernel");
 }

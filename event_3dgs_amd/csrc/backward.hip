@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int P, int nranks, i
 #ifndef E3_SH_SLICE
 #define E3_SH_SLICE 2      // SH coefficients (x 3 channels) per workgroup slice: 18 streams per thread (1 / 2 / 4 / 8: 0.329 / 0.303 / 0.318 / 0.388 ms for the optimizer stage)
 #endif
-struct ShAdam { float* m; float* v; float ss_dc, ss_rest, bc2s, b1, b2, eps; };
+struct ShAdam { float* m; float* v; float ss_dc, ss_rest, bc2s, b1, b2, eps, omb1, omb2 /* 1 - beta as torch's fp32 (common.h) */; };
 __global__ __launch_bounds__(256) void sh_adam_views_sliced_kernel(int P, int nranks, int views_per_rank, int D, int M,
                                                             const float* __restrict__ means,
                                                             const float* __restrict__ packed, size_t rank_stride,
@@ -1221,8 +1221,8 @@ __global__ __launch_bounds__(256) void sh_adam_views_sliced_kernel(int P, int nr
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
         const float g = (k0 + j / 3 < nk) ? acc[j / 3][j % 3] * scale : 0.0f;     // inactive degrees: zero gradient, moments decay
-        const float mi = m0[j] + (1.0f - ad.b1) * (g - m0[j]);
-        const float vi = v0[j] * ad.b2 + (1.0f - ad.b2) * g * g;
+        const float mi = m0[j] + ad.omb1 * (g - m0[j]);
+        const float vi = v0[j] * ad.b2 + ad.omb2 * g * g;
         ad.m[e0 + j * st] = mi; ad.v[e0 + j * st] = vi;
         sh[e0 + j * st] = p0[j] - ((k0 == 0 && j < 3) ? ad.ss_dc : ad.ss_rest) * (mi / (__builtin_sqrtf(vi) / ad.bc2s + ad.eps));
     }
@@ -1304,8 +1304,8 @@ __global__ __launch_bounds__(256, MEAN ? E3_SH_MEAN_OCC : 3) void sh_adam_views_
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const float g = (k0 + j / 3 < nk) ? acc[j / 3][j % 3] * scale : 0.0f;     // inactive degrees: zero gradient, moments decay
-            const float mi = m0[j] + (1.0f - ad.b1) * (g - m0[j]);
-            const float vi = v0[j] * ad.b2 + (1.0f - ad.b2) * g * g;
+            const float mi = m0[j] + ad.omb1 * (g - m0[j]);
+            const float vi = v0[j] * ad.b2 + ad.omb2 * g * g;
             ad.m[e0 + j * st] = mi; ad.v[e0 + j * st] = vi;
             sh[e0 + j * st] = p0[j] - ((k0 == 0 && j < 3) ? ad.ss_dc : ad.ss_rest) * (mi / (__builtin_sqrtf(vi) / ad.bc2s + ad.eps));
         }
@@ -1330,8 +1330,9 @@ int e3_sh_adam_views_impl(int P, int nranks, int views_per_rank, int D, int M, c
                           size_t rank_stride, float scale, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc,
                           float lr_rest, float b1, float b2, float eps, int step, int flags, hipStream_t s, float* dmean) {
     if (P <= 0) return 0;
-    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    const double bc1 = 1.0 - pow(e3_beta_double(b1), step), bc2 = 1.0 - pow(e3_beta_double(b2), step);
     ShAdam ad;
+    ad.omb1 = e3_one_minus_beta(b1); ad.omb2 = e3_one_minus_beta(b2);
     ad.m = exp_avg; ad.v = exp_avg_sq; ad.ss_dc = (float)((double)lr_dc / bc1); ad.ss_rest = (float)((double)lr_rest / bc1);
     ad.bc2s = (float)sqrt(bc2); ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
     static const bool reg_views = !(getenv("E3DGS_SH_ADAM_SLICED") && atoi(getenv("E3DGS_SH_ADAM_SLICED")) != 0);   // (A/B switch)

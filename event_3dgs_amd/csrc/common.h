@@ -405,6 +405,13 @@ struct Rank1Views {
     uint32_t mask;              // bit v: view v's pixel gradient is plane 0 of its (3, H, W) block times w[v]
 };
 
+// Adam's betas cross the C ABI as fp32, but torch.optim.Adam evaluates 1 - beta, beta^step and their roots on the Python
+// double the caller wrote (0.9, 0.999: short decimals).  (float)0.999 = 0.99900001287..., and 1 - that is 1.3e-5 away
+// from the fp32 value of 1 - 0.999 torch multiplies g^2 with.  The host therefore recovers the decimal (7 digits: exact
+// for anything a caller writes as a literal) and derives every constant from it, as torch does.
+static inline double e3_beta_double(float b) { return __builtin_nearbyint((double)b * 1e7) / 1e7; }
+static inline float e3_one_minus_beta(float b) { return (float)(1.0 - e3_beta_double(b)); }
+
 // the options of one call, resolved from its flags word (capi.hip holds the process-wide defaults)
 struct CallOpts {
     int cull;          // 0: reference rectangle binning, 1: exact culling, 3: exact culling without the tight box

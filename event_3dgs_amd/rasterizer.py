@@ -152,10 +152,53 @@ def _debug_guard(enabled, args, path, what, fn):
         raise
 
 
+def _check_operator_args(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+    """The argument rules of upstream's operator, with its messages (SURVEY 8b "Errors")."""
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+    P = means3D.shape[0]
+    if P:
+        if opacities is None or opacities.numel() != P:
+            raise RuntimeError("opacities must have P elements")
+        if (sh is None or sh.numel() == 0) == (colors_precomp is None or colors_precomp.numel() == 0):
+            raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
+        has_sr = scales is not None and rotations is not None and scales.numel() and rotations.numel()
+        if bool(has_sr) == (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0):
+            raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+
+
+def cpp_autograd_ext():
+    """The compiled extension when its C++ autograd node may serve the operator (csrc/ext.cpp RasterizeFunction;
+    E3DGS_CPP_AUTOGRAD=0: the Python autograd.Function below over the same extension functions)."""
+    import os
+    ext = native_ext()
+    if ext is None or not hasattr(ext, "rasterize_autograd") or os.environ.get("E3DGS_CPP_AUTOGRAD", "1") == "0":
+        return None
+    return ext
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                        raster_settings, flags=0):
+    """The operator.  With the compiled extension the autograd node itself lives in C++ (no Python frame per render and
+    per backward); debug / prefiltered calls -- which snapshot their arguments or check the caller's promise on the host
+    -- and builds without the extension take the Python autograd.Function.  Identical results (same C ABI underneath).
+    flags: the C ABI's flags word (E3DGS_FLAG_PREACT: raw log-scales / quaternions / logits, activations in the kernels)."""
+    rs = raster_settings
+    ext = cpp_autograd_ext()
+    if ext is None or rs.debug or rs.prefiltered:
+        if flags:
+            raise RuntimeError("flags need the compiled extension's autograd node")
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+    _check_operator_args(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    empty = means3D.new_empty(0)
+    e = lambda t: empty if t is None else t
+    return ext.rasterize_autograd(means3D, e(means2D), e(sh), e(colors_precomp), e(opacities), e(scales), e(rotations),
+                                  e(cov3Ds_precomp), rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos,
+                                  float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height),
+                                  int(rs.image_width), int(rs.sh_degree), int(flags))
 
 
 def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, flags=0):
@@ -337,21 +380,10 @@ class _RasterizeGaussians(torch.autograd.Function):
     def _forward_native(ctx, ext, args, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
         """Upstream's own Python layer, verbatim in structure: empty tensor = not provided, the extension returns
         (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer)."""
-        if means3D.dim() != 2 or means3D.shape[1] != 3:
-            raise RuntimeError("means3D must have dimensions (num_points, 3)")
-        if not means3D.is_cuda:
-            raise RuntimeError("means3D must be a CUDA/HIP tensor (this op has no CPU path)")
+        _check_operator_args(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         P = means3D.shape[0]
         empty = means3D.new_empty(0)
         e = lambda t: empty if t is None else t
-        if P:
-            if opacities is None or opacities.numel() != P:
-                raise RuntimeError("opacities must have P elements")
-            if (sh is None or sh.numel() == 0) == (colors_precomp is None or colors_precomp.numel() == 0):
-                raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
-            has_sr = scales is not None and rotations is not None and scales.numel() and rotations.numel()
-            if bool(has_sr) == (cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0):
-                raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         def call():
             # (the caller's promise is checked first: upstream's kernel traps the device on a violation, see forward_raw)
             if rs.prefiltered and P and not bool(ext.mark_visible(means3D, rs.viewmatrix, rs.projmatrix).all()):

@@ -94,13 +94,17 @@ void gso_event_loss(int W, int H, const float *image, const float *now, const fl
     free(D); free(Dg);
 }
 
+/* torch.optim.Adam evaluates 1 - beta, beta^step on the Python double the caller wrote (0.9, 0.999); the betas arrive here
+ * as fp32, so the decimal is recovered first (7 digits) -- (float)0.999 would put 1 - beta2 1.3e-5 away from torch's. */
+static double beta_double(float b) { return nearbyint((double)b * 1e7) / 1e7; }
 void gso_adam(size_t n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps, int step) {
-    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    double bc1 = 1.0 - pow(beta_double(b1), step), bc2 = 1.0 - pow(beta_double(b2), step);
     float step_size = (float)(lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
+    const float omb1 = (float)(1.0 - beta_double(b1)), omb2 = (float)(1.0 - beta_double(b2));
     for (size_t i = 0; i < n; ++i) {
-        m[i] = m[i] + (1.0f - b1) * (g[i] - m[i]);           /* lerp form used by torch */
-        v[i] = v[i] * b2 + (1.0f - b2) * g[i] * g[i];
+        m[i] = m[i] + omb1 * (g[i] - m[i]);                  /* lerp form used by torch */
+        v[i] = v[i] * b2 + omb2 * g[i] * g[i];
         float denom = sqrtf(v[i]) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (m[i] / denom);
     }

@@ -108,3 +108,18 @@ def test_bench_single_gpu_line_carries_the_contract():
     for key in ("contrast_only_substep", "shared_pose_iteration", "dropin_autograd_step"):
         assert key in out
     assert out["shared_pose_iteration"]["taken"] is True and out["shared_pose_iteration"]["renders"] == 2
+    # how to read the headline: a sustained window, a frozen workload, the literal reference binning
+    assert out["sustained"]["steps"] >= 500 and out["sustained"]["ms_per_step"] > 0
+    assert out["static_workload"]["ms_per_step"] > 0 and out["static_workload"]["parameters_moved_by"] == 0.0
+    rb = out["reference_binning_iteration"]
+    assert rb["ms_per_step"] > 0 and rb["tile_instances_reference_binning_3views"] >= rb["tile_instances_exact_culling_3views"]
+    assert out["config"]["tile_instances_reference_binning"] == rb["tile_instances_reference_binning"]
+    assert out["config"]["tile_instances_reference_binning"] >= out["config"]["tile_instances"]
+    assert rf["frac_on_reference_instances"] >= rf["frac"]
+    # the adoption ladder: every rung measured, the last one on torch.optim's interface with this repo's pieces
+    lad = out["dropin_autograd_step"]["tiny"]["ladder"]
+    for key in ("rung0_unmodified", "rung1_render", "rung2_render_loss", "rung3_render_loss_optimizer",
+                "rung4_one_call_for_the_three_renders"):
+        assert lad[key]["ms"] > 0 and lad[key]["rasteriser_kernels_ms"] > 0, key
+        assert lad[key]["render_bwd_ms"] > 0 and lad[key]["geom_bwd_ms"] > 0, key      # backward kernels timed (autograd thread)
+    assert out["dropin_autograd_step"]["tiny"]["cpp_autograd_node"] is True
