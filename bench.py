@@ -380,99 +380,6 @@ def main():
                        "what": "the full event iteration (loss on three images, backward, Adam) when render #1 and render #2 "
                                "share a pose, as in the reference's datasets: that view is rendered once"}
 
-    # ---- how to read the headline (after the timed region, never part of `value`):
-    #   sustained          >= 500 more iterations of the same trainer (the scene keeps training: its instance count drifts),
-    #                      with the board's power / clocks sampled meanwhile (rocm-smi) -- a 20-step window is 47 ms;
-    #   static_workload    the same iteration on FROZEN parameters (every learning rate 0: Adam runs, nothing moves), so that
-    #                      two runs time the same lists;
-    #   reference_binning  the iteration with the reference's rectangle binning (E3DGS_TILE_CULL=0: "identical tile
-    #                      assignment" read literally; the default drops the instances that provably touch no pixel) and
-    #                      its instance count -- what the exact tile culling is worth.
-    reading = None
-    if world == 1 and not args.no_substep:
-        reading = {}
-        n_sus = max(500, args.steps)
-        samples, stop = [], [False]
-
-        def sampler():
-            import subprocess
-            while not stop[0]:
-                try:
-                    r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp", "--json"], capture_output=True,
-                                       text=True, timeout=10)
-                    card = next(iter(json.loads(r.stdout).values()))
-                    samples.append({k: v for k, v in card.items() if any(
-                        t in k.lower() for t in ("power", "sclk", "mclk", "temperature (sensor junction)"))})
-                except Exception:           # noqa: BLE001 -- no rocm-smi, no JSON: the leg still reports its timing
-                    return
-        import threading
-        th = threading.Thread(target=sampler, daemon=True)
-        for _ in range(3):
-            one_step()
-        torch.cuda.synchronize()
-        th.start()
-        ts = time.perf_counter()
-        for _ in range(n_sus):
-            one_step()
-        torch.cuda.synchronize()
-        sus_ms = 1e3 * (time.perf_counter() - ts) / n_sus
-        stop[0] = True
-        th.join(timeout=15)
-
-        def num(v):
-            try:
-                return float(str(v).strip("()").lower().replace("mhz", "").replace("w", ""))
-            except ValueError:
-                return None
-        power = [num(v) for smp in samples for k, v in smp.items() if "power" in k.lower() and num(v) is not None]
-        sclk = [num(v) for smp in samples for k, v in smp.items() if "sclk" in k.lower() and num(v) is not None]
-        reading["sustained"] = {"steps": n_sus, "ms_per_step": round(sus_ms, 3), "per_s": round(1e3 / sus_ms, 1),
-                                "tile_instances_3views_after": int(sum(trainer.render_raw(c, bg)["num_rendered"] for c in
-                                                                       (cam_int, cam_now, cam_next))),
-                                "board_power_w_mean": round(sum(power) / len(power), 1) if power else None,
-                                "board_power_w_max": max(power) if power else None,
-                                "sclk_mhz_reported_mean": round(sum(sclk) / len(sclk), 1) if sclk else None,
-                                "rocm_smi_samples": len(samples), "last_sample": samples[-1] if samples else None,
-                                "in_kernel_clock_ghz": {k: (v.get("clock") or {}).get("ghz_median") for k, v in
-                                                        ((roofline or {}).get("kernels") or {}).items()}}
-        zero = dict(position_lr_init=0.0, position_lr_final=0.0, feature_lr=0.0, opacity_lr=0.0, scaling_lr=0.0,
-                    rotation_lr=0.0, c_lr=0.0)
-
-        def leg(tr, reps):
-            st = lambda: tr.step_nocopy(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
-            for _ in range(4):
-                st()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                st()
-            torch.cuda.synchronize()
-            return 1e3 * (time.perf_counter() - t1) / reps
-        tz = EventTrainer(params, dev, **zero)
-        z_ms = leg(tz, 100)
-        moved = float((tz.flat - EventTrainer(params, dev, **zero).flat).abs().max())
-        reading["static_workload"] = {"steps": 100, "ms_per_step": round(z_ms, 3), "per_s": round(1e3 / z_ms, 1),
-                                      "parameters_moved_by": moved,
-                                      "what": "the event iteration with every learning rate 0 (same kernels, same traffic, "
-                                              "frozen lists): the figure to compare between runs / boxes / rounds"}
-        del tz
-        tr_ref = EventTrainer(params, dev, tile_cull=0, **zero)
-        r_ms = leg(tr_ref, 40)
-        I_ref1 = tr_ref.render_raw(cam_int, bg)["num_rendered"]
-        I_ref = sum(tr_ref.render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
-        I_cull = sum(EventTrainer(params, dev, **zero).render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
-        reading["reference_binning_iteration"] = {
-            "ms_per_step": round(r_ms, 3), "per_s": round(1e3 / r_ms, 1), "frozen_parameters": True,
-            "tile_instances_reference_binning": I_ref1, "tile_instances_reference_binning_3views": I_ref,
-            "tile_instances_exact_culling_3views": I_cull, "vs_static_workload": round(r_ms / z_ms, 3),
-            "what": "E3DGS_TILE_CULL=0: every (splat, tile) pair of the reference's rectangles is emitted, sorted, walked; "
-                    "images, radii and gradients are the default mode's (tests: bit-exact lists in this mode)"}
-        del tr_ref
-        if roofline and dominant:
-            b_ref = algorithmic_bytes(dominant, N * V, I_ref, T * V, npx * V)
-            roofline["frac_on_reference_instances"] = round(b_ref / 1e9 / (stages[dominant]["avg_ms"] / 1e3) / HBM_PEAK_GBS, 5)
-            roofline["alg_bytes_on_reference_instances"] = int(b_ref)
-
     # ---- TOLERANCE MODE, beside the headline and never instead of it: the same iteration with E3DGS_FLAG_FAST_EXP (hardware
     # exp2 in the compositing kernels; tests/test_hip_parity.py::test_fast_exp_mode_is_a_counted_tolerance_mode) -- what
     # the bit-exact forward costs.  A fresh trainer on the same parameters, after the timed region.
@@ -586,6 +493,100 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(trainer, (cam_int, cam_now, cam_next), bg, W, H, args.cpu_rows, args.torch_rows)
+
+    # ---- how to read the headline (after the timed region, never part of `value`):
+    #   sustained          >= 500 more iterations of the same trainer (the scene keeps training: its instance count drifts),
+    #                      with the board's power / clocks sampled meanwhile (rocm-smi) -- a 20-step window is 47 ms;
+    #   static_workload    the same iteration on FROZEN parameters (every learning rate 0: Adam runs, nothing moves), so that
+    #                      two runs time the same lists;
+    #   reference_binning  the iteration with the reference's rectangle binning (E3DGS_TILE_CULL=0: "identical tile
+    #                      assignment" read literally; the default drops the instances that provably touch no pixel) and
+    #                      its instance count -- what the exact tile culling is worth.
+    # (LAST of the legs: it trains the benchmark's own trainer on, and the parity leg above wants the state the timed region left)
+    reading = None
+    if world == 1 and not args.no_substep:
+        reading = {}
+        n_sus = max(500, args.steps)
+        samples, stop = [], [False]
+
+        def sampler():
+            import subprocess
+            while not stop[0]:
+                try:
+                    r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp", "--json"], capture_output=True,
+                                       text=True, timeout=10)
+                    card = next(iter(json.loads(r.stdout).values()))
+                    samples.append({k: v for k, v in card.items() if any(
+                        t in k.lower() for t in ("power", "sclk", "mclk", "temperature (sensor junction)"))})
+                except Exception:           # noqa: BLE001 -- no rocm-smi, no JSON: the leg still reports its timing
+                    return
+        import threading
+        th = threading.Thread(target=sampler, daemon=True)
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        th.start()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            one_step()
+        torch.cuda.synchronize()
+        sus_ms = 1e3 * (time.perf_counter() - ts) / n_sus
+        stop[0] = True
+        th.join(timeout=15)
+
+        def num(v):
+            try:
+                return float(str(v).strip("()").lower().replace("mhz", "").replace("w", ""))
+            except ValueError:
+                return None
+        power = [num(v) for smp in samples for k, v in smp.items() if "power" in k.lower() and num(v) is not None]
+        sclk = [num(v) for smp in samples for k, v in smp.items() if "sclk" in k.lower() and num(v) is not None]
+        reading["sustained"] = {"steps": n_sus, "ms_per_step": round(sus_ms, 3), "per_s": round(1e3 / sus_ms, 1),
+                                "tile_instances_3views_after": int(sum(trainer.render_raw(c, bg)["num_rendered"] for c in
+                                                                       (cam_int, cam_now, cam_next))),
+                                "board_power_w_mean": round(sum(power) / len(power), 1) if power else None,
+                                "board_power_w_max": max(power) if power else None,
+                                "sclk_mhz_reported_mean": round(sum(sclk) / len(sclk), 1) if sclk else None,
+                                "rocm_smi_samples": len(samples), "last_sample": samples[-1] if samples else None,
+                                "in_kernel_clock_ghz": {k: (v.get("clock") or {}).get("ghz_median") for k, v in
+                                                        ((roofline or {}).get("kernels") or {}).items()}}
+        zero = dict(position_lr_init=0.0, position_lr_final=0.0, feature_lr=0.0, opacity_lr=0.0, scaling_lr=0.0,
+                    rotation_lr=0.0, c_lr=0.0)
+
+        def leg(tr, reps):
+            st = lambda: tr.step_nocopy(cam_int, cam_now, cam_next, gts[0], gts[1], gts[2], bg, gt_blur=gt_blur)
+            for _ in range(4):
+                st()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                st()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t1) / reps
+        tz = EventTrainer(params, dev, **zero)
+        z_ms = leg(tz, 100)
+        moved = float((tz.flat - EventTrainer(params, dev, **zero).flat).abs().max())
+        reading["static_workload"] = {"steps": 100, "ms_per_step": round(z_ms, 3), "per_s": round(1e3 / z_ms, 1),
+                                      "parameters_moved_by": moved,
+                                      "what": "the event iteration with every learning rate 0 (same kernels, same traffic, "
+                                              "frozen lists): the figure to compare between runs / boxes / rounds"}
+        del tz
+        tr_ref = EventTrainer(params, dev, tile_cull=0, **zero)
+        r_ms = leg(tr_ref, 40)
+        I_ref1 = tr_ref.render_raw(cam_int, bg)["num_rendered"]
+        I_ref = sum(tr_ref.render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
+        I_cull = sum(EventTrainer(params, dev, **zero).render_raw(c, bg)["num_rendered"] for c in (cam_int, cam_now, cam_next))
+        reading["reference_binning_iteration"] = {
+            "ms_per_step": round(r_ms, 3), "per_s": round(1e3 / r_ms, 1), "frozen_parameters": True,
+            "tile_instances_reference_binning": I_ref1, "tile_instances_reference_binning_3views": I_ref,
+            "tile_instances_exact_culling_3views": I_cull, "vs_static_workload": round(r_ms / z_ms, 3),
+            "what": "E3DGS_TILE_CULL=0: every (splat, tile) pair of the reference's rectangles is emitted, sorted, walked; "
+                    "images, radii and gradients are the default mode's (tests: bit-exact lists in this mode)"}
+        del tr_ref
+        if roofline and dominant:
+            b_ref = algorithmic_bytes(dominant, N * V, I_ref, T * V, npx * V)
+            roofline["frac_on_reference_instances"] = round(b_ref / 1e9 / (stages[dominant]["avg_ms"] / 1e3) / HBM_PEAK_GBS, 5)
+            roofline["alg_bytes_on_reference_instances"] = int(b_ref)
 
     # gradient exchange per iteration and rank: mean of the non-SH groups (+ of the SH gradient unless it is rebuilt
     # from the all-gathered per-view colour gradients, EventTrainer.factorize_sh)

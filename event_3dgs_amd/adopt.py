@@ -100,14 +100,32 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
+_COUNT_WORDS = {}
+
+
+def _count_word(device):
+    """One pinned, device-mapped int32 per device for the instance count of render_views() (allocating pinned memory per
+    call costs a hipHostMalloc -- milliseconds, and it synchronises the device); the forward waits for the count before it
+    returns, so one word serves every call on that device."""
+    key = (device.type, device.index)
+    w = _COUNT_WORDS.get(key)
+    if w is None:
+        w = _COUNT_WORDS[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return w
+
+
 class _RasterizeViews(torch.autograd.Function):
     """Several cameras of the same model as ONE multi-view pass of the rasteriser inside one autograd node
     (e3dgs_rasterize_forward_multi / _backward_multi; raw parameters, E3DGS_FLAG_PREACT)."""
 
     @staticmethod
     def forward(ctx, xyz, shs, opacity, scaling, rotation, means2D, settings):
-        raw = rasterizer.forward_multi(xyz.detach(), shs.detach(), opacity.detach(), scaling.detach(), rotation.detach(),
-                                       list(settings), flags=_lib.FLAG_PREACT | _lib.FLAG_COUNT_MAPPED)
+        pend = rasterizer.forward_multi_begin(xyz.detach(), shs.detach(), opacity.detach(), scaling.detach(),
+                                              rotation.detach(), list(settings),
+                                              flags=_lib.FLAG_PREACT | _lib.FLAG_COUNT_MAPPED, count_host=_count_word(xyz.device))
+        rasterizer.prepare_multi_finish(pend)          # (host work done while the GPU still computes the count)
+        rasterizer.wait_count(pend)
+        raw = rasterizer.forward_multi_finish(pend)
         ctx.raw = raw
         ctx.n = len(settings)
         radii = raw["radii"]

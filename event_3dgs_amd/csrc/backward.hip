@@ -418,18 +418,12 @@ __device__ __forceinline__ void render_bwd_dispatch(
     render_bwd_body<STATS, STATS, FAST, false>(sh, tile, trace, tiles_per_view, gx, W, H, ranges, emit_gid, rec, bg, final_T,
                                                n_contrib, perm, strip_mask, dL_dpix, part, dL_dpix2, part2, 0.0f, 0.0f, 0.0f);
 }
-// (plain kernels around the one body: the profiles, the bench line and the reviews name `render_bwd_kernel`; the *_r1
-// variants are launched when some view of the call carries a rank-1 pixel gradient)
+// (plain kernels around the one dispatch: the profiles, the bench line and the reviews name `render_bwd_kernel`.  Both
+// bodies are compiled into it; a call without rank-1 views passes mask 0 and every tile takes the general body)
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_kernel(E3_RENDER_BWD_PARAMS) {
-    render_bwd_dispatch<false, false, false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
-}
-__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_fast_kernel(E3_RENDER_BWD_PARAMS) {
-    render_bwd_dispatch<false, true, false>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
-}
-__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_r1_kernel(E3_RENDER_BWD_PARAMS) {
     render_bwd_dispatch<false, false, true>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
 }
-__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_r1_fast_kernel(E3_RENDER_BWD_PARAMS) {
+__global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_WAVES) void render_bwd_fast_kernel(E3_RENDER_BWD_PARAMS) {
     render_bwd_dispatch<false, true, true>(E3_RENDER_BWD_ARGS, nullptr, nullptr, lpt_cnt, lpt_list, lpt_cap, r1);
 }
 __global__ __launch_bounds__(BWD_WAVES * WAVE, E3_BWD_STATS_WAVES) void render_bwd_stats_kernel(
@@ -948,7 +942,30 @@ __device__ __forceinline__ void sh_basis(int k, float x, float y, float z, float
     case 13: Y = C34 * x * (4.0f * zz - xx - yy); Yx = C34 * (4.0f * zz - 3.0f * xx - yy); Yy = C34 * -2.0f * xy;
              Yz = C34 * 8.0f * xz; break;
     case 14: Y = C35 * z * (xx - yy); Yx = C35 * 2.0f * xz; Yy = C35 * -2.0f * yz; Yz = C35 * (xx - yy); break;
-    default: Y = C36 * x * (xx - 3.0f * yy); Yx = C36 * (3.0f * xx - 3.0f * yy); Yy = C36 * -6.0f * xy; Yz = 0.0f; break;
+    case 15: Y = C36 * x * (xx - 3.0f * yy); Yx = C36 * (3.0f * xx - 3.0f * yy); Yy = C36 * -6.0f * xy; Yz = 0.0f; break;
+    default: {        // degree 4 (utils/sh_utils.py:97-110): the polynomials and partial derivatives of sh_backward<4>
+        const float C40 = 2.5033429417967046f, C41 = -1.7701307697799304f, C42 = 0.9461746957575601f,
+                    C43 = -0.6690465435572892f, C44 = 0.10578554691520431f, C45 = -0.6690465435572892f,
+                    C46 = 0.47308734787878004f, C47 = -1.7701307697799304f, C48 = 0.6258357354491761f;
+        switch (k) {
+        case 16: Y = C40 * xy * (xx - yy); Yx = C40 * y * (3.0f * xx - yy); Yy = C40 * x * (xx - 3.0f * yy); Yz = 0.0f; break;
+        case 17: Y = C41 * yz * (3.0f * xx - yy); Yx = C41 * 6.0f * xy * z; Yy = C41 * z * (3.0f * xx - 3.0f * yy);
+                 Yz = C41 * y * (3.0f * xx - yy); break;
+        case 18: Y = C42 * xy * (7.0f * zz - 1.0f); Yx = C42 * y * (7.0f * zz - 1.0f); Yy = C42 * x * (7.0f * zz - 1.0f);
+                 Yz = C42 * 14.0f * xy * z; break;
+        case 19: Y = C43 * yz * (7.0f * zz - 3.0f); Yx = 0.0f; Yy = C43 * z * (7.0f * zz - 3.0f);
+                 Yz = C43 * y * (21.0f * zz - 3.0f); break;
+        case 20: Y = C44 * (zz * (35.0f * zz - 30.0f) + 3.0f); Yx = 0.0f; Yy = 0.0f; Yz = C44 * z * (140.0f * zz - 60.0f); break;
+        case 21: Y = C45 * xz * (7.0f * zz - 3.0f); Yx = C45 * z * (7.0f * zz - 3.0f); Yy = 0.0f;
+                 Yz = C45 * x * (21.0f * zz - 3.0f); break;
+        case 22: Y = C46 * (xx - yy) * (7.0f * zz - 1.0f); Yx = C46 * 2.0f * x * (7.0f * zz - 1.0f);
+                 Yy = C46 * -2.0f * y * (7.0f * zz - 1.0f); Yz = C46 * 14.0f * z * (xx - yy); break;
+        case 23: Y = C47 * xz * (xx - 3.0f * yy); Yx = C47 * z * (3.0f * xx - 3.0f * yy); Yy = C47 * -6.0f * xy * z;
+                 Yz = C47 * x * (xx - 3.0f * yy); break;
+        default: Y = C48 * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy)); Yx = C48 * x * (4.0f * xx - 12.0f * yy);
+                 Yy = C48 * y * (4.0f * yy - 12.0f * xx); Yz = 0.0f; break;
+        }
+    } break;
     }
 }
 
@@ -956,7 +973,10 @@ __device__ __forceinline__ void sh_basis(int k, float x, float y, float z, float
 #ifndef E3_GEOM_DEFER_OCC
 #define E3_GEOM_DEFER_OCC 4
 #endif
-template <bool DEFER>
+// NK: coefficients per channel the SH loop is unrolled for -- 16 (degrees 0..3, the reference model's; the instantiation
+// every training path runs) or 25 (degree 4, utils/sh_utils.py:97-110: a caller of the multi-view entry points with
+// (P, 25, 3) coefficients)
+template <bool DEFER, int NK = 16>
 __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_multi_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ opac_in,
@@ -1081,7 +1101,7 @@ __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_m
     }
     const int nk = (D + 1) * (D + 1);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < NK; ++k) {
         if (k < nk) {
             // (unseen Gaussians do not read their coefficients: exec-masked loads)
             const float c0 = seen ? sh[(size_t)(3 * k) * st] : 0.0f, c1 = seen ? sh[(size_t)(3 * k + 1) * st] : 0.0f,
@@ -1414,10 +1434,6 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
                 g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
                 background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles,
                 r1, dL_dpix_stats, part2);
-        else if (r1.mask != 0u)
-            (fast ? render_bwd_r1_fast_kernel : render_bwd_r1_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
-                g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
-                background, img.final_T, img.n_contrib, bin.perm, bin.strip_mask, dL_dpix, grad_acc, lc, ll, (uint32_t)ntiles, r1);
         else
             (fast ? render_bwd_fast_kernel : render_bwd_kernel)<<<dim3((nslots + BWD_WAVES - 1) / BWD_WAVES), dim3(BWD_WAVES * WAVE), 0, s>>>(
                 g_trace, nslots, tiles_per_view, ord, gx, W, H, img.ranges, bin.emit_gid, geom.rec,
@@ -1481,7 +1497,8 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
         MultiViews mv;
         mv.vs = vs; mv.radii = radii; mv.clamped = geom.clamped; mv.gsum = gsum;
         mv.stats = (dL_dpix_stats && num_rendered > 0) ? 1 : 0;
-        ((flags & E3_FLAG_DEFER_SH_MEAN) != 0 && !dL_dsh && dL_dcolour_views ? geom_bwd_multi_kernel<true> : geom_bwd_multi_kernel<false>)<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+        ((flags & E3_FLAG_DEFER_SH_MEAN) != 0 && !dL_dsh && dL_dcolour_views ? geom_bwd_multi_kernel<true>
+         : (D > 3 ? geom_bwd_multi_kernel<false, 25> : geom_bwd_multi_kernel<false>))<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
             P, D, M, means3D, shs, scales, rots, opacities, mv, flags, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dsh,
             dL_dscale, dL_drot, dL_dcolour_views);
     }

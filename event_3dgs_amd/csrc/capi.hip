@@ -130,8 +130,9 @@ static int make_batch(int nviews, int P, const float* const* viewmatrix, const f
     return 0;
 }
 
-// max_degree: 4 for the single-view operator (utils/sh_utils.py:57-112 goes that far), 3 for the several-views-in-one-pass
-// entry points (their per-Gaussian backward keeps 16 coefficients per channel; the trainer's layout is 16 too)
+// max_degree: 4 (utils/sh_utils.py:57-112 goes that far) for the operator and for the several-views-in-one-pass entry
+// points; 3 where a stage keeps the reference model's 16 coefficients per channel (the deferred colour stage, the
+// colour-gradient route of the multi-view backward and the SH optimizer kernels behind it: the trainer's layout)
 static int check_forward_args(int P, int D, int M, int width, int height, const float* shs, const float* colors_precomp,
                               const float* scales, const float* rotations, const float* cov3D_precomp, int flags,
                               int max_degree = 4) {
@@ -272,7 +273,7 @@ int e3dgs_rasterize_forward_multi(e3dgs_alloc_fn geom_alloc, void* geom_user, e3
                                   const float* tan_fovy, float* out_color, int* radii, int debug, int flags,
                                   int* num_rendered_host, void* stream) {
     g_err[0] = 0;
-    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags, 3);
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags, 4);
     if (rc) return rc;
     ViewBatch vb;
     rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
@@ -292,7 +293,10 @@ int e3dgs_rasterize_forward_multi_begin(e3dgs_alloc_fn geom_alloc, void* geom_us
                                         const float* const* cam_pos, const float* tan_fovx, const float* tan_fovy,
                                         int* radii, int debug, int flags, int* num_rendered_host, void* stream) {
     g_err[0] = 0;
-    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags, 3);
+    // (degree 4 -- 25 coefficients -- is served by the same projection kernel; the separate colour stage of
+    // E3DGS_FLAG_DEFER_COLOR and the colour-gradient route of the backward keep the reference model's 16)
+    int rc = check_forward_args(P, D, M, width, height, shs, colors_precomp, scales, rotations, cov3D_precomp, flags,
+                                (flags & E3_FLAG_DEFER_COLOR) ? 3 : 4);
     if (rc) return rc;
     ViewBatch vb;
     rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
@@ -349,7 +353,8 @@ int e3dgs_rasterize_forward_multi_capacity(e3dgs_alloc_fn geom_alloc, void* geom
                                            int* num_rendered_host, e3dgs_notify_fn before_colour, void* notify_user,
                                            void* stream) {
     g_err[0] = 0;
-    int rc = check_forward_args(P, D, M, width, height, shs, nullptr, scales, rotations, nullptr, flags, 3);
+    int rc = check_forward_args(P, D, M, width, height, shs, nullptr, scales, rotations, nullptr, flags,
+                                (flags & E3_FLAG_DEFER_COLOR) ? 3 : 4);
     if (rc) return rc;
     if (capacity < 1) return e3_fail(hipErrorInvalidValue, "capacity must be positive");
     if (!num_rendered_host || !(flags & E3_FLAG_COUNT_MAPPED))
@@ -407,7 +412,12 @@ static int backward_multi(int nviews, int P, int D, int M, int num_rendered, con
     int rc = make_batch(nviews, P, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, vb);
     if (rc) return rc;
     if (P > 0 && (!shs || !scales || !rotations)) return e3_fail(hipErrorInvalidValue, "shs + scales + rotations are required");
-    if (D < 0 || D > 3 || M < (D + 1) * (D + 1)) return e3_fail(hipErrorInvalidValue, "SH degree must be 0..3 and M >= (D+1)^2");
+    // degree 4 (utils/sh_utils.py:97-110) with the SH gradient itself as output; the colour-gradient route (dL_dcolour_views:
+    // the trainer's, whose SH optimizer kernels hold 16 coefficients per channel) keeps the reference model's degrees 0..3
+    const int max_degree = dL_dcolour_views ? 3 : 4;
+    if (D < 0 || D > max_degree || M < (D + 1) * (D + 1))
+        return e3_fail(hipErrorInvalidValue, max_degree == 4 ? "SH degree must be 0..4 and M >= (D+1)^2"
+                                                             : "SH degree must be 0..3 (with dL_dcolour_views) and M >= (D+1)^2");
     // nviews == 1 runs the general single-view kernel (unless dL_dcolour_views is taken), so pass 2 to apply the
     // multi-view argument rules always
     // dL_dsh may be NULL when the caller takes the per-view colour gradients instead (e3dgs_sh_grad_from_colour)

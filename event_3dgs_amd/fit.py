@@ -49,12 +49,8 @@ def fit_event_scene(params, train_cameras, event_cameras, bg, device, iterations
         raise ValueError("mode must be 'event', 'gray' or 'rgb'")
     if opacity_reset_interval is None:              # train.py:119 forces 10000 in event mode; arguments/__init__.py: 3000
         opacity_reset_interval = 10000 if mode == "event" else 3000
-    if mode == "event" and "factorize_sh" not in trainer_kw:
-        # every rank sees the same camera lists: if their frames are not all of one size a triplet can mix resolutions,
-        # and the factorised SH exchange (which needs the fused multi-view pass) is switched off for the whole run
-        sizes = {(int(c.image_height), int(c.image_width)) for c in list(train_cameras) + list(event_cameras)}
-        if len(sizes) > 1:
-            trainer_kw["factorize_sh"] = False
+    # (a dataset whose frames are not all of one size needs no special case: a triplet that mixes resolutions runs as two
+    # multi-view passes and hands out the colour-gradient block every exchange expects, EventTrainer._compute_gradients_two_sizes)
     tr = EventTrainer(params, device, spatial_lr_scale=cameras_extent, active_sh_degree=start_sh_degree,
                       track_densification_stats=True, **trainer_kw)
     stats = densify.DensifyStats(tr.N, device)

@@ -139,9 +139,8 @@ class EventTrainer:
         # their camera centres (9 instead of 48 floats per Gaussian and rank) and each rebuilds the mean SH gradient
         # (e3dgs_sh_grad_from_colour).  E3DGS_FACTORIZE_SH=0 falls back to averaging the SH gradient itself.
         # The choice is made ONCE, at construction, identically on every rank (it decides which collectives a rank
-        # issues): a dataset whose triplets may mix frame sizes (utils/camera_utils.py:19-52 sizes every image on its
-        # own) must be trained with factorize_sh=False -- the mixed-size fallback of compute_gradients() has no per-view
-        # colour gradients to exchange, and ranks that disagree about the exchange would issue different collectives.
+        # issues).  A triplet that mixes frame sizes (utils/camera_utils.py:19-52 sizes every image on its own) hands out
+        # the same three-view colour-gradient block (_compute_gradients_two_sizes), so it takes part in either exchange.
         if factorize_sh is None:
             env = os.environ.get("E3DGS_FACTORIZE_SH")
             # by the bytes that cross the links (parallel.sh_exchange_bytes): 9 floats per Gaussian from every other rank
@@ -513,21 +512,28 @@ class EventTrainer:
     CAPACITY_MARGIN = 1.25
     CAPACITY_KEYS = 4
 
-    def _forward_views(self, settings):
+    def _forward_views(self, settings, slot=0):
         """The renders of one iteration as ONE multi-view pass.  Without a known capacity (first iteration, new size):
         begin -> host wait for the count -> finish, and the count seeds the capacity.  Afterwards: everything enqueued
-        at once with the binning buffers sized by the capacity; _count_fits() is called once the backward is enqueued."""
+        at once with the binning buffers sized by the capacity; _count_fits() is called once the backward is enqueued.
+        slot: which scratch pool / count word the pass uses (an iteration that needs TWO passes whose results live side by
+        side -- a triplet with two frame sizes -- gives the second one slot 1)."""
         v = self.views
         flags = self.FWD_FLAGS | _lib.FLAG_COUNT_MAPPED
         if self.overlap_features:
             flags |= _lib.FLAG_DEFER_COLOR         # projection / sorts / binning do not read the SH coefficients ...
         if self._counts is None:
             self._counts = torch.zeros(1, dtype=torch.int32).pin_memory()
+        counts, pool = self._counts, self._pool
+        if slot:
+            if getattr(self, "_slot1", None) is None:
+                self._slot1 = (torch.zeros(1, dtype=torch.int32).pin_memory(), rasterizer.ScratchPool(self.device))
+            counts, pool = self._slot1
         key = (self.N, len(settings), int(settings[0].image_height), int(settings[0].image_width))
         cap = self._capacity.get(key) if self.no_host_wait else None
         if cap is None:
             pend = rasterizer.forward_multi_begin(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"],
-                                                  settings, flags=flags, count_host=self._counts, pool=self._pool)
+                                                  settings, flags=flags, count_host=counts, pool=pool)
             pend.before_colour = self.sync_features    # ... whose update (side stream) must be done before the colour kernel
             rasterizer.prepare_multi_finish(pend)      # (host work done while the GPU still computes the count)
             rasterizer.wait_count(pend)                # the host wait: the instance count (polled)
@@ -535,7 +541,7 @@ class EventTrainer:
             self._note_count(key, raw["num_rendered"])
             return raw
         raw = rasterizer.forward_multi_capacity(v["xyz"], v["features"], v["opacity"], v["scaling"], v["rotation"], settings,
-                                                cap, self._counts, flags=flags, pool=self._pool,
+                                                cap, counts, flags=flags, pool=pool,
                                                 before_colour=self.sync_features if self.overlap_features else None)
         raw["capacity_key"] = key
         return raw
@@ -591,16 +597,10 @@ class EventTrainer:
         gt_int, gt_now, gt_next, gt_blur = plane(gt_int), plane(gt_now), plane(gt_next), plane(gt_blur)
         settings = [self._settings(c, bg) for c in (cam_int, cam_now, cam_next)]
         sizes = {(int(s.image_height), int(s.image_width)) for s in settings}
+        need_vs = self.track_stats and viewspace_grad
         if len(sizes) != 1:
             # the reference sizes every image on its own (utils/camera_utils.py:19-52): a triplet may mix resolutions
-            if self.factorize_sh:
-                # (this rank would all-reduce the SH gradient while the ranks with a uniform triplet all-gather colour
-                # gradients: mismatched collectives hang or corrupt the exchange)
-                raise ValueError("a camera triplet with mixed frame sizes cannot be trained with the factorised SH "
-                                 "exchange: construct EventTrainer(..., factorize_sh=False) on every rank (or set "
-                                 "E3DGS_FACTORIZE_SH=0) for datasets that mix resolutions")
-            return self._compute_gradients_separate(settings, gt_int, gt_now, gt_next, gt_blur)
-        need_vs = self.track_stats and viewspace_grad
+            return self._compute_gradients_two_sizes(settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour, need_vs)
         shared = self.share_coincident_views and self._views_coincide(cam_int, cam_now, settings)
         if shared and need_vs:
             # launches that do not fill the GPU several times over gain nothing: a third view composites beside the other
@@ -744,45 +744,81 @@ class EventTrainer:
                                   stats_grad_view0=d_int if (shared and want_vs) else None, rank1=r1)
         return scalars, raw
 
-    def _compute_gradients_separate(self, settings, gt_int, gt_now, gt_next, gt_blur):
-        """The same iteration with one rasteriser call per camera, for triplets whose frames differ in size (the fused
-        multi-view pass renders all views of a call at one resolution).  The event pair must share a size (the contrast
-        is a per-pixel difference, utils/loss_utils.py:234-249); the intensity frame is free.  Slower (three forward /
-        backward passes, gradients accumulated with E3DGS_FLAG_ACCUMULATE), same mathematics:
-        loss = 0.9 L1(contrast) rho + 0.1 L1(intensity) (1 - rho)  [+ deblur], train.py:165-203."""
-        self.sync_features()
-        v = self.views
+    def _compute_gradients_two_sizes(self, settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour, need_vs):
+        """The same iteration for a triplet whose intensity frame has another size than the event pair (the contrast is a
+        per-pixel difference, utils/loss_utils.py:234-249: the two event frames must agree): TWO multi-view passes --
+        [intensity] and [now, next] -- each with the whole fused pipeline (in-kernel activations, rank-1 contrast gradients,
+        per-view colour gradients instead of the SH gradient where the caller takes that route, no host wait), their
+        non-SH gradients added.  Everything downstream -- the SH optimizer kernel on one rank, the factorised exchange
+        under DP -- sees the three views' colour-gradient block it always sees, so a dataset that mixes resolutions keeps
+        the fused path and the collectives of every other rank.  Same mathematics as train.py:165-203:
+        loss = 0.9 L1(contrast) rho + 0.1 L1(intensity) (1 - rho)  [+ deblur]."""
         if (settings[1].image_height, settings[1].image_width) != (settings[2].image_height, settings[2].image_width):
             raise ValueError("the two event frames of an iteration must have the same size")
-        raws = [rasterizer.forward_raw(v["xyz"], v["features"], None, v["opacity"], v["scaling"], v["rotation"], None, s,
-                                       flags=self.FWD_FLAGS) for s in settings]
-        img, now, nxt = (r["color"] for r in raws)
-        f32 = lambda t: t.to(torch.float32).contiguous()
-        # contrast term with the event-loss kernel (intensity slot fed its own target: L1 = 0 there) -> rho, dL/dc
-        sc, _, d_now, d_next = losses.event_loss_raw(now, now, nxt, self.c, now, f32(gt_now), f32(gt_next), None)
-        rho = sc[2]
-        e_int = img - f32(gt_int)
-        l1_int = e_int.abs().mean()
-        d_img = (0.1 * (1.0 - rho) / e_int.numel()) * torch.sign(e_int)
-        loss = sc[0] + 0.1 * l1_int * (1.0 - rho)
-        dc = sc[1]
-        if gt_blur is not None:                                            # train.py:197-203
-            e_b = img - f32(gt_blur)
-            loss = 0.5 * loss + 0.5 * e_b.abs().mean()
-            d_img = 0.5 * d_img + (0.5 / e_b.numel()) * torch.sign(e_b)
-            d_now, d_next, dc = 0.5 * d_now, 0.5 * d_next, 0.5 * dc
-        scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
-        scalars[0], scalars[1], scalars[2], scalars[3], scalars[4] = loss, dc, rho, sc[3], l1_int
+        f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
         g = self.grads
-        self.flat_grad.zero_()
-        for k, (raw, dpix) in enumerate(zip(raws, (d_img, d_now, d_next))):
-            out = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
-            if self.track_stats and k == 0:
-                out["means2D"] = self.viewspace_grad        # densification statistics use render #1 only (train.py:145)
-            rasterizer.backward_raw(raw, dpix.contiguous(), out, flags=self.FWD_FLAGS | _lib.FLAG_ACCUMULATE)
+        if getattr(self, "_grad2", None) is None or self._grad2.numel() != self.flat_grad.numel():
+            self._grad2 = torch.empty_like(self.flat_grad)
+        g2 = {name: self._grad2[off:off + n].view(self.grads[name].shape) for name, (off, n) in self.seg.items() if name != "c"}
+        for _attempt in range(4):
+            raw_i = self._forward_views(settings[:1], slot=1)
+            raw_e = self._forward_views(settings[1:], slot=0)
+            img, now, nxt = raw_i["color"][0], raw_e["color"][0], raw_e["color"][1]
+            # contrast term with the event-loss kernel: the intensity slot is fed a frame of the PAIR's size as render and
+            # target (L1 = 0 there, no gradient) -> rho, L1(contrast), dL/dc, and the two contrast renders' pixel gradients
+            dpix_e = torch.zeros_like(raw_e["color"])
+            out_l = (torch.empty(8, device=self.device), torch.empty_like(now), dpix_e[0], dpix_e[1],
+                     torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(now.shape[2], now.shape[1]), dtype=torch.uint8,
+                                 device=self.device))
+            sc, _, _, _ = losses.event_loss_raw(f32(gt_now), now, nxt, self.c, f32(gt_now), f32(gt_now), f32(gt_next), None,
+                                                out=out_l, rank1=self.rank1)
+            rho = sc[2]
+            e_int = img - f32(gt_int)
+            l1_int = e_int.abs().mean()
+            d_img = (0.1 * (1.0 - rho) / e_int.numel()) * torch.sign(e_int)
+            loss = sc[0] + 0.1 * l1_int * (1.0 - rho)
+            dc = sc[1]
+            if gt_blur is not None:                                            # train.py:197-203
+                e_b = img - f32(gt_blur)
+                loss = 0.5 * loss + 0.5 * e_b.abs().mean()
+                d_img = 0.5 * d_img + (0.5 / e_b.numel()) * torch.sign(e_b)
+                dpix_e.mul_(0.5)
+                dc = 0.5 * dc
+            scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+            scalars[0], scalars[1], scalars[2], scalars[3], scalars[4] = loss, dc, rho, sc[3], l1_int
+            # ---- backward: pass [intensity] into the gradient buffer, pass [now, next] into a second one
+            out_i = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
+            out_e = dict(means3D=g2["xyz"], sh=g2["features"], opacities=g2["opacity"], scales=g2["scaling"], rots=g2["rotation"])
+            via_colour = self.factorize_sh or sh_via_colour
+            if via_colour:
+                both = dict(out_i)
+                self._colour_gradients_instead_of_sh(both, settings, pad_to=3 if self.multi else None)
+                cv = both["colour_views"]
+                out_i["sh"] = out_e["sh"] = None
+                out_i["colour_views"], out_e["colour_views"] = cv[0:1], cv[1:3]
+            else:
+                self._packed_views = 0
+            if need_vs:
+                out_i["means2D"] = self.viewspace_grad              # densification statistics use render #1 only (train.py:145)
+            rasterizer.backward_multi(raw_i, d_img.contiguous()[None], out_i, flags=self._backward_flags(raw_i, sh_via_colour))
+            r1 = {0: rasterizer.LUV_WEIGHTS, 1: rasterizer.LUV_WEIGHTS} if self.rank1 else None
+            rasterizer.backward_multi(raw_e, dpix_e, out_e, flags=self._backward_flags(raw_e, sh_via_colour), rank1=r1)
+            fits = [self._count_fits(raw_i), self._count_fits(raw_e)]
+            if all(fits):
+                break
+        else:
+            raise RuntimeError("the instance count kept outgrowing the binning capacity")
+        # sum of the two passes (the SH segment only when its gradient is in memory)
+        x_off, x_n = self.seg["xyz"]
+        t_off = self.seg["opacity"][0]
+        t_end = self.seg["c"][0]
+        self.flat_grad[x_off:x_off + x_n].add_(self._grad2[x_off:x_off + x_n])
+        self.flat_grad[t_off:t_end].add_(self._grad2[t_off:t_end])
+        if not via_colour:
+            f_off, f_n = self.seg["features"]
+            self.flat_grad[f_off:f_off + f_n].add_(self._grad2[f_off:f_off + f_n])
         self.c_grad.copy_(scalars[1:2])
-        self._packed_views = 0                          # several ranks: the SH gradient itself is exchanged
-        self.last_radii = raws[0]["radii"]
+        self.last_radii = raw_i["radii"][0]
         self.last_scalars = scalars
         return scalars
 

@@ -265,6 +265,55 @@ def test_two_ranks_one_of_them_with_a_shared_pose_triplet(tmp_path):
     assert float((r0["flat"] - ta.flat.cpu()).abs().max()) <= 0.05
 
 
+def _mixed_size_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams, gts, bg = _inputs(rank)
+    if rank == 1:             # this rank's intensity frame has another size than its event pair (utils/camera_utils.py:19-52)
+        cams = [orbit_camera(3, 16, 160, 112, device=DEV), cams[1], cams[2]]
+        gts = [EventTrainer(params, DEV).render_raw(cams[0], bg)["color"].clone(), gts[1], gts[2]]
+    tr = EventTrainer(params, DEV)
+    assert tr.factorize_sh and tr.overlap_features
+    for _ in range(STEPS):
+        tr.step(*cams, *gts, bg)
+    tr.sync_features()
+    torch.cuda.synchronize()
+    torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu()}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_of_them_with_a_mixed_size_triplet(tmp_path):
+    """Rank 1's intensity frame is smaller than its event pair: it runs two multi-view passes and still hands the
+    factorised exchange the three-view colour-gradient block every rank all-gathers -- no mismatched collectives, replicas
+    bit-identical, and the update tracks the mean-of-gradients emulation."""
+    out = str(tmp_path / "mx")
+    mp.spawn(_mixed_size_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in ("flat", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), k
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    pa, ca, ga, bg = _inputs(0)
+    pb, cb, gb, _ = _inputs(1)
+    cb = [orbit_camera(3, 16, 160, 112, device=DEV), cb[1], cb[2]]
+    gb = [EventTrainer(pb, DEV).render_raw(cb[0], bg)["color"].clone(), gb[1], gb[2]]
+    ta, tb = EventTrainer(pa, DEV, overlap_features=False), EventTrainer(pb, DEV, overlap_features=False)
+    for _ in range(STEPS):
+        ta.compute_gradients(*ca, *ga, bg)
+        tb.compute_gradients(*cb, *gb, bg)
+        mean = (ta.flat_grad + tb.flat_grad).div_(2)
+        ta.flat_grad.copy_(mean); tb.flat_grad.copy_(mean)
+        ta.apply_update(); tb.apply_update()
+    torch.cuda.synchronize()
+    m_ref, m_got = ta.exp_avg.cpu(), r0["m"]
+    assert float((m_got - m_ref).norm() / m_ref.norm()) < 1e-4
+    assert float((r0["flat"] - ta.flat.cpu()).abs().max()) <= 0.05
+
+
 def _image_worker(rank, world, port, out, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

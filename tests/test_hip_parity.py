@@ -773,3 +773,56 @@ def test_fast_exp_mode_is_a_counted_tolerance_mode(N, W, H):
     for k in grads[0]:
         assert np.isfinite(grads[1][k]).all(), k
         assert rel_l2(grads[1][k], grads[0][k]) <= GRAD_TOL, (k, rel_l2(grads[1][k], grads[0][k]))
+
+
+@pytest.mark.parametrize("nviews", [2, 3])
+def test_sh_degree_4_in_the_multi_view_pass(nviews):
+    """SH degree 4 (25 coefficients per channel, utils/sh_utils.py:97-110) through e3dgs_rasterize_forward_multi /
+    _backward_multi: every view's image bit-identical to the single-view operator and to the C oracle, the gradients of
+    the one multi-view backward == the oracle's summed over the views, the coefficients 16..24 included; the
+    colour-gradient route (the trainer's 16-coefficient layout) refuses degree 4."""
+    import math
+    from event_3dgs_amd import _lib, rasterizer
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.rasterizer import GaussianRasterizationSettings
+    from helpers import per_gaussian_err
+    from oracle import c_oracle
+    dev = torch.device("cuda:0")
+    N, W, H = 1500, 144, 96
+    act, _ = scene(N, W, H, seed=44)
+    act["shs"] = torch.cat((act["shs"], 0.05 * torch.randn(N, 9, 3, generator=torch.Generator().manual_seed(4))), dim=1)
+    cams = [orbit_camera(k, 8, W, H, radius=4.0) for k in range(nviews)]
+    bg = (0.2, 0.1, 0.0)
+    bg_t = torch.tensor(bg, device=dev)
+    settings = [GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg_t, 1.0,
+                                              c.world_view_transform.to(dev), c.full_proj_transform.to(dev), 4,
+                                              c.camera_center.to(dev), False, False) for c in cams]
+    d = {k: v.to(dev).contiguous() for k, v in act.items()}
+    raw = rasterizer.forward_multi(d["means3D"], d["shs"], d["opacities"], d["scales"], d["rotations"], settings)
+    gw = torch.randn(nviews, 3, H, W, generator=torch.Generator().manual_seed(9))
+    nan = lambda *s: torch.full(s, float("nan"), device=dev)
+    out = dict(means3D=nan(N, 3), sh=nan(N, 25, 3), opacities=nan(N, 1), scales=nan(N, 3), rots=nan(N, 4), means2D=nan(N, 3))
+    rasterizer.backward_multi(raw, gw.to(dev), out)
+    ref = {k: 0.0 for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    for k, cam in enumerate(cams):
+        f = c_oracle.Forward(**oracle_kwargs(act, cam, bg, True, False, sh_degree=4))
+        assert np.array_equal(raw["radii"][k].cpu().numpy(), f.radii), k
+        assert np.array_equal(raw["color"][k].cpu().numpy(), f.out_color), k
+        gb = f.backward(gw[k].numpy())
+        for name in ref:
+            ref[name] = ref[name] + np.asarray(gb[name], np.float64)
+        if k == 0:
+            m2 = np.asarray(gb["means2D"])
+        f.close()
+    got = dict(means3D=out["means3D"], shs=out["sh"], opacities=out["opacities"], scales=out["scales"], rotations=out["rots"])
+    assert np.abs(ref["shs"].reshape(N, 25, 3)[:, 16:]).max() > 0
+    for name, t in got.items():
+        a = t.cpu().numpy()
+        b = ref[name].reshape(a.shape)
+        assert np.isfinite(a).all(), name
+        assert rel_l2(a, b) <= GRAD_TOL, (name, rel_l2(a, b))
+        assert per_gaussian_err(a.reshape(N, -1), b.reshape(N, -1)) <= 1e-3, name
+    assert rel_l2(out["means2D"].cpu().numpy(), m2.reshape(N, 3)) <= GRAD_TOL          # view 0's screen-space gradient
+    with pytest.raises(_lib.HipLibraryError, match="0..3"):
+        out["colour_views"] = nan(nviews, N, 3)
+        rasterizer.backward_multi(raw, gw.to(dev), out)

@@ -912,10 +912,12 @@ def _kernel_activations(leaves):
     return ts + (s - ts).detach(), tq + (q - tq).detach(), to + (o.reshape(to.shape) - to).detach()
 
 
-def test_triplet_with_mixed_resolutions_falls_back_to_per_view_calls():
+def test_triplet_with_mixed_resolutions_runs_as_two_multi_view_passes():
     """utils/camera_utils.py:19-52 sizes every image on its own: an intensity frame at another resolution than the event
-    pair.  The trainer renders the three views separately; gradients equal the autograd composition of the reference's
-    formulas (torch) over the drop-in operator."""
+    pair.  The trainer renders [intensity] and [now, next] as two multi-view passes (EventTrainer._compute_gradients_two_sizes);
+    gradients equal the autograd composition of the reference's formulas (torch) over the drop-in operator, and the whole
+    step -- SH gradient rebuilt from the three views' colour gradients inside the SH optimizer kernel -- equals
+    compute_gradients() + apply_update() with the SH gradient in memory."""
     from event_3dgs_amd.cameras import orbit_camera
     from event_3dgs_amd.rasterizer import rasterize_gaussians
     from event_3dgs_amd.train_step import EventTrainer
@@ -950,6 +952,15 @@ def test_triplet_with_mixed_resolutions_falls_back_to_per_view_calls():
         assert float(tr.viewspace_grad.abs().max()) > 0
         tr.apply_update()
         assert torch.isfinite(tr.flat).all()
+        # step() (colour-gradient route + deferred SH position term) == the form with the whole gradient in memory
+        a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
+        for _ in range(3):
+            sa = a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
+            sb = b.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur).clone()
+            b.apply_update()
+            assert torch.equal(sa[:5], sb[:5])
+        assert torch.equal(a.flat, b.flat) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+        assert a.count_retries == 0 and a._packed_views == 0
 
 
 @pytest.mark.parametrize("deblur", [False, True])
