@@ -105,20 +105,27 @@ class ScratchPool:
 
 
 class _Scratch:
-    """One growable uint8 torch tensor handed to the C ABI through an allocation callback."""
+    """One growable uint8 torch tensor handed to the C ABI through an allocation callback.  The callback closes over a
+    holder list, not over the object: a ctypes callback that references its owner forms a cycle (object -> callback ->
+    bound method -> object) that only the cyclic garbage collector frees -- with ~1 GB of scratch per forward behind it, a
+    loop that keeps the collector out of its timing (bench.py, timeit) would allocate fresh device memory every call."""
 
     def __init__(self, device, pool=None, name=None):
         self.device = device
         self.pool, self.name = pool, name
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _lib.ALLOC_FN(self._alloc)
+        holder = self._holder = [torch.empty(0, dtype=torch.uint8, device=device)]
 
-    def _alloc(self, _user, nbytes):
-        if self.pool is not None:
-            self.tensor = self.pool.get(self.name, nbytes)
-        else:
-            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-        return self.tensor.data_ptr()
+        def alloc(_user, nbytes):
+            if pool is not None:
+                holder[0] = pool.get(name, nbytes)
+            else:
+                holder[0] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            return holder[0].data_ptr()
+        self.cb = _lib.ALLOC_FN(alloc)
+
+    @property
+    def tensor(self):
+        return self._holder[0]
 
 
 def _mark_visible(pos, view, proj):

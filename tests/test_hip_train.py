@@ -952,14 +952,21 @@ def test_triplet_with_mixed_resolutions_runs_as_two_multi_view_passes():
         assert float(tr.viewspace_grad.abs().max()) > 0
         tr.apply_update()
         assert torch.isfinite(tr.flat).all()
-        # step() (colour-gradient route + deferred SH position term) == the form with the whole gradient in memory
+        # step() (colour-gradient route + deferred SH position term) against the form with the whole gradient in memory: the
+        # two passes' position gradients are added before / after the SH view-direction terms -- fp32 association, not bits
         a, b = EventTrainer(params, DEV), EventTrainer(params, DEV)
-        for _ in range(3):
+        for it in range(3):
             sa = a.step(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur)
             sb = b.compute_gradients(cams[0], cams[1], cams[2], gts[0], gts[1], gts[2], bg, gt_blur=blur).clone()
             b.apply_update()
-            assert torch.equal(sa[:5], sb[:5])
-        assert torch.equal(a.flat, b.flat) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+            if it == 0:
+                assert torch.equal(sa[:5], sb[:5])
+            assert torch.allclose(sa[:5], sb[:5], rtol=1e-4, atol=0)
+        assert rel_l2(a.exp_avg.cpu().numpy(), b.exp_avg.cpu().numpy()) <= 1e-5
+        assert rel_l2(a.exp_avg_sq.cpu().numpy(), b.exp_avg_sq.cpu().numpy()) <= 1e-5
+        f_off, f_n = a.seg["features"]
+        assert torch.equal(a.exp_avg[f_off:f_off + f_n], b.exp_avg[f_off:f_off + f_n]) or \
+            rel_l2(a.exp_avg[f_off:f_off + f_n].cpu().numpy(), b.exp_avg[f_off:f_off + f_n].cpu().numpy()) <= 1e-5
         assert a.count_retries == 0 and a._packed_views == 0
 
 
