@@ -11,8 +11,9 @@
      kernels, and the FINGERPRINT of the sources the profiled library was built from (bench.py compares it with the
      sources it runs on and marks the numbers stale when they differ).
 
-All passes profile `python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-substep` (the 3-view launches of the
-benchmark iteration are the largest launches of each kernel: max over launches).  PMC passes carry no trace domain
+The duration pass profiles the driver's window, `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-substep`; the
+counter passes `--steps 4 --warmup 2` (the 3-view launches of the benchmark iteration are the largest launches of each
+kernel: max over launches).  PMC passes carry no trace domain
 besides kernel dispatch.  gfx950 corrections (MI355X_MICROARCH.md, re-calibrated with tools/ubench/pmc_calib.hip):
 FETCH_SIZE counts 128-byte line requests at 64 bytes -> x2; WRITE_SIZE x1.  Afterwards, in the build container:
 `python profiles/collect.py --install <tag>` copies the summaries into profiles/<tag>/ and profiles/traffic.json.
@@ -55,11 +56,11 @@ def kname(r):
     return r["Kernel_Name"].split("(")[0]
 
 
-def rocprof(out, name, extra):
+def rocprof(out, name, extra, steps=4, warmup=2):
     d = os.path.join(out, name)
     cmd = ["rocprofv3"] + extra + ["-d", d, "-o", name, "--output-format", "csv", "--", sys.executable,
-                                   os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                                   "--no-substep"]
+                                   os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup),
+                                   "--no-cpu-baseline", "--no-substep"]
     with open(os.path.join(out, name + ".log"), "w") as log:
         rc = subprocess.call(cmd, stdout=log, stderr=subprocess.STDOUT, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
     files = glob.glob(os.path.join(d, "**", "*.csv"), recursive=True)
@@ -85,16 +86,19 @@ def collect(tag, head):
     out = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     os.makedirs(out, exist_ok=True)
     summary = {"source_fingerprint": source_fingerprint(), "git_head": head,
-               "command": "python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-substep (one rocprofv3 pass each)"}
+               "command": "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-substep (kernel trace); --steps 4 "
+                          "--warmup 2 (one rocprofv3 counter pass each)"}
     # ---- 1. kernel durations
-    files = rocprof(out, "trace", ["--kernel-trace", "--stats"])
+    # (the duration pass runs the DRIVER's window -- 5 warm-up + 20 timed iterations -- so that the kernel's average is
+    # taken over the launches the bench line's HIP events bracket, not over a cold 4-step run)
+    files = rocprof(out, "trace", ["--kernel-trace", "--stats"], steps=20, warmup=5)
     stats = [f for f in files if f.endswith("kernel_stats.csv")]
     if stats:
         shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
         rows = list(csv.DictReader(open(stats[0])))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
         with open(os.path.join(out, "kernel_stats_top.txt"), "w") as f:
-            f.write("rocprofv3 --kernel-trace --stats -- " + summary["command"] + "\n(one launch of every rasteriser kernel covers the 3 "
+            f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-substep\n(one launch of every rasteriser kernel covers the 3 "
                     "views of an event iteration; the single-view launches in the min column come from the ground-truth "
                     "renders bench.py makes before the timed region)\n\n")
             for r in rows[:32]:
