@@ -220,6 +220,9 @@ int e3dgs_rasterize_backward(
  * Backward needs shs + scales + rotations (no colors_precomp / cov3D_precomp); flags: PREACT, SH_PLANAR,
  * BWD_ONLY_RENDER, BWD_ONLY_GEOM.  dL_dmean2D (P,3), optional, receives view 0's screen-space gradient
  * (densification statistics use render #1 only, train.py:145).
+ * SH degree: 0..4 (utils/sh_utils.py:57-112; M >= (D+1)^2) with the SH gradient dL_dsh as output; the stages that keep the
+ * reference model's 16 coefficients per channel accept 0..3 only: E3DGS_FLAG_DEFER_COLOR (the separate colour stage),
+ * dL_dcolour_views (the colour-gradient route) and e3dgs_sh_grad_from_colour / e3dgs_sh_adam_from_colour behind it.
  */
 int e3dgs_rasterize_forward_multi(
     e3dgs_alloc_fn geom_alloc, void* geom_user,
