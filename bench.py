@@ -341,9 +341,11 @@ def main():
                 lbuf = (torch.empty(8, device=dev), torch.empty_like(im[0]), torch.empty_like(im), torch.empty(
                     L.e3dgs_event_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev))
             # the intensity slot gets its own target: its L1 is 0 and only the contrast term drives the two renders
+            # (both renders enter the loss through one luminance: rank-1 pixel gradients, as EventTrainer hands them over)
             losses.event_loss_raw(gts[0], im[0], im[1], trainer.c, gts[0], gts[1], gts[2],
-                                  out=(lbuf[0], lbuf[1], lbuf[2][0], lbuf[2][1], lbuf[3]))
-            rasterizer.backward_multi(raw2, lbuf[2], out2)
+                                  out=(lbuf[0], lbuf[1], lbuf[2][0], lbuf[2][1], lbuf[3]), rank1=trainer.rank1)
+            rasterizer.backward_multi(raw2, lbuf[2], out2, rank1={0: rasterizer.LUV_WEIGHTS, 1: rasterizer.LUV_WEIGHTS}
+                                      if trainer.rank1 else None)
         for _ in range(2):
             contrast_step()
         torch.cuda.synchronize()
