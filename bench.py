@@ -535,6 +535,14 @@ def main():
         sus_ms = 1e3 * (time.perf_counter() - ts) / n_sus
         stop[0] = True
         th.join(timeout=15)
+        # the stages at the END of the window: a slower sustained figure can be the clocks or the workload (the scene the
+        # extra iterations train is not the scene the timed region saw: opacities move, pixels saturate later, walks deepen)
+        L.e3dgs_profile_enable(0xFF)
+        for _ in range(5):
+            one_step()
+        torch.cuda.synchronize()
+        end_stages = {k: round(ms / n, 4) for k, (ms, n) in read_slots().items() if n}
+        L.e3dgs_profile_enable(0)
 
         def num(v):
             try:
@@ -550,6 +558,8 @@ def main():
                                 "board_power_w_max": max(power) if power else None,
                                 "sclk_mhz_reported_mean": round(sum(sclk) / len(sclk), 1) if sclk else None,
                                 "rocm_smi_samples": len(samples), "last_sample": samples[-1] if samples else None,
+                                "stage_avg_ms_at_the_end": end_stages,
+                                "stage_avg_ms_in_the_timed_region_s_table": {k: v["avg_ms"] for k, v in stages.items()},
                                 "in_kernel_clock_ghz": {k: (v.get("clock") or {}).get("ghz_median") for k, v in
                                                         ((roofline or {}).get("kernels") or {}).items()}}
         zero = dict(position_lr_init=0.0, position_lr_final=0.0, feature_lr=0.0, opacity_lr=0.0, scaling_lr=0.0,
