@@ -669,7 +669,9 @@ def measure_kernel_clocks(trainer, cams, bg, L, W, H):
                                                flags=trainer.FWD_FLAGS)
                 torch.cuda.synchronize()
                 L.e3dgs_debug_set_trace(buf.data_ptr() if (arm and which == "render_bwd_kernel") else None)
-                rasterizer.backward_multi(raw, dpix, out)
+                # (the timed iteration's form: the contrast renders' pixel gradients are rank 1)
+                rasterizer.backward_multi(raw, dpix, out, rank1={1: rasterizer.LUV_WEIGHTS, 2: rasterizer.LUV_WEIGHTS}
+                                          if (trainer.rank1 and len(cams) == 3) else None)
                 torch.cuda.synchronize()
                 L.e3dgs_debug_set_trace(None)
             t = buf.cpu().numpy().reshape(T, 6)
