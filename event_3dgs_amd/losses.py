@@ -57,20 +57,34 @@ class PairCounts:
 
     @staticmethod
     def _sig(gt_now, gt_next, gt_c):
-        return (gt_now._version, gt_next._version, float(gt_c), tuple(gt_now.shape))
+        # (versions catch in-place torch ops; the data pointers catch set_() / .data swaps.  A write through a raw pointer or
+        # DLPack that bumps neither is invisible here: such a caller passes pair_counts=None or starts a fresh PairCounts)
+        return (gt_now._version, gt_next._version, gt_now.data_ptr(), gt_next.data_ptr(), float(gt_c), tuple(gt_now.shape))
 
     def lookup(self, gt_now, gt_next, gt_c):
         """The pair's count tensor, or None when the pair is new (or was modified in place since)."""
-        e = self._entries.get((id(gt_now), id(gt_next)))
-        if e is not None and e[0]() is gt_now and e[1]() is gt_next and e[2] == self._sig(gt_now, gt_next, gt_c):
+        key = (id(gt_now), id(gt_next))
+        e = self._entries.get(key)
+        if e is None:
+            return None
+        if e[0]() is gt_now and e[1]() is gt_next and e[2] == self._sig(gt_now, gt_next, gt_c):
             return e[3]
+        if e[0]() is None or e[1]() is None:            # the frames are gone (their ids may be reused): drop the entry
+            del self._entries[key]
         return None
+
+    def purge(self):
+        """Drop the entries whose frames have been freed (called when the table fills up)."""
+        for key in [k for k, e in self._entries.items() if e[0]() is None or e[1]() is None]:
+            del self._entries[key]
 
     def remember(self, gt_now, gt_next, gt_c, count):
         """`count`: the device double an ENQUEUED e3dgs_event_loss_cached(nz_valid = 0) call fills."""
         import weakref
         key = (id(gt_now), id(gt_next))
         self._entries.pop(key, None)
+        if len(self._entries) >= self.capacity:
+            self.purge()
         while len(self._entries) >= self.capacity:
             self._entries.pop(next(iter(self._entries)))
         self._entries[key] = (weakref.ref(gt_now), weakref.ref(gt_next), self._sig(gt_now, gt_next, gt_c), count)

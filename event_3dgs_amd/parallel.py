@@ -9,13 +9,27 @@ import torch.distributed as dist
 # Test hook: issue the collectives also in a ONE-rank process group (they are short-circuited there otherwise), so that
 # the real RCCL entry points -- ncclAvg all-reduce, reduce_scatter_tensor, all_gather_into_tensor -- execute on a box with a
 # single GPU (tests/test_hip_rccl.py; EventTrainer(force_distributed=True) sets it for its own calls).
-FORCE_SINGLE_RANK_COLLECTIVES = False
+# A count of the live trainers that asked for it (released when such a trainer is collected): the hook does not outlive them.
+FORCE_SINGLE_RANK_COLLECTIVES = 0
+
+
+def force_single_rank_collectives(owner):
+    """Switch the hook on for as long as `owner` is alive."""
+    import weakref
+    global FORCE_SINGLE_RANK_COLLECTIVES
+    FORCE_SINGLE_RANK_COLLECTIVES += 1
+    weakref.finalize(owner, _release_forced)
+
+
+def _release_forced():
+    global FORCE_SINGLE_RANK_COLLECTIVES
+    FORCE_SINGLE_RANK_COLLECTIVES = max(0, FORCE_SINGLE_RANK_COLLECTIVES - 1)
 
 
 def _collective_needed(group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size(group) > 1 or FORCE_SINGLE_RANK_COLLECTIVES
+    return dist.get_world_size(group) > 1 or FORCE_SINGLE_RANK_COLLECTIVES > 0
 
 
 def allreduce_mean_(flat_grad, group=None):

@@ -107,7 +107,7 @@ class EventTrainer:
         # ONE-rank process group too, so that the schedules run over the real RCCL backend on a single GPU.
         self.multi = self.world > 1 or (bool(force_distributed) and dist.is_available() and dist.is_initialized())
         if self.multi and self.world == 1:
-            parallel.FORCE_SINGLE_RANK_COLLECTIVES = True
+            parallel.force_single_rank_collectives(self)       # (for this trainer's lifetime)
         # Exchange of the non-SH groups (11 floats per Gaussian + c) between the ranks:
         #   "allreduce"  in-place mean (RCCL picks ring / tree), every rank then runs Adam on all of them;
         #   "rs_ag"      the direct schedule of SURVEY 5.8: reduce-scatter of the gradients, Adam on the OWNED shard only
