@@ -74,7 +74,9 @@ const char* e3dgs_last_error(void);
                                         by e3dgs_sh_adam_from_colour_mean, which reads the coefficients anyway */
 /* ---- per-call OPTIONS (ABI 13).  The library keeps no mutable process-wide state that a call reads when
  * E3DGS_FLAG_OPTIONS is set: calls with different settings may run concurrently from any number of host threads and
- * streams.  Every call of one forward / backward (begin, finish, backward) must be given the same option bits.
+ * streams.  Every call of one forward / backward (begin, finish, backward) must be given the same option bits: the halves
+ * derive scratch offsets and launch shapes from them on the host, and nothing short of a device read-back could check a
+ * mismatch -- different bits in `finish` or `backward` than in `begin` are undefined behaviour (out-of-bounds emission).
  * Without E3DGS_FLAG_OPTIONS the process-wide defaults apply (environment at load time, the deprecated setters
  * e3dgs_set_tile_cull / e3dgs_set_small_scene_paths). */
 #define E3DGS_FLAG_OPTIONS 0x0800         /* the option bits below describe this call */
