@@ -167,6 +167,15 @@ struct RasterizeFunction : public torch::autograd::Function<RasterizeFunction> {
                      &bg = sv[6], &view = sv[7], &proj = sv[8], &campos = sv[9], &radii = sv[10], &geom = sv[11],
                      &binning = sv[12], &img = sv[13], &opac = sv[14];
         Tensor g = grad_outputs[0];
+        if (!g.defined()) {      // (the image did not reach the loss: a zero pixel gradient of the frame's size)
+            const int64_t P = means3D.size(0);
+            auto z = [&](std::initializer_list<int64_t> shape) { return torch::zeros(shape, means3D.options().dtype(torch::kFloat32)); };
+            const bool hc = cov.defined() && cov.numel() != 0, hcol = colors.defined() && colors.numel() != 0,
+                       hsh = sh.defined() && sh.numel() != 0;
+            return {z({P, 3}), z({P, 3}), hsh ? torch::zeros_like(sh) : Tensor(), hcol ? z({P, 3}) : Tensor(), z({P, 1}),
+                    hc ? Tensor() : z({P, 3}), hc ? Tensor() : z({P, 4}), hc ? z({P, 6}) : Tensor(), Tensor(), Tensor(),
+                    Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        }
         if (g.scalar_type() != torch::kFloat32) g = g.to(torch::kFloat32);
         auto d = rasterize_backward_impl(bg, means3D, radii, colors, scales, rotations,
                                          (float)ctx->saved_data["scale_modifier"].toDouble(), cov, view, proj,

@@ -191,6 +191,17 @@ def event_loss(image, image_now, image_next, c, gt_image_intensity, image_now_gt
                                        gt_blur_image, gt_c)
 
 
+def gray_loss(image, gt_image, lambda_dssim=0.2):
+    """The `--gray` loss block train.py:213-223 ((1 - lambda) l1_loss_gray + lambda (1 - ssim_gray), utils/loss_utils.py:40-48,
+    368-385) with the fused SSIM kernel behind autograd."""
+    return losses.gray_iteration_loss(image, gt_image, lambda_dssim)
+
+
+def rgb_loss(image, gt_image, lambda_dssim=0.2):
+    """The RGB loss block train.py:292-296 ((1 - lambda) l1_loss + lambda (1 - ssim), utils/loss_utils.py:270-271,388-396)."""
+    return losses.rgb_iteration_loss(image, gt_image, lambda_dssim)
+
+
 class FusedAdam(torch.optim.Optimizer):
     """Rung 3: torch.optim.Adam's interface and state layout over the fused Adam kernel (e3dgs_adam_step).
 
