@@ -24,6 +24,9 @@ int launch_tile_order(int ntiles, int tiles_per_view, int gx, uint2* ranges, con
 #ifndef E3_BWD_WAVES
 #define E3_BWD_WAVES 6
 #endif
+#ifndef E3_R1_TWO_READS
+#define E3_R1_TWO_READS 1     // rank-1 body: two 16-byte LDS broadcasts per entry instead of three (pmin staged beside colour . w)
+#endif
 #ifndef E3_BWD_STATS_WAVES
 #define E3_BWD_STATS_WAVES 5      // render_bwd_stats_kernel (second gradient chain: +16 VGPRs)
 #endif
@@ -163,7 +166,10 @@ __device__ __forceinline__ void render_bwd_body(
     for (int base = 0; base < n; base += WAVE) {
         const int cnt = min(WAVE, n - base);
         rc.w = __uint_as_float(re);                 // the record's spare word carries the emission index (where its gradient record goes)
-        if (RANK1) rb.z = FMA(rb.z, rw0, FMA(rb.w, rw1, rc.x * rw2));      // colour . w of the entry, in the red slot
+        if (RANK1) {
+            rb.z = FMA(rb.z, rw0, FMA(rb.w, rw1, rc.x * rw2));      // colour . w of the entry, in the red slot
+            if (E3_R1_TWO_READS) rb.w = rc.y;                        // ... and pmin beside it: the entry loop reads a, b only
+        }
         sRec[wave][lane].a = ra; sRec[wave][lane].b = rb; sRec[wave][lane].c = rc;
         const uint32_t mvec = lane < cnt ? rm : 0u;
         wave_sync();
@@ -190,10 +196,18 @@ __device__ __forceinline__ void render_bwd_body(
                 uint32_t rec_addr;
                 asm("v_mad_u32_u24 %0, %1, 48, %2" : "=v"(rec_addr) : "s"(j), "v"(recs_base_v));
                 LdsF4* vp = (LdsF4*)(uintptr_t)rec_addr;
-                const f4_t va = vp[0], vb = vp[1], vc = vp[2];
+                const f4_t va = vp[0], vb = vp[1];
                 const float4 a = make_float4(va.x, va.y, va.z, va.w);
                 const float4 b = make_float4(vb.x, vb.y, vb.z, vb.w);
-                const float4 c = make_float4(vc.x, vc.y, vc.z, vc.w);
+                float4 c;
+                if (RANK1 && E3_R1_TWO_READS) {
+                    // the rank-1 body needs neither green nor blue: pmin rides in b.w (staging), and the band bound is the
+                    // sum preprocess_kernel stored -- pmin + 4e-4f, the same single fp32 addition: the same bits
+                    c = make_float4(0.0f, vb.w, vb.w + 4e-4f, 0.0f);
+                } else {
+                    const f4_t vc = vp[2];
+                    c = make_float4(vc.x, vc.y, vc.z, vc.w);
+                }
                 const uint32_t contributor = (uint32_t)(nrem - j);         // 1-based position in the list
                 const float dx = a.x - pfx;
                 // power in the FORWARD's operation order (q = fma(C dy, dy, (A dx) dx); power = fma(-0.5, q, -((B dx) dy))):
