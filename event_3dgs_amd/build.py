@@ -42,5 +42,21 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def status():
+    """What build() would do here, without doing it: (objects that would be recompiled, whether the library would be
+    relinked, modification time of the library).  smoke() prints it on the GPU box, so that the driver's records say whether
+    the box ran the binaries that travelled with the tree or rebuilt them."""
+    sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "e3dgs_hip.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    stale = []
+    for src in sources:
+        sp, op = os.path.join(CSRC, src), os.path.join(OBJ, src.replace(".hip", ".o"))
+        if not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_time):
+            stale.append(src)
+    have = os.path.exists(OUT)
+    return stale, (not have) or bool(stale), (os.path.getmtime(OUT) if have else None)
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
