@@ -595,6 +595,9 @@ __device__ __forceinline__ void build_cov3(const float sact[3], float scale_modi
 // order (fixed order -> deterministic).  Output: 3 float4 per splat at its INDEX q,
 // (mx my A B | C o c0 c1 | c2 - - -), which the per-Gaussian kernels then read coalesced.
 constexpr int RR_CHUNK = 128;
+#ifndef E3_RR_PACKED_STORES
+#define E3_RR_PACKED_STORES 1
+#endif
 __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint32_t* __restrict__ order,
                                                          const uint2* __restrict__ run_sorted,
                                                          const float* __restrict__ part, float4* __restrict__ gsum,
@@ -652,12 +655,34 @@ __global__ __launch_bounds__(256) void run_reduce_kernel(uint32_t Q, const uint3
         wave_sync();
     }
     // (zeros for splats whose every tile was culled: their radius can still be > 0)
+#if E3_RR_PACKED_STORES
+    // The sums go to the splat's INDEX q: 48 bytes at a random place.  As three 16-byte stores per lane those are three
+    // partial-sector write transactions per splat, and it is their NUMBER that costs (a 4-byte scatter of the same count
+    // costs the same, EXPERIMENTS.md round 5).  Through the wave's LDS slice the three float4 of a splat are handed to three
+    // CONSECUTIVE lanes: one store instruction then writes 21 whole 48-byte blocks, each as one transaction.
+    {
+        float4* s4 = reinterpret_cast<float4*>(sb);                 // 64 x 3 float4 (3 KB of the wave's 4.5 KB slice)
+        uint32_t* sq = reinterpret_cast<uint32_t*>(sb + 64 * 12);   // the splats' indices (+ 256 B)
+        s4[3 * lane] = make_float4(a[0], a[1], a[2], a[3]);
+        s4[3 * lane + 1] = make_float4(a[4], a[5], a[6], a[7]);
+        s4[3 * lane + 2] = make_float4(a[8], 0.0f, 0.0f, 0.0f);
+        sq[lane] = j < Q ? order[j] : 0xFFFFFFFFu;
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint32_t idx = lane + 64u * t, sp = idx / 3u, part = idx - 3u * sp;
+            const uint32_t q = sq[sp];
+            if (q != 0xFFFFFFFFu) gsum[3 * (size_t)q + part] = s4[idx];
+        }
+    }
+#else
     if (j < Q) {
         const size_t q = order[j];
         gsum[3 * q] = make_float4(a[0], a[1], a[2], a[3]);
         gsum[3 * q + 1] = make_float4(a[4], a[5], a[6], a[7]);
         gsum[3 * q + 2] = make_float4(a[8], 0.0f, 0.0f, 0.0f);
     }
+#endif
 }
 
 // Few splats with long runs (point-cloud initialisation: thousands of Gaussians covering hundreds of tiles each): one
