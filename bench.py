@@ -61,6 +61,12 @@ def main():
     ap.add_argument("--no-substep", action="store_true",
                     help="skip the contrast-only two-render measurement after the timed region (profiling runs: keeps the "
                          "kernel statistics to the 3-view launches of the iteration)")
+    ap.add_argument("--trained-steps", type=int, default=1000,
+                    help="training iterations of the trained_random_camera leg before its timed window (0 = skip the leg)")
+    ap.add_argument("--trained-timed", type=int, default=200, help="timed iterations of the trained_random_camera leg")
+    ap.add_argument("--only-trained", action="store_true",
+                    help="run ONLY the trained_random_camera leg and print its record (profiling runs: the kernel statistics "
+                         "of the process then describe that leg; see profiles/collect.py --trained)")
     ap.add_argument("--cpu-rows", type=int, default=3, help="tile rows composited by the C-oracle sample")
     ap.add_argument("--torch-rows", type=int, default=1, help="tile rows composited by the PyTorch CPU baseline sample")
     args = ap.parse_args()
@@ -115,6 +121,12 @@ def main():
            for c in (cam_int, cam_now, cam_next)]
     gt_blur = (0.5 * (gts[0] + gts[2])).contiguous() if deblur else None
     del gt_tr
+    if args.only_trained:
+        rec = measure_trained_random_camera(params, gt_params, dev, W, H, bg, L, deblur, args.trained_steps,
+                                            args.trained_timed, K, trace_dir=os.environ.get("E3DGS_TRAINED_TRACE_DIR"))
+        print(json.dumps({"trained_random_camera": rec, "config": {"workload": cfg_name, "gaussians": N, "width": W,
+                                                                   "height": H}}))
+        return
     trainer = EventTrainer(params, dev)
 
     def one_step():
@@ -600,6 +612,16 @@ def main():
             roofline["frac_on_reference_instances"] = round(b_ref / 1e9 / (stages[dominant]["avg_ms"] / 1e3) / HBM_PEAK_GBS, 5)
             roofline["alg_bytes_on_reference_instances"] = int(b_ref)
 
+    # ---- the state a trainer lives in (train.py:116-131 draws a random camera every iteration; the headline renders one
+    # triplet of a scene that has never been trained): after the timed region, never part of `value`
+    trained = None
+    if world == 1 and not args.no_substep and args.trained_steps > 0:
+        del trainer
+        torch.cuda.empty_cache()
+        trained = measure_trained_random_camera(params, gt_params, dev, W, H, bg, L, deblur, args.trained_steps,
+                                                args.trained_timed, K)
+        trainer = EventTrainer(params, dev)        # (the fields below read configuration flags off a trainer)
+
     # gradient exchange per iteration and rank: mean of the non-SH groups (+ of the SH gradient unless it is rebuilt
     # from the all-gathered per-view colour gradients, EventTrainer.factorize_sh)
     if world == 1:
@@ -627,6 +649,7 @@ def main():
             "roofline": roofline, "stages": stages, "contrast_only_substep": contrast,
             "sustained": (reading or {}).get("sustained"), "static_workload": (reading or {}).get("static_workload"),
             "reference_binning_iteration": (reading or {}).get("reference_binning_iteration"),
+            "trained_random_camera": trained,
             "dropin_autograd_step": dropin, "shared_pose_iteration": shared_pose, "fast_exp_iteration": fast_exp,
             "cfg5_per_rank_workload": cfg5, "cpu_baseline": cpu_baseline,
             "device_allocs_in_timed_region": device_allocs,
@@ -639,6 +662,182 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_trained_random_camera(params, gt_params, dev, W, H, bg, L, deblur, n_train, n_timed, K=64, trace_dir=None):
+    """The iteration in the state a trainer actually lives in: K orbit cameras (each with its event pair and its 8-bit
+    ground-truth frames, all resident in HBM), a fresh random camera per iteration with the reference's draw
+    (train.py:116-131 = fit.sample_index), `n_train` training iterations, THEN `n_timed` timed ones (still training, still
+    drawing).  Next to it, so that the gap to the headline can be read: (a) the same random draw on the UNTRAINED scene
+    with every learning rate 0 (what random cameras alone cost: camera / pair-count caches, capacity keys, per-view instance
+    counts that differ from the headline's triplet), (b) the trained end state, frozen, on the headline's fixed triplet (what
+    training alone costs per instance).  Stage tables with all slots bracketed are taken after each timed window."""
+    import ctypes as C
+    import random
+    import torch
+    from event_3dgs_amd import fit
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+
+    cams = [tuple(orbit_camera(k, K, W, H, device=dev, daz=d) for d in (0.0, 0.005, 0.015)) for k in range(K)]
+    gt_tr = EventTrainer(gt_params, dev)
+    quant = lambda c: (torch.round(gt_tr.render_raw(c, bg)["color"].clamp(0, 1) * 255.0) / 255.0).contiguous()
+    gts = [tuple(quant(c) for c in trip) for trip in cams]
+    blur = [(0.5 * (g[0] + g[2])).contiguous() for g in gts] if deblur else None
+    del gt_tr
+    zero = dict(position_lr_init=0.0, position_lr_final=0.0, feature_lr=0.0, opacity_lr=0.0, scaling_lr=0.0,
+                rotation_lr=0.0, c_lr=0.0)
+
+    def read_slots():
+        out = {}
+        for slot in range(8):
+            ms, n = C.c_double(0), C.c_int(0)
+            L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
+            if n.value:
+                out[L.e3dgs_profile_slot_name(slot).decode()] = round(ms.value / n.value, 4)
+        return out
+
+    marks = []
+    mark_pos = torch.zeros(64, 3, device=dev)
+    mark_mat = torch.eye(4, device=dev).contiguous()
+
+    def mark(tag):
+        """A launch of mark_visible_kernel -- which no iteration contains -- in stream order: profiles/collect_trained.py cuts
+        the kernel trace of this process at these launches (the k-th one is marks[k])."""
+        from event_3dgs_amd.rasterizer import _mark_visible
+        _mark_visible(mark_pos, mark_mat, mark_mat)
+        marks.append(tag)
+
+    def window(tr, draw, n, n_stage=40, tag=""):
+        """n timed iterations (wall clock, nothing bracketed), then n_stage with every stage bracketed."""
+        inst = []
+
+        def it():
+            k = draw()
+            tr.step_nocopy(*cams[k], *gts[k], bg, gt_blur=blur[k] if blur else None)
+            inst.append(tr._instances_per_view * 3)      # (the count the host has just read for this iteration's pass)
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize()
+        del inst[:]
+        r0 = tr.count_retries
+        mark(tag + ":timed:begin")
+        t0 = time.perf_counter()
+        for _ in range(n):
+            it()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        mark(tag + ":timed:end")
+        retries = tr.count_retries - r0
+        I_mean = sum(inst) / max(len(inst), 1)
+        I_min, I_max = (min(inst), max(inst)) if inst else (0, 0)
+        L.e3dgs_profile_enable(0xFF)
+        del inst[:]
+        for _ in range(n_stage):
+            it()
+        torch.cuda.synchronize()
+        st = read_slots()
+        L.e3dgs_profile_enable(0)
+        I_stage = sum(inst) / max(len(inst), 1)
+        per = {k: round(1e9 * st[k] / I_stage, 1) for k in ("render_fwd", "render_bwd") if k in st and I_stage}   # ps / instance
+        return {"ms_per_step": round(ms, 3), "per_s": round(1e3 / ms, 1), "steps": n, "count_retries": retries,
+                "tile_instances_3views_mean": int(I_mean), "tile_instances_3views_min": int(I_min),
+                "tile_instances_3views_max": int(I_max), "stage_avg_ms": st,
+                "tile_instances_3views_mean_in_the_stage_window": int(I_stage), "compositing_ps_per_instance": per}
+
+    rng = random.Random(0)
+    draw = lambda: fit.sample_index(K, "event", rng.randint)
+    fixed = lambda: 0
+    rec = {"cameras": K, "draw": "train.py:116-131 (fit.sample_index, event mode), python random.Random(0)",
+           "training_steps_before_the_timed_window": n_train}
+    # (a) random cameras alone: untrained scene, frozen
+    tz = EventTrainer(params, dev, **zero)
+    rec["untrained_frozen_random_camera"] = window(tz, draw, max(50, n_timed // 2), tag="untrained_frozen_random_camera")
+    rec["untrained_frozen_fixed_triplet"] = window(tz, fixed, max(50, n_timed // 2), tag="untrained_frozen_fixed_triplet")
+    walk_untrained = _walk_statistics(tz, cams[0], bg, W, H)
+    del tz
+    # (b) the leg itself
+    tr = EventTrainer(params, dev)
+    t0 = time.perf_counter()
+    for _ in range(n_train):
+        k = draw()
+        tr.step_nocopy(*cams[k], *gts[k], bg, gt_blur=blur[k] if blur else None)
+    torch.cuda.synchronize()
+    rec["training_phase"] = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / max(n_train, 1), 3),
+                             "count_retries": tr.count_retries, "shared_pose_iterations": tr.shared_pose_iterations}
+    rec["trained_random_camera"] = window(tr, draw, n_timed, tag="trained_random_camera")
+    rec["pair_count_cache_entries"] = len(tr._pair_counts._entries) if getattr(tr, "_pair_counts", None) is not None else None
+    # (c) the end state, frozen, on the headline's triplet and on random cameras
+    frozen = _freeze(tr)
+    rec["trained_frozen_fixed_triplet"] = window(frozen, fixed, max(50, n_timed // 2), tag="trained_frozen_fixed_triplet")
+    rec["trained_frozen_random_camera"] = window(frozen, draw, max(50, n_timed // 2), tag="trained_frozen_random_camera")
+    rec["walk_statistics"] = {"untrained": walk_untrained, "trained": _walk_statistics(frozen, cams[0], bg, W, H)}
+    if trace_dir:
+        os.makedirs(trace_dir, exist_ok=True)
+        json.dump(rec["walk_statistics"], open(os.path.join(trace_dir, "walk_statistics.json"), "w"), indent=1)
+    rec["trace_markers"] = marks
+    a, b = rec["trained_random_camera"], rec["untrained_frozen_fixed_triplet"]
+    rec["vs_untrained_fixed_triplet"] = {
+        "ms_per_step_ratio": round(a["ms_per_step"] / b["ms_per_step"], 3),
+        "instances_ratio": round(a["tile_instances_3views_mean"] / max(b["tile_instances_3views_mean"], 1), 3),
+        "what": "trained + random camera against the headline's state (untrained scene, one triplet), both by this function"}
+    return rec
+
+
+def _freeze(tr):
+    """The trainer `tr` with every learning rate 0 from here on (Adam keeps running, nothing moves)."""
+    for k in list(tr.lrs):
+        tr.lrs[k] = 0.0
+    tr.c_lr = 0.0
+    tr.xyz_lr = lambda step: 0.0
+    return tr
+
+
+def _walk_statistics(tr, trip, bg, W, H):
+    """Walk statistics of the compositing kernels on the state `tr` holds, per view of the triplet: tile list lengths,
+    entries the walk reaches (largest n_contrib of the tile's pixels), `touched` fraction of the slots, strips evaluated
+    per entry with a non-zero strip mask."""
+    import numpy as np
+    import torch
+    from event_3dgs_amd import rasterizer
+    res = {}
+    for name, cam in zip(("intensity", "now", "next"), trip):
+        raw = tr.render_raw(cam, bg)
+        st = rasterizer.state_views(raw, tr.N, W, H)
+        rg = st["ranges"].long()
+        ln = (rg[:, 1] - rg[:, 0]).cpu().numpy().astype(np.float64)
+        gx = (W + 15) // 16
+        gy = (H + 15) // 16
+        nc = st["n_contrib"].view(H, W).long()
+        pad = torch.zeros(gy * 16, gx * 16, dtype=torch.long, device=nc.device)
+        pad[:H, :W] = nc
+        walked = pad.view(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256).max(dim=1).values.cpu().numpy().astype(np.float64)
+        rec = {"instances": int(ln.sum()), "walked_entries": int(walked.sum()),
+               "walked_fraction": round(float(walked.sum() / max(ln.sum(), 1)), 4),
+               "list_length_percentiles_50_90_99_max": [float(x) for x in np.percentile(ln, [50, 90, 99, 100])],
+               "walked_percentiles_50_90_99_max": [float(x) for x in np.percentile(walked, [50, 90, 99, 100])]}
+        if "touched" in st:
+            rec["touched_fraction_of_slots"] = round(float(st["touched"].float().mean()), 4)
+        if "strip_mask" in st:
+            # (the forward writes the mask bytes of the entries it walked; the rest of a list holds whatever the scratch held)
+            sm = st["strip_mask"].to(torch.int32)
+            pos = torch.arange(sm.numel(), device=sm.device)
+            tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=sm.device), (rg[:, 1] - rg[:, 0]))
+            wt = torch.from_numpy(walked).to(sm.device).long()
+            inside = torch.zeros_like(sm, dtype=torch.bool)
+            if tile_of.numel() == sm.numel():
+                # lists are stored tile-major in range order only when ranges are ascending: use each entry's own range start
+                inside = pos < (rg[tile_of, 0] + wt[tile_of])
+                order_ok = bool((pos >= rg[tile_of, 0]).all())
+                if not order_ok:
+                    inside = torch.zeros_like(inside)
+            sm = torch.where(inside, sm, torch.zeros_like(sm))
+            bits = ((sm & 1) + ((sm >> 1) & 1) + ((sm >> 2) & 1) + ((sm >> 3) & 1)).float()
+            nz = sm != 0
+            rec["entries_with_a_strip"] = int(nz.sum())
+            rec["strips_per_entry_with_a_strip"] = round(float(bits[nz].mean()), 3) if bool(nz.any()) else None
+        res[name] = rec
+    return res
 
 
 def measure_kernel_clocks(trainer, cams, bg, L, W, H):

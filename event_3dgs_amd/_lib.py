@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe3dgs_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 NOTIFY_FN = C.CFUNCTYPE(None, C.c_void_p)
@@ -98,6 +98,8 @@ def lib():
     L.e3dgs_get_small_scene_paths.restype = C.c_int
     L.e3dgs_state_offset_emit_gid.restype = C.c_size_t
     L.e3dgs_state_offset_emit_gid.argtypes = [C.c_int]
+    L.e3dgs_state_offsets_binning.restype = None
+    L.e3dgs_state_offsets_binning.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
     L.e3dgs_state_offsets.restype = None
     L.e3dgs_state_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)]
     L.e3dgs_state_offsets_multi.restype = None
@@ -149,6 +151,10 @@ def lib():
     L.e3dgs_adam_step.argtypes = [C.c_size_t] + [_fp] * 4 + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_int, C.c_int, _vp]
     L.e3dgs_sort_scratch_bytes.restype = C.c_size_t
     L.e3dgs_sort_scratch_bytes.argtypes = [C.c_size_t]
+    L.e3dgs_depth_sort_scratch_bytes.restype = C.c_size_t
+    L.e3dgs_depth_sort_scratch_bytes.argtypes = [C.c_size_t]
+    L.e3dgs_sort_depth_keys.restype = C.c_int
+    L.e3dgs_sort_depth_keys.argtypes = [C.c_size_t, _vp, _vp, _vp, _vp, _cp, _vp, _vp]
     L.e3dgs_sort_pairs.restype = C.c_int
     L.e3dgs_sort_pairs.argtypes = [C.c_size_t, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _cp, _vp, _vp, C.c_uint32,
                                    C.POINTER(C.c_int), _vp]
@@ -231,4 +237,5 @@ EXPORTED_SYMBOLS = [
     "e3dgs_event_loss", "e3dgs_event_loss_cached", "e3dgs_ssim_scratch_bytes", "e3dgs_ssim", "e3dgs_image_loss_scratch_bytes", "e3dgs_image_loss", "e3dgs_densify_stats_update", "e3dgs_densify_scratch_bytes", "e3dgs_densify_plan", "e3dgs_densify_split_rows", "e3dgs_densify_apply", "e3dgs_adam_step_segments", "e3dgs_adam_step_groups", "e3dgs_adam_step_groups_gap", "e3dgs_adam_step", "e3dgs_profile_enable", "e3dgs_profile_select", "e3dgs_profile_query", "e3dgs_profile_slot_name",
     "e3dgs_sort_scratch_bytes", "e3dgs_sort_pairs", "e3dgs_rasterize_forward_multi_capacity",
     "e3dgs_rasterize_backward_multi_rank1", "e3dgs_event_loss_rank1", "e3dgs_image_loss_rank1",
+    "e3dgs_state_offsets_binning", "e3dgs_depth_sort_scratch_bytes", "e3dgs_sort_depth_keys",
 ]

@@ -1447,6 +1447,7 @@ int e3_backward_impl(const ViewBatch& views, int P, int D, int M, int num_render
     const size_t Q = (size_t)P * nv;
     char* gp = const_cast<char*>(geom_buffer);
     char* bp = const_cast<char*>(binning_buffer);
+    if (const int rc = e3_geom_opts_check(gp, Q, e3_call_opts(flags), "backward")) return rc;
     char* ip = const_cast<char*>(image_buffer);
     GeomState geom = GeomState::from(gp, Q);
     BinningState bin = BinningState::from(bp, (size_t)num_rendered);

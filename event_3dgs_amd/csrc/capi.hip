@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <chrono>
 #include <mutex>
+#include <unordered_map>
 
 thread_local char g_err[512] = "";
 
@@ -33,6 +35,38 @@ CallOpts e3_call_opts(int flags) {
     }
     o.fast_exp = (flags & E3_FLAG_FAST_EXP) ? 1 : 0;
     return o;
+}
+
+// ---- the resolved options of the last `begin` on a geometry scratch (include/e3dgs_hip.h, "per-call OPTIONS").  Host
+// memory only: a device read-back would cost a stream synchronisation per half.  Keyed by the scratch address the
+// caller's allocator returned; a caller that MOVES the scratch between the halves is not checked (no entry: accepted).
+// The table is validation state, not behaviour: no call reads its settings from it.
+namespace {
+struct GeomOpts { size_t Q; int cull, small_paths, fast_exp; };
+std::mutex g_opts_mu;
+std::unordered_map<const void*, GeomOpts> g_opts;
+constexpr size_t OPTS_MAX = 1 << 14;          // addresses are recycled by every allocator; beyond this: start over
+}  // namespace
+void e3_geom_opts_remember(const void* geom, size_t Q, const CallOpts& o) {
+    if (!geom) return;
+    std::lock_guard<std::mutex> lock(g_opts_mu);
+    if (g_opts.size() >= OPTS_MAX && !g_opts.count(geom)) g_opts.clear();
+    g_opts[geom] = GeomOpts{Q, o.cull, o.small_paths, o.fast_exp};
+}
+int e3_geom_opts_check(const void* geom, size_t Q, const CallOpts& o, const char* who) {
+    GeomOpts g;
+    {
+        std::lock_guard<std::mutex> lock(g_opts_mu);
+        auto it = g_opts.find(geom);
+        if (it == g_opts.end()) return 0;
+        g = it->second;
+    }
+    if (g.Q == Q && g.cull == o.cull && g.small_paths == o.small_paths && g.fast_exp == o.fast_exp) return 0;
+    snprintf(g_err, sizeof g_err,
+             "%s: option bits / sizes differ from the ones `begin` resolved for this geometry scratch (begin: P*nviews %zu, "
+             "cull %d, small_paths %d, fast_exp %d; this call: %zu, %d, %d, %d) -- nothing was launched (hipError %d)",
+             who, g.Q, g.cull, g.small_paths, g.fast_exp, Q, o.cull, o.small_paths, o.fast_exp, (int)hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
 }
 
 // ---- event profiler.  PROCESS-WIDE state behind a mutex: torch runs the autograd nodes of a backward pass on its own
@@ -101,7 +135,7 @@ const int* e3_densify_split_rows(int, char*);
 
 extern "C" {
 
-int e3dgs_abi_version(void) { return 16; }
+int e3dgs_abi_version(void) { return 17; }
 const char* e3dgs_last_error(void) { return g_err; }
 
 static ViewBatch one_view(const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
@@ -190,15 +224,23 @@ static int forward_sync(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_
     // runtime wake-up behind a stream synchronisation, during which the GPU has nothing queued (measured on the trainer's
     // path: 68 -> 26 us of GPU idle per forward; the reference's iteration calls the operator three times).
     // E3DGS_COUNT_POLL=0, debug calls and a failed pinned allocation take the stream synchronisation.
-    static thread_local volatile int* mapped = nullptr;
-    static thread_local bool mapped_tried = false;
+    // Semantics that differ from a stream synchronisation (documented in include/e3dgs_hip.h): the host returns as soon
+    // as the count is there, NOT when the stream has drained, so an asynchronous error of earlier work on the stream does
+    // not surface here (it surfaces at the caller's next synchronising call, as with any enqueue-only API).
+    struct MappedWord {                 // one 64-byte pinned word per host thread, released when the thread exits
+        volatile int* p = nullptr;
+        bool tried = false;
+        ~MappedWord() { if (p) (void)hipHostFree((void*)p); }
+    };
+    static thread_local MappedWord mw;
     static const bool poll_ok = !(getenv("E3DGS_COUNT_POLL") && getenv("E3DGS_COUNT_POLL")[0] == '0');
-    if (!mapped_tried && poll_ok) {
-        mapped_tried = true;
+    if (!mw.tried && poll_ok) {
+        mw.tried = true;
         void* hp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) mapped = (volatile int*)hp;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) mw.p = (volatile int*)hp;
         else (void)hipGetLastError();
     }
+    volatile int* const mapped = mw.p;
     const bool poll = mapped != nullptr && poll_ok && !debug && P > 0;
     int count = 0;
     if (poll) *mapped = -1;
@@ -208,15 +250,17 @@ static int forward_sync(e3dgs_alloc_fn geom_alloc, void* geom_user, e3dgs_alloc_
                                    (hipStream_t)stream);
     if (rc) return rc;
     if (poll) {
-        unsigned long long spins = 0;
+        // poll with a cpu-relax between reads; every 4096 polls look at the clock: after 2 s without a count the wait
+        // becomes a stream synchronisation (a hung or dead stream then reports its own error instead of spinning forever)
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
         while (*mapped == -1) {
-            if ((++spins & 0xFFFFFull) == 0ull) {
-                // (every ~1 M polls: if the stream has drained and the word is still armed, a kernel died on the way)
-                hipError_t q = hipStreamQuery((hipStream_t)stream);
-                if (q != hipErrorNotReady) {
-                    if (*mapped != -1) break;
-                    return e3_fail(q == hipSuccess ? hipErrorUnknown : q, "the instance count never arrived");
-                }
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFu) == 0u &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                hipError_t q = hipStreamSynchronize((hipStream_t)stream);
+                if (q != hipSuccess) return e3_fail(q, "hipStreamSynchronize (instance count, after 2 s of polling)");
+                if (*mapped == -1) return e3_fail(hipErrorUnknown, "the instance count never arrived");
             }
         }
         count = *mapped;
@@ -574,6 +618,11 @@ size_t e3dgs_state_offset_emit_gid(int num_rendered) {
     BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
     return (size_t)b.emit_gid;
 }
+void e3dgs_state_offsets_binning(int num_rendered, size_t* out2) {
+    char* p = nullptr;
+    BinningState b = BinningState::from(p, (size_t)(num_rendered > 0 ? num_rendered : 0));
+    out2[0] = (size_t)b.strip_mask; out2[1] = (size_t)b.touched;
+}
 void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t* out9) {
     char* p = nullptr;
     GeomState g = GeomState::from(p, (size_t)(P > 0 ? P : 0));
@@ -763,6 +812,21 @@ int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys
     if (rc) return rc;
     *result_index_host = (vout == vals1) ? 1 : 0;
     return 0;
+}
+
+size_t e3dgs_depth_sort_scratch_bytes(size_t n) { return depth_sort_scratch_words(n ? n : 1) * sizeof(uint32_t) + 256; }
+int e3dgs_sort_depth_keys(size_t n, uint32_t* keys0, uint32_t* keys1, uint32_t* order, uint32_t* order_alt, char* scratch,
+                          uint32_t* kept_count_dev, void* stream) {
+    g_err[0] = 0;
+    if (n >= 0xFFFFFFFFull) return e3_fail(hipErrorInvalidValue, "n must be below 2^32 - 1");
+    if (!kept_count_dev) return e3_fail(hipErrorInvalidValue, "kept_count_dev is required");
+    if (n > 0 && (!keys0 || !keys1 || !order || !order_alt || !scratch)) return e3_fail(hipErrorInvalidValue, "null pointer");
+    if ((reinterpret_cast<uintptr_t>(scratch) & 7) != 0) return e3_fail(hipErrorInvalidValue, "scratch must be 8-byte aligned");
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(kept_count_dev, 0, sizeof(uint32_t), (hipStream_t)stream);
+        return e == hipSuccess ? 0 : e3_fail(e, "hipMemsetAsync(kept_count_dev)");
+    }
+    return launch_depth_sort_wide(keys0, keys1, order, order_alt, n, (uint32_t*)scratch, (hipStream_t)stream, kept_count_dev);
 }
 
 extern unsigned long long* g_trace;

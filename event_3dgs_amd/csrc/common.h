@@ -198,6 +198,14 @@ static inline size_t sort_scratch_words(size_t n) {
 }
 // words (uint32) of the descriptors of a chained scan over n elements (64-bit descriptors + ticket)
 static inline size_t scan_desc_words(size_t n) { return 2 * (scan_blocks(n) + 1); }
+// ... and for the depth sort's three 11-bit passes (launch_depth_sort_wide: 2048-bin histograms per workgroup); the
+// geometry scratch holds whichever of the two is larger
+static inline size_t depth_sort_scratch_words(size_t n) {
+    const size_t hw = sort_blocks(n) * 2048;
+    const size_t wide = hw + 2 + 2 * (scan_blocks(hw) + 1) + 64;
+    const size_t narrow = sort_scratch_words(n);
+    return wide > narrow ? wide : narrow;
+}
 
 // ---------------------------------------------------------------- scratch layouts
 // Splats per binning wave = 1 << shift: 64 when there are plenty of splats, fewer when the launch would otherwise
@@ -251,7 +259,7 @@ struct GeomState {
         g.ord1 = carve<uint32_t>(p, n);
         g.tiles = carve<uint32_t>(p, n);
         g.offsets = carve<uint32_t>(p, n + 64);      // [0] = 0, then one entry per binning wave (<= n of them)
-        g.scratch = carve<uint32_t>(p, sort_scratch_words(n) + scan_desc_words(n) + 64);
+        g.scratch = carve<uint32_t>(p, depth_sort_scratch_words(n) + scan_desc_words(n) + 64);
         g.total = carve<uint32_t>(p, 64);
         g.nvis = g.total + 16;
         g.binrec = carve<float4>(p, 2 * n);
@@ -409,7 +417,13 @@ struct Rank1Views {
 // double the caller wrote (0.9, 0.999: short decimals).  (float)0.999 = 0.99900001287..., and 1 - that is 1.3e-5 away
 // from the fp32 value of 1 - 0.999 torch multiplies g^2 with.  The host therefore recovers the decimal (7 digits: exact
 // for anything a caller writes as a literal) and derives every constant from it, as torch does.
-static inline double e3_beta_double(float b) { return __builtin_nearbyint((double)b * 1e7) / 1e7; }
+// The decimal is only taken when it IS what the caller wrote, i.e. when it converts back to the same fp32 value, and when
+// it lies in [0, 1): a beta that is not a 7-digit decimal (a schedule, 1 - 1/k) or within 5e-8 of 1 keeps its own value
+// (rounding 0.99999997f to 1.0 would make both bias corrections 0 and the step inf / NaN).
+static inline double e3_beta_double(float b) {
+    const double d = __builtin_nearbyint((double)b * 1e7) / 1e7;
+    return ((float)d == b && d >= 0.0 && d < 1.0) ? d : (double)b;
+}
 static inline float e3_one_minus_beta(float b) { return (float)(1.0 - e3_beta_double(b)); }
 
 // the options of one call, resolved from its flags word (capi.hip holds the process-wide defaults)
@@ -419,6 +433,12 @@ struct CallOpts {
     int fast_exp;      // hardware exp2 in compositing (tolerance mode)
 };
 CallOpts e3_call_opts(int flags);
+// What `begin` resolved for a geometry scratch, kept on the HOST per scratch address (capi.hip): `finish` and the backward
+// derive scratch offsets and launch shapes from the option bits and the splat count, so a caller that hands them other
+// bits than it gave `begin` would make the kernels write out of bounds.  remember() is called by begin, check() by every
+// later half: non-zero (hipErrorInvalidValue + message, nothing launched) on a mismatch.
+void e3_geom_opts_remember(const void* geom, size_t Q, const CallOpts& o);
+int e3_geom_opts_check(const void* geom, size_t Q, const CallOpts& o, const char* who);
 
 // host drivers (forward.hip / backward.hip), called by the C ABI wrappers in capi.hip
 typedef char* (*e3_alloc_fn)(void*, size_t);
@@ -478,6 +498,9 @@ int launch_radix_sort_pairs(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* 
                             bool identity_payload = false, uint32_t* drop_count_dev = nullptr,
                             const uint32_t* n_dev = nullptr, uint2* ranges_out = nullptr, uint32_t nranges = 0,
                             uint32_t* lpt_cnt = nullptr, uint32_t* lpt_list = nullptr);
+// the depth sort as three 11-bit passes (scan_sort.hip): identity payload, all-ones keys dropped, order in v0
+int launch_depth_sort_wide(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, uint32_t* scratch,
+                           hipStream_t s, uint32_t* kept_dev);
 int launch_radix_sort_pairs_u16(uint16_t* k0, uint16_t* k1, uint32_t* v0, uint32_t* v1, size_t n, int nbits,
                                 uint32_t* scratch, uint16_t** keys_out, uint32_t** vals_out, hipStream_t s,
                                 bool identity_payload = false, const uint32_t* n_dev = nullptr,

@@ -1282,6 +1282,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     char* gp = geom_alloc(geom_user, GeomState::required(Q));
     char* ip = img_alloc(img_user, ImageState::required(npix * nv, (size_t)ntiles * nv));
     if (!gp || !ip) return e3_fail(hipErrorOutOfMemory, "scratch allocation callback returned NULL");
+    e3_geom_opts_remember(gp, Q, e3_call_opts(flags));      // (before from(): it advances the pointer)
     GeomState geom = GeomState::from(gp, Q);
     ImageState img = ImageState::from(ip, npix * nv, (size_t)ntiles * nv);
     if (P <= 0) HIP_OK(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * nv * sizeof(uint2), s));
@@ -1289,7 +1290,7 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
     if (P > 0) {
         const unsigned pb = (unsigned)(((size_t)P + 255) / 256);      // one thread per Gaussian (its views are a loop)
         // descriptors of the scan behind the count pass: the tail of the scratch, which the depth sort does not use
-        uint32_t* bin_scan_desc = geom.scratch + sort_scratch_words(Q);
+        uint32_t* bin_scan_desc = geom.scratch + depth_sort_scratch_words(Q);
         {
         ProfScope ps(PS_PREPROCESS, s);
         // (P, M, 3) coefficient rows that start on 16-byte boundaries are loaded as float4 (the planar layout is coalesced
@@ -1311,9 +1312,20 @@ int e3_forward_begin_impl(e3_alloc_fn geom_alloc, void* geom_user, e3_alloc_fn i
         {
         ProfScope ps(PS_SORT_DEPTH, s);
         // culled splats carry the all-ones key: the first pass drops them, geom.nvis receives the kept count
+        // E3DGS_DEPTH_SORT_WIDE=1: three passes of 11 + 11 + 10 bits (launch_depth_sort_wide) instead of four of 8.  Built and
+        // measured in round 6, NOT the default: 0.188 ms against 0.115 ms for the benchmark's 3 M splats -- the 2048-bin
+        // passes scatter two keys per (workgroup, digit) instead of sixteen (profiles/EXPERIMENTS.md, round 6)
+        static const bool wide = getenv("E3DGS_DEPTH_SORT_WIDE") && getenv("E3DGS_DEPTH_SORT_WIDE")[0] == '1';
+        if (wide) {
+            // (the sorted keys themselves are not produced: nobody reads them)
+            const int rc = launch_depth_sort_wide(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, geom.scratch, s, geom.nvis);
+            if (rc) return rc;
+            order = geom.ord0; keys_sorted = geom.key0;
+        } else {
         const int rc = launch_radix_sort_pairs(geom.key0, geom.key1, geom.ord0, geom.ord1, Q, 32, geom.scratch,
                                                &keys_sorted, &order, s, true, geom.nvis);
         if (rc) return rc;
+        }
         }
         KERNEL_OK("radix sort (depth)");
         if (order != geom.ord0 || keys_sorted != geom.key0)
@@ -1359,6 +1371,7 @@ int e3_forward_finish_impl(e3_alloc_fn bin_alloc, void* bin_user, int nviews, in
     const uint32_t I = (uint32_t)num_rendered;
     char* gp = geom_buffer;
     char* ip = image_buffer;
+    if (const int rc = e3_geom_opts_check(gp, Q, opt, "forward finish")) return rc;
     GeomState geom = GeomState::from(gp, Q);
     ImageState img = ImageState::from(ip, (size_t)W * H * nviews, ntiles);
     char* bp = bin_alloc(bin_user, BinningState::required(I));

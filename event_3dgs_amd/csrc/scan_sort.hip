@@ -556,6 +556,216 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
     }
 }
 
+// ------------------------------------------------------------------------------------ wide-digit passes (depth sort)
+// The depth sort's keys are the 32 bits of a positive float: three passes of 11 + 11 + 10 bits instead of four of 8
+// (2048-bin histograms: 8 KB of LDS; the review of round 5 asked for this build).  Same three launches per pass and the
+// same ranking scheme as the 8-bit kernels above -- 11 ballots per round instead of 8, 16-bit per-wave counters (a wave
+// ranks 1024 keys, a workgroup 4096), eight consecutive digits per thread in the digit phase.  DROP / identity payload in
+// the first pass and NOKEYS in the last one as above.
+constexpr int WIDE_BITS = 11;
+constexpr int WIDE_BINS = 1 << WIDE_BITS;
+constexpr int WIDE_DPT = WIDE_BINS / SORT_THREADS;      // digits per thread in the digit phase (8)
+
+template <bool DROP>
+__global__ __launch_bounds__(SORT_THREADS) void wide_hist_kernel(const uint32_t* __restrict__ keys, size_t n_host,
+                                                                 const uint32_t* __restrict__ n_dev, int shift,
+                                                                 uint32_t* __restrict__ hist, unsigned nblocks,
+                                                                 unsigned long long* __restrict__ scan_desc,
+                                                                 unsigned ndesc) {
+    __shared__ uint32_t h[WIDE_BINS];
+    if (blockIdx.x == 0) for (unsigned t = threadIdx.x; t < ndesc; t += SORT_THREADS) scan_desc[t] = 0ull;
+#pragma unroll
+    for (int j = 0; j < WIDE_DPT; ++j) h[j * SORT_THREADS + threadIdx.x] = 0;
+    __syncthreads();
+    const size_t n = device_count(n_dev, n_host);
+    const size_t base = (size_t)blockIdx.x * SORT_TILE;
+    if (base + SORT_TILE <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
+        uint4 q[SORT_ITEMS / 4];
+        const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(keys + base);
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS / 4; ++i) q[i] = k4[(size_t)i * SORT_THREADS + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS / 4; ++i) {
+            const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!DROP || w[j] != 0xFFFFFFFFu) atomicAdd(&h[(w[j] >> shift) & (WIDE_BINS - 1)], 1u);
+        }
+    } else if (base < n) {
+        uint32_t k[SORT_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+            k[i] = keys[idx < n ? idx : n - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            size_t idx = base + (size_t)i * SORT_THREADS + threadIdx.x;
+            if (idx < n && (!DROP || k[i] != 0xFFFFFFFFu)) atomicAdd(&h[(k[i] >> shift) & (WIDE_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WIDE_DPT; ++j) {
+        const int d = j * SORT_THREADS + threadIdx.x;
+        hist[(size_t)d * nblocks + blockIdx.x] = h[d];
+    }
+}
+
+struct WideLds {
+    union {
+        uint16_t wcnt[SORT_THREADS / WAVE][WIDE_BINS];   // per-wave digit counters, then workgroup-local offsets (< 4096)
+        uint32_t glob[WIDE_BINS];                        // (once the keys are staged) global minus local position, per digit
+    };
+    uint32_t key[SORT_TILE];
+    uint32_t val[SORT_TILE];
+    uint32_t wtot[SORT_THREADS / WAVE];
+    uint32_t nvalid;
+};                                                       // 48 KB: three workgroups per CU
+static_assert(SORT_TILE <= 65535, "16-bit workgroup-local offsets");
+
+template <bool DROP, bool NOKEYS>
+__global__ __launch_bounds__(SORT_THREADS) void wide_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                    const uint32_t* __restrict__ vals_in,
+                                                                    uint32_t* __restrict__ keys_out,
+                                                                    uint32_t* __restrict__ vals_out, size_t n_host,
+                                                                    const uint32_t* __restrict__ n_dev, int shift,
+                                                                    const uint32_t* __restrict__ offs, unsigned nblocks) {
+    constexpr int NW = SORT_THREADS / WAVE;
+    constexpr int WAVE_KEYS = SORT_TILE / NW;
+    __shared__ WideLds L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t n = device_count(n_dev, n_host);
+    const size_t block_first = (size_t)blockIdx.x * SORT_TILE;
+    if (block_first >= n) return;
+    // (32-bit stores: two counters each)
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&L.wcnt[0][0]);
+#pragma unroll
+        for (int j = 0; j < NW * WIDE_BINS / 2 / SORT_THREADS; ++j) z[j * SORT_THREADS + threadIdx.x] = 0u;
+    }
+    // global positions of this workgroup's first key of each digit (digit-major scanned histogram): issued early
+    uint32_t gfirst[WIDE_DPT];
+#pragma unroll
+    for (int j = 0; j < WIDE_DPT; ++j) gfirst[j] = offs[(size_t)(threadIdx.x * WIDE_DPT + j) * nblocks + blockIdx.x];
+    __syncthreads();
+    const size_t wbase = block_first + (size_t)wave * WAVE_KEYS;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        size_t idx = wbase + (size_t)r * WAVE + lane;
+        bool ok = idx < n;
+        key[r] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        size_t idx = wbase + (size_t)r * WAVE + lane;
+        const bool ok = idx < n && (!DROP || key[r] != 0xFFFFFFFFu);
+        const uint32_t d = (key[r] >> shift) & (WIDE_BINS - 1);
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < WIDE_BITS; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = __popcll(peers & lt_mask);
+        const uint32_t cnt = __popcll(peers);
+        uint32_t basep = 0;
+        if (ok) basep = L.wcnt[wave][d];
+        wave_sync();
+        if (ok && before == 0) L.wcnt[wave][d] = (uint16_t)(basep + cnt);
+        wave_sync();
+        pos[r] = ok ? basep + before : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // ---- digit phase: thread t owns the WIDE_DPT consecutive digits t * WIDE_DPT ...
+    uint32_t c[WIDE_DPT][NW], tot[WIDE_DPT], tsum = 0;
+#pragma unroll
+    for (int j = 0; j < WIDE_DPT; ++j) {
+        tot[j] = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { c[j][w] = L.wcnt[w][threadIdx.x * WIDE_DPT + j]; tot[j] += c[j][w]; }
+        tsum += tot[j];
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) L.wtot[wave] = inc;
+    __syncthreads();
+    uint32_t lbase = inc - tsum;
+    for (int w = 0; w < wave; ++w) lbase += L.wtot[w];
+#pragma unroll
+    for (int j = 0; j < WIDE_DPT; ++j) {
+        const int d = threadIdx.x * WIDE_DPT + j;
+        gfirst[j] -= lbase;                       // global minus local position of digit d (goes to L.glob below)
+        uint32_t l = lbase;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { L.wcnt[w][d] = (uint16_t)l; l += c[j][w]; }
+        lbase += tot[j];
+    }
+    if (threadIdx.x == SORT_THREADS - 1) L.nvalid = lbase;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        if (pos[r] != 0xFFFFFFFFu) {
+            const uint32_t dg = (key[r] >> shift) & (WIDE_BINS - 1);
+            const uint32_t lp = (uint32_t)L.wcnt[wave][dg] + pos[r];
+            L.key[lp] = key[r];
+            L.val[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    // (the offsets are dead: their storage now holds the per-digit global bases)
+#pragma unroll
+    for (int j = 0; j < WIDE_DPT; ++j) L.glob[threadIdx.x * WIDE_DPT + j] = gfirst[j];
+    __syncthreads();
+    const uint32_t nvalid = L.nvalid;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const uint32_t lp = (uint32_t)j * SORT_THREADS + threadIdx.x;
+        if (lp < nvalid) {
+            const uint32_t k = L.key[lp];
+            const uint32_t dst = L.glob[(k >> shift) & (WIDE_BINS - 1)] + lp;
+            if (!NOKEYS) keys_out[dst] = k;
+            vals_out[dst] = L.val[lp];
+        }
+    }
+}
+
+// Stable sort of n 32-bit keys (all 32 bits) with the identity payload: keys equal to 0xFFFFFFFF are dropped, the kept
+// count goes to *kept_dev, and the sorted payload lands in `v0` (three passes: v0 -> v1 -> v0).  k0 holds the keys on
+// entry; k0 / k1 are clobbered and the sorted keys are not produced (nobody reads them).  scratch: depth_sort_scratch_words(n).
+int launch_depth_sort_wide(uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, uint32_t* scratch,
+                           hipStream_t s, uint32_t* kept_dev) {
+    if (n == 0) return 0;
+    const unsigned nb = (unsigned)sort_blocks(n);
+    const size_t hn = (size_t)nb * WIDE_BINS;
+    uint32_t* hist = scratch;
+    uint32_t* scan_scratch = scratch + hn + (hn & 1);
+    unsigned long long* desc = reinterpret_cast<unsigned long long*>(scan_scratch);
+    const unsigned ndesc = (unsigned)scan_blocks(hn) + 1u;
+    const uint32_t* n_dev = nullptr;
+    uint32_t *ki = k0, *ko = k1, *vi = nullptr, *vo = v0;
+    for (int p = 0; p < 3; ++p) {
+        const int shift = WIDE_BITS * p;
+        if (p == 0) wide_hist_kernel<true><<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, n_dev, shift, hist, nb, desc, ndesc);
+        else wide_hist_kernel<false><<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, n, n_dev, shift, hist, nb, desc, ndesc);
+        LAUNCH_OK("wide_hist_kernel");
+        const int rc = launch_scan_chained_u32(hist, hist, hn, scan_scratch, false, s, nullptr, p == 0 ? kept_dev : nullptr);
+        if (rc) return rc;
+        if (p == 0) wide_scatter_kernel<true, false><<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, vi, ko, vo, n, n_dev, shift, hist, nb);
+        else if (p == 1) wide_scatter_kernel<false, false><<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, vi, ko, vo, n, n_dev, shift, hist, nb);
+        else wide_scatter_kernel<false, true><<<dim3(nb), dim3(SORT_THREADS), 0, s>>>(ki, vi, ko, vo, n, n_dev, shift, hist, nb);
+        LAUNCH_OK("wide_scatter_kernel");
+        n_dev = kept_dev;
+        uint32_t* t = ki; ki = ko; ko = t;
+        vi = vo; vo = (vo == v0) ? v1 : v0;
+    }
+    return 0;
+}
+
 // workgroups of a segment-aligned (RANGES) pass over n keys
 static inline unsigned seg_blocks(size_t n) { return (unsigned)(sort_blocks(n) + 256); }
 

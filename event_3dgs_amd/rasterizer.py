@@ -331,7 +331,10 @@ def state_views(raw, P, W, H):
         return buf[off:off + nbytes].view(dtype).reshape(shape)
     g, b, im = raw["geom"], raw["binning"], raw["image"]
     rec = view(g, offs[0], torch.float32, 12 * P, (P, 12))
+    offs_b = (C.c_size_t * 2)()
+    _lib.lib().e3dgs_state_offsets_binning(I, offs_b)
     return dict(
+        strip_mask=view(b, offs_b[0], torch.uint8, I, (I,)), touched=view(b, offs_b[1], torch.uint8, I, (I,)),
         recA=rec[:, 0:4], recB=rec[:, 4:8], recC=rec[:, 8:10], clamped=view(g, offs[3], torch.int32, P, (P,)),
         rect=view(g, offs[4], torch.int32, 2 * P, (P, 2)),
         perm=view(b, offs[5], torch.int32, I, (I,)),

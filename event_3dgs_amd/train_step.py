@@ -690,8 +690,10 @@ class EventTrainer:
         # and is matched by identity: a stale hit would rebuild the SH gradient with last iteration's directions)
         cams = tuple(st.campos for st in settings) + (settings[-1].campos,) * (nv - n_real)
         if self._packed_cams is None or not self._same_tensors(self._packed_cams, cams):
-            for k, t in enumerate(cams):
-                tail[k].copy_(t)
+            # (one launch for the three centres: a 12-byte tensor.copy_ is a hipMemcpyAsync each -- a blit kernel plus its
+            # barrier packets, ~12 us of stream time apiece, and a random camera per iteration, train.py:116-131, pays
+            # them every iteration: bench.py trained_random_camera measured +40 us per iteration against a fixed triplet)
+            torch._foreach_copy_([tail[k] for k in range(len(cams))], [t.reshape(3) for t in cams])
             self._packed_cams = (cams, tuple(t._version for t in cams))
 
     def _event_forward_backward(self, settings, gt_int, gt_now, gt_next, gt_blur, sh_via_colour, shared=False,

@@ -74,9 +74,13 @@ const char* e3dgs_last_error(void);
                                         by e3dgs_sh_adam_from_colour_mean, which reads the coefficients anyway */
 /* ---- per-call OPTIONS (ABI 13).  The library keeps no mutable process-wide state that a call reads when
  * E3DGS_FLAG_OPTIONS is set: calls with different settings may run concurrently from any number of host threads and
- * streams.  Every call of one forward / backward (begin, finish, backward) must be given the same option bits: the halves
- * derive scratch offsets and launch shapes from them on the host, and nothing short of a device read-back could check a
- * mismatch -- different bits in `finish` or `backward` than in `begin` are undefined behaviour (out-of-bounds emission).
+ * streams.  Every call of one forward / backward (begin, finish, backward) must be given the same option bits (and the
+ * same P and view count): the halves derive scratch offsets and launch shapes from them on the host.  `begin` records
+ * what it resolved -- cull mode, small-scene paths, E3DGS_FLAG_FAST_EXP, P * nviews -- on the HOST under the address of
+ * the geometry scratch (no device read-back); `finish` and every backward entry point compare and return
+ * hipErrorInvalidValue with a message, launching nothing, when they were given something else (ABI 17; until ABI 16 this
+ * was undefined behaviour: out-of-bounds emission).  The geometry scratch must therefore stay at the address the
+ * allocator returned (a scratch the caller moved is not recognised and not checked).
  * Without E3DGS_FLAG_OPTIONS the process-wide defaults apply (environment at load time, the deprecated setters
  * e3dgs_set_tile_cull / e3dgs_set_small_scene_paths). */
 #define E3DGS_FLAG_OPTIONS 0x0800         /* the option bits below describe this call */
@@ -107,7 +111,13 @@ const char* e3dgs_last_error(void);
  *   out_color (3,H,W) and radii (P) are written in full (radii 0 = culled).
  *   geom/binning/image scratch is requested through the three allocators and
  *   must stay alive, unmodified, until the matching backward has run.
- *   Contains exactly one device->host synchronisation (the instance count).
+ *   Contains exactly one device->host wait (the instance count).  Since ABI 16 that wait is NOT a stream
+ *   synchronisation: the GPU stores the count into a pinned word of the calling host thread (64 bytes, released
+ *   when the thread exits) and the host polls it (cpu-relax between reads; after 2 s without a count it falls
+ *   back to hipStreamSynchronize and reports that call's error).  The call therefore returns as soon as the count is
+ *   known, with the rest of the stream still running: asynchronous errors of EARLIER work on the stream no longer
+ *   surface here but at the caller's next synchronising call.  E3DGS_COUNT_POLL=0 in the environment, debug != 0
+ *   and a failed pinned allocation take the stream synchronisation instead.
  *   *num_rendered_host receives the number of (tile, Gaussian) instances.
  */
 int e3dgs_rasterize_forward(
@@ -456,6 +466,10 @@ void e3dgs_state_offsets(int P, int num_rendered, int width, int height, size_t*
  * out[6] -> ranges of the nviews * tiles tiles, out[7] / out[8] -> final_T / n_contrib as (nviews, H, W) planes */
 void e3dgs_state_offsets_multi(int nviews, int P, int num_rendered, int width, int height, size_t* out9);
 size_t e3dgs_state_offset_emit_gid(int num_rendered);
+/* (ABI 17) two more members of the binning scratch, for tools: out[0] -> strip_mask (one byte per LIST POSITION: bit k =
+ * the forward evaluated the entry on the tile's 16x4 pixel strip k), out[1] -> touched (one byte per SLOT: the compositing
+ * backward writes a gradient record for this instance) */
+void e3dgs_state_offsets_binning(int num_rendered, size_t* out2);
 
 /*
  * present[i] = 1 iff Gaussian i passes the near-plane test of the forward.
@@ -583,6 +597,10 @@ int e3dgs_image_loss_rank1(int height, int width, float lambda_dssim, const floa
  * Fused Adam step over one flat parameter tensor (train.py:330-332; groups
  * scene/gaussian_model.py:154-163; eps 1e-15).  Matches torch.optim.Adam
  * (no amsgrad, no weight decay): bias-corrected with step count `step`.
+ * beta1 / beta2 cross this boundary as fp32 while torch derives 1 - beta and beta^step from the Python double the
+ * caller wrote; every Adam entry point of this header therefore takes the 7-digit decimal nearest to the fp32 value
+ * WHEN that decimal converts back to the same fp32 value and lies in [0, 1) (0.9f -> 0.9, 0.999f -> 0.999), and the
+ * fp32 value itself otherwise (a scheduled beta, 1 - 1/k, a beta within 5e-8 of 1).
  */
 int e3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg,
                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
@@ -670,6 +688,17 @@ size_t e3dgs_sort_scratch_bytes(size_t n);
 int e3dgs_sort_pairs(size_t n, int nbits, int key_bytes, void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1,
                      int identity_payload, char* scratch, uint32_t* kept_count_dev, uint32_t* ranges, uint32_t nranges,
                      int* result_index_host, void* stream);
+/*
+ * The depth sort of the splats on its own (ABI 17): stable sort of n 32-bit keys on ALL 32 bits in three passes of
+ * 11 + 11 + 10 bits (2048-bin histograms in LDS) with the identity payload -- order[j] = index of the j-th smallest key,
+ * ties in index order; keys equal to 0xFFFFFFFF (splats the projection culled) are dropped and the kept count is stored
+ * in *kept_count_dev (device word, required).  keys0 holds the keys on entry; keys0 / keys1 / order_alt are clobbered and
+ * the sorted keys are not produced.  scratch: e3dgs_depth_sort_scratch_bytes(n) bytes, 8-byte aligned.
+ * Replaces the depth half of cub::DeviceRadixSort::SortPairs ([UPSTREAM] rasterizer_impl.cu; DESIGN.md decision 51).
+ */
+size_t e3dgs_depth_sort_scratch_bytes(size_t n);
+int e3dgs_sort_depth_keys(size_t n, uint32_t* keys0, uint32_t* keys1, uint32_t* order, uint32_t* order_alt, char* scratch,
+                          uint32_t* kept_count_dev, void* stream);
 
 /*
  * Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).

@@ -96,7 +96,10 @@ void gso_event_loss(int W, int H, const float *image, const float *now, const fl
 
 /* torch.optim.Adam evaluates 1 - beta, beta^step on the Python double the caller wrote (0.9, 0.999); the betas arrive here
  * as fp32, so the decimal is recovered first (7 digits) -- (float)0.999 would put 1 - beta2 1.3e-5 away from torch's. */
-static double beta_double(float b) { return nearbyint((double)b * 1e7) / 1e7; }
+static double beta_double(float b) {
+    const double d = nearbyint((double)b * 1e7) / 1e7;       /* only when it IS the caller's decimal and < 1 */
+    return ((float)d == b && d >= 0.0 && d < 1.0) ? d : (double)b;
+}
 void gso_adam(size_t n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps, int step) {
     double bc1 = 1.0 - pow(beta_double(b1), step), bc2 = 1.0 - pow(beta_double(b2), step);
     float step_size = (float)(lr / bc1);

@@ -24,7 +24,7 @@ def test_loader_symbol_list_matches_header():
 
 
 def test_abi_version_and_scratch_sizes(hip_lib):
-    assert hip_lib.e3dgs_abi_version() == 16
+    assert hip_lib.e3dgs_abi_version() == 17
     assert hip_lib.e3dgs_knn_scratch_bytes(1000) > 1000 * 16
     assert hip_lib.e3dgs_event_loss_scratch_bytes(1920, 1080) >= 5 * 8
 

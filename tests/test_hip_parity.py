@@ -558,6 +558,33 @@ def test_argument_errors_of_the_operator_and_the_c_abi():
                     (dict(colors=d["colors"]), "exactly one of shs")):
         assert call(**kw) != 0
         assert msg in L.e3dgs_last_error().decode()
+    # the halves of one forward / backward must be given the option bits `begin` resolved (include/e3dgs_hip.h, "per-call
+    # OPTIONS"): the library remembers them per geometry scratch and refuses anything else -- code + message, no launch
+    from event_3dgs_amd import rasterizer
+    args = (d["means3D"], None, d["colors"], d["opacities"], d["scales"], d["rotations"], None, rs)
+    exact = _lib.option_flags(tile_cull=True, small_scene_paths=True)
+    rect = _lib.option_flags(tile_cull=False, small_scene_paths=True)
+    big = _lib.option_flags(tile_cull=True, small_scene_paths=False)
+    assert len({exact, rect, big}) == 3
+    for wrong, what in ((rect, "cull"), (big, "small_paths"), (exact | _lib.FLAG_FAST_EXP, "fast_exp")):
+        pend = rasterizer.forward_begin(*args, flags=exact)
+        torch.cuda.synchronize()
+        pend.flags = wrong
+        with pytest.raises(RuntimeError, match="option bits"):
+            rasterizer.forward_finish(pend)
+        assert "nothing was launched" in L.e3dgs_last_error().decode() and what in L.e3dgs_last_error().decode()
+        pend.flags = exact
+        raw = rasterizer.forward_finish(pend)        # the right bits still work on the same scratch
+        out = {"cov3D": None, "sh": None, "means2D": torch.empty(50, 3, device=dev), "opacities": torch.empty(50, 1, device=dev),
+               "colors": torch.empty(50, 3, device=dev), "scales": torch.empty(50, 3, device=dev),
+               "rots": torch.empty(50, 4, device=dev), "means3D": torch.full((50, 3), 7.0, device=dev)}
+        with pytest.raises(RuntimeError, match="option bits"):
+            rasterizer.backward_raw(raw, torch.ones(3, 32, 48, device=dev), out, flags=wrong)
+        torch.cuda.synchronize()
+        assert bool((out["means3D"] == 7.0).all()), "the refused backward must not have written anything"
+        rasterizer.backward_raw(raw, torch.ones(3, 32, 48, device=dev), out, flags=exact)
+        torch.cuda.synchronize()
+        assert not bool((out["means3D"] == 7.0).all())
 
 
 def test_operator_on_a_side_stream_and_interleaved_forwards():

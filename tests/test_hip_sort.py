@@ -62,6 +62,39 @@ def test_depth_sort_32_bit_keys_with_and_without_the_compacting_first_pass(n, id
         assert np.array_equal(kout[:m], kref) and np.array_equal(vout[:m], vref), (n, identity, drop)
 
 
+@pytest.mark.parametrize("n", [1, 63, 4096, 4097, 300_001, 3_000_000])
+@pytest.mark.parametrize("kind", ["random", "depths", "few"])
+def test_depth_sort_in_three_11_bit_passes(n, kind):
+    """e3dgs_sort_depth_keys (what the forward runs): all 32 key bits in passes of 11 + 11 + 10, culled splats dropped,
+    ties in index order -- against numpy's stable argsort."""
+    from event_3dgs_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(n + len(kind))
+    if kind == "random":
+        keys = rs.randint(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    elif kind == "depths":            # float bits of view-space depths 0.2 ... 100 (what the projection stores)
+        keys = np.exp(rs.uniform(np.log(0.2), np.log(100.0), n)).astype(np.float32).view(np.uint32).copy()
+    else:                             # three distinct values: every digit of every pass collides
+        keys = rs.choice(np.array([0x40000000, 0x40000800, 0x40400000], np.uint32), n)
+    keys[rs.rand(n) < 0.35] = 0xFFFFFFFF
+    keys[rs.rand(n) < 0.05] = keys[0]
+    k0 = torch.from_numpy(keys.view(np.int32).copy()).to(dev)
+    k1 = torch.empty_like(k0)
+    v0 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    v1 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(L.e3dgs_depth_sort_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    kept = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    rc = L.e3dgs_sort_depth_keys(n, _lib.ptr(k0), _lib.ptr(k1), _lib.ptr(v0), _lib.ptr(v1), _lib.ptr(scratch), _lib.ptr(kept),
+                                 _lib.current_stream())
+    _lib.check(rc, "e3dgs_sort_depth_keys")
+    torch.cuda.synchronize()
+    sel = np.arange(n)[keys != 0xFFFFFFFF]
+    ref = sel[np.argsort(keys[sel], kind="stable")]
+    assert int(kept[0]) == len(ref)
+    assert np.array_equal(v0.cpu().numpy()[:len(ref)], ref.astype(np.int32))
+
+
 def test_all_keys_dropped():
     keys = np.full(10_000, 0xFFFFFFFF, np.uint32)
     _, _, kept, _, _ = _sort(keys, 32, 4, drop=True)
