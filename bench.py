@@ -100,6 +100,25 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # ---- who is really in the communicator: every rank contributes (host, device UUID / PCI bus id) through the backend's own
+    # all-gather; `rccl_ranks` in the JSON line is the number of DISTINCT devices that answered -- world ranks that share a GPU,
+    # or a backend that is not RCCL, show up here instead of hiding behind get_world_size().  E3DGS_BENCH_STRICT=1: anything
+    # but one RCCL rank per GPU is an error.
+    rccl_ranks, distinct_devices = 1, 1
+    if world > 1:
+        import socket
+        import zlib
+        props = torch.cuda.get_device_properties(dev)
+        ident = "%s|%s|%s" % (socket.gethostname(), getattr(props, "uuid", ""), getattr(props, "pci_bus_id", dev_index))
+        mine = torch.tensor([zlib.crc32(ident.encode()) & 0x7FFFFFFF, dev_index], dtype=torch.int64, device=dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        distinct_devices = len({(int(t[0]), int(t[1])) for t in everyone})
+        rccl_ranks = distinct_devices if dist.get_backend() == "nccl" else 0
+        if os.environ.get("E3DGS_BENCH_STRICT") == "1" and (dist.get_backend() != "nccl" or distinct_devices != world):
+            raise SystemExit("E3DGS_BENCH_STRICT=1: %d ranks over backend %s on %d distinct devices -- expected one RCCL rank "
+                             "per GPU" % (world, dist.get_backend(), distinct_devices))
+
     cfg_name = args.config or "cfg3_1M_1080p_event"
     N, W, H, deblur = CONFIGS[cfg_name]
     L = _lib.lib()
@@ -151,6 +170,10 @@ def main():
             err = "%s: %s" % (type(ex).__name__, str(ex)[:200])
         flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag[0]) and os.environ.get("E3DGS_BENCH_STRICT") == "1":
+            # strict runs never trade a failing exchange for a slower schedule: they stop, with the first error on record
+            raise SystemExit("E3DGS_BENCH_STRICT=1: the overlapped / factorised gradient exchange failed on rank %d: %s"
+                             % (rank, err or "(another rank failed)"))
         if int(flag[0]):
             os.environ["E3DGS_FACTORIZE_SH"] = "0"
             os.environ["E3DGS_OVERLAP"] = "0"
@@ -655,7 +678,8 @@ def main():
             "device_allocs_in_timed_region": device_allocs,
             # ranks the communicator itself reports (1: no process group) and whether the factorised / overlapped
             # exchange had to be replaced by the plain schedule (a failing exchange must not hide in a slower number)
-            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "rccl_ranks": rccl_ranks, "distinct_devices_in_the_communicator": distinct_devices,
+            "world_size": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "comm_backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
             "dp_fallback": dp_fallback, "comm": comm,
         }

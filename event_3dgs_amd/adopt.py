@@ -41,18 +41,31 @@ def _features(pc):
     (scene/gaussian_model.py:105-108), made ONCE per parameter version instead of once per render() -- the three renders of
     an iteration see the same coefficients (192 MB per cat at 1 M Gaussians).  The cached tensor is detached; the
     gradient goes back to the two leaves through the autograd node of render()."""
+    import weakref
     dc, rest = pc._features_dc, pc._features_rest
     key = (dc._version, rest._version, dc.data_ptr(), rest.data_ptr(), tuple(dc.shape), tuple(rest.shape))
     hit = getattr(pc, "_e3dgs_feature_cache", None)
-    if hit is not None and hit[0] == key and hit[1] is dc and hit[2] is rest:
+    # (weak references: after a densification step the entry must not keep the replaced Parameters -- and their 192 MB at
+    # 1 M Gaussians -- alive until the next render.  Writers that go through raw pointers must bump the version counters:
+    # FusedAdam and losses.adam_step_ / adam_step_segments_ do; anything else calls adopt.invalidate(pc).)
+    if hit is not None and hit[0] == key and hit[1]() is dc and hit[2]() is rest:
         return hit[3]
     with torch.no_grad():
         cat = torch.cat((dc, rest), dim=1).contiguous()
     try:
-        pc._e3dgs_feature_cache = (key, dc, rest, cat)
+        pc._e3dgs_feature_cache = (key, weakref.ref(dc), weakref.ref(rest), cat)
     except AttributeError:
         pass
     return cat
+
+
+def invalidate(pc):
+    """Drop the cached (P, 16, 3) coefficient tensor of `pc` (see _features): for callers that update `_features_dc` /
+    `_features_rest` through a path that bumps no autograd version counter (a raw-pointer kernel of their own, DLPack)."""
+    try:
+        pc._e3dgs_feature_cache = None
+    except AttributeError:
+        pass
 
 
 class _SplitFeatures(torch.autograd.Function):
@@ -128,6 +141,9 @@ class _RasterizeViews(torch.autograd.Function):
         raw = rasterizer.forward_multi_finish(pend)
         ctx.raw = raw
         ctx.n = len(settings)
+        # (the kernels read the inputs again in backward: saved through autograd, so that an in-place update between forward
+        # and backward is reported the way autograd reports it for any saved tensor, as the C++ node of single renders does)
+        ctx.save_for_backward(xyz, shs, opacity, scaling, rotation)
         radii = raw["radii"]
         ctx.mark_non_differentiable(radii)
         return (radii,) + tuple(raw["color"][k] for k in range(ctx.n))
@@ -135,6 +151,10 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g_radii, *g_imgs):
         raw, n = ctx.raw, ctx.n
+        if raw is None:
+            raise RuntimeError("Trying to backward through render_views() a second time: the rasteriser's scratch buffers "
+                               "were released by the first backward (render again; retain_graph=True is not supported here)")
+        _ = ctx.saved_tensors                    # (autograd's version check of the five inputs)
         ctx.raw = None
         xyz, shs, _, scaling, rotation, _ = raw["inputs"]
         H, W = raw["color"].shape[2], raw["color"].shape[3]

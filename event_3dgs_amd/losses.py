@@ -153,6 +153,15 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.99
                                         _lib.ptr(exp_avg_sq), float(lr), beta1, beta2, eps, int(step), float(lr_b),
                                         int(period), int(split), _lib.current_stream())
     _lib.check(rc, "e3dgs_adam_step")
+    _bump_versions(param, exp_avg, exp_avg_sq)
+
+
+def _bump_versions(*tensors):
+    """The kernels above write through raw pointers, which autograd's version counters do not see: bump them, so that
+    everything keyed on `tensor._version` (adopt._features' coefficient cache, autograd's saved-tensor check, PairCounts)
+    notices the update as it would notice an in-place torch op."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
 
 
 def adam_step_segments_(param, grad, exp_avg, exp_avg_sq, seg_end, lrs, eps, step, beta1=0.9, beta2=0.999, gap=None):
@@ -183,6 +192,7 @@ def adam_step_segments_(param, grad, exp_avg, exp_avg_sq, seg_end, lrs, eps, ste
         else:
             rc = _lib.lib().e3dgs_adam_step_segments(*common, int(step), _lib.current_stream())
     _lib.check(rc, "e3dgs_adam_step_segments")
+    _bump_versions(param, exp_avg, exp_avg_sq)
 
 
 # ---------------------------------------------------------------------------------------------------------------

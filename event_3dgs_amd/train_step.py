@@ -759,39 +759,60 @@ class EventTrainer:
             raise ValueError("the two event frames of an iteration must have the same size")
         f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
         g = self.grads
-        if getattr(self, "_grad2", None) is None or self._grad2.numel() != self.flat_grad.numel():
-            self._grad2 = torch.empty_like(self.flat_grad)
-        g2 = {name: self._grad2[off:off + n].view(self.grads[name].shape) for name, (off, n) in self.seg.items() if name != "c"}
+        via_colour = self.factorize_sh or sh_via_colour
+        # second gradient buffer (pass [now, next]): the non-SH segments, packed; the 48 N floats of the SH segment only when
+        # its gradient goes to memory at all (via_colour: never written -- 192 MB at 1 M Gaussians that nobody would touch)
+        names2 = [n_ for n_ in ("xyz", "opacity", "scaling", "rotation") + (() if via_colour else ("features",))]
+        need2 = sum(self.seg[n_][1] for n_ in names2)
+        if getattr(self, "_grad2", None) is None or self._grad2.numel() != need2:
+            self._grad2 = torch.empty(need2, dtype=torch.float32, device=self.device)
+        g2, o2 = {}, 0
+        for n_ in names2:
+            cnt = self.seg[n_][1]
+            g2[n_] = self._grad2[o2:o2 + cnt].view(self.grads[n_].shape)
+            o2 += cnt
+        g2.setdefault("features", None)
         for _attempt in range(4):
             raw_i = self._forward_views(settings[:1], slot=1)
             raw_e = self._forward_views(settings[1:], slot=0)
             img, now, nxt = raw_i["color"][0], raw_e["color"][0], raw_e["color"][1]
             # contrast term with the event-loss kernel: the intensity slot is fed a frame of the PAIR's size as render and
             # target (L1 = 0 there, no gradient) -> rho, L1(contrast), dL/dc, and the two contrast renders' pixel gradients
-            dpix_e = torch.zeros_like(raw_e["color"])
-            out_l = (torch.empty(8, device=self.device), torch.empty_like(now), dpix_e[0], dpix_e[1],
-                     torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(now.shape[2], now.shape[1]), dtype=torch.uint8,
-                                 device=self.device))
+            # (loss buffers kept per pair of frame sizes, as _loss_bufs of the uniform path: nothing is allocated per iteration)
+            key2 = ("event2",) + tuple(raw_e["color"].shape) + tuple(img.shape)
+            if getattr(self, "_loss_bufs2", None) is None or self._loss_bufs2[0] != key2:
+                self._loss_bufs2 = (key2, torch.zeros_like(raw_e["color"]), torch.empty(8, device=self.device),
+                                    torch.empty_like(now),
+                                    torch.empty(_lib.lib().e3dgs_event_loss_scratch_bytes(now.shape[2], now.shape[1]),
+                                                dtype=torch.uint8, device=self.device),
+                                    torch.zeros(2, 8, dtype=torch.float32, device=self.device))
+            _, dpix_e, sc_buf, d_dummy, scr2, scal2 = self._loss_bufs2
+            out_l = (sc_buf, d_dummy, dpix_e[0], dpix_e[1], scr2)
             sc, _, _, _ = losses.event_loss_raw(f32(gt_now), now, nxt, self.c, f32(gt_now), f32(gt_now), f32(gt_next), None,
-                                                out=out_l, rank1=self.rank1)
+                                                out=out_l, pair_counts=self._pair_counts, rank1=self.rank1)
             rho = sc[2]
             e_int = img - f32(gt_int)
             l1_int = e_int.abs().mean()
             d_img = (0.1 * (1.0 - rho) / e_int.numel()) * torch.sign(e_int)
             loss = sc[0] + 0.1 * l1_int * (1.0 - rho)
             dc = sc[1]
+            l1_blur = None
             if gt_blur is not None:                                            # train.py:197-203
                 e_b = img - f32(gt_blur)
-                loss = 0.5 * loss + 0.5 * e_b.abs().mean()
+                l1_blur = e_b.abs().mean()
+                loss = 0.5 * loss + 0.5 * l1_blur
                 d_img = 0.5 * d_img + (0.5 / e_b.numel()) * torch.sign(e_b)
                 dpix_e.mul_(0.5)
                 dc = 0.5 * dc
-            scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+            self._loss_flip2 = 1 - getattr(self, "_loss_flip2", 0)
+            scalars = scal2[self._loss_flip2]             # (two blocks used alternately, as the uniform path's)
+            scalars.zero_()
             scalars[0], scalars[1], scalars[2], scalars[3], scalars[4] = loss, dc, rho, sc[3], l1_int
+            if l1_blur is not None:
+                scalars[5] = l1_blur                      # (the uniform path reports the blur L1 there too)
             # ---- backward: pass [intensity] into the gradient buffer, pass [now, next] into a second one
             out_i = dict(means3D=g["xyz"], sh=g["features"], opacities=g["opacity"], scales=g["scaling"], rots=g["rotation"])
             out_e = dict(means3D=g2["xyz"], sh=g2["features"], opacities=g2["opacity"], scales=g2["scaling"], rots=g2["rotation"])
-            via_colour = self.factorize_sh or sh_via_colour
             if via_colour:
                 both = dict(out_i)
                 self._colour_gradients_instead_of_sh(both, settings, pad_to=3 if self.multi else None)
@@ -811,14 +832,8 @@ class EventTrainer:
         else:
             raise RuntimeError("the instance count kept outgrowing the binning capacity")
         # sum of the two passes (the SH segment only when its gradient is in memory)
-        x_off, x_n = self.seg["xyz"]
-        t_off = self.seg["opacity"][0]
-        t_end = self.seg["c"][0]
-        self.flat_grad[x_off:x_off + x_n].add_(self._grad2[x_off:x_off + x_n])
-        self.flat_grad[t_off:t_end].add_(self._grad2[t_off:t_end])
-        if not via_colour:
-            f_off, f_n = self.seg["features"]
-            self.flat_grad[f_off:f_off + f_n].add_(self._grad2[f_off:f_off + f_n])
+        for n_ in names2:
+            self.grads[n_].add_(g2[n_])
         self.c_grad.copy_(scalars[1:2])
         self.last_radii = raw_i["radii"][0]
         self.last_scalars = scalars

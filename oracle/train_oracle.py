@@ -39,6 +39,46 @@ class _OracleRasterize(torch.autograd.Function):
                 t(g["rotations"], (P, 4)), None, None, None)
 
 
+class _OracleRasterizeViews(torch.autograd.Function):
+    """The three renders of an iteration as one node: the C oracle is single-threaded and ctypes releases the GIL, so the
+    views run on three host threads, forward and backward (same arithmetic per view; the gradients are summed in view
+    order, as autograd would add them)."""
+
+    @staticmethod
+    def forward(ctx, means3D, shs, opacities, scales, rotations, cams, bg, sh_degree):
+        from concurrent.futures import ThreadPoolExecutor
+        arrs = dict(means3D=means3D.detach().numpy(), opacities=opacities.detach().numpy(), shs=shs.detach().numpy(),
+                    scales=scales.detach().numpy(), rotations=rotations.detach().numpy())
+
+        def one(cam):
+            return c_oracle.Forward(viewmatrix=cam["view"], projmatrix=cam["proj"], campos=cam["campos"], bg=bg,
+                                    width=cam["W"], height=cam["H"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                    sh_degree=sh_degree, **arrs)
+        with ThreadPoolExecutor(max_workers=len(cams)) as ex:
+            ctx.fs = list(ex.map(one, cams))
+        return tuple(torch.from_numpy(f.out_color.copy()) for f in ctx.fs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(args):
+            f, g = args
+            out = f.backward(g.contiguous().numpy())
+            f.close()
+            return out
+        with ThreadPoolExecutor(max_workers=len(ctx.fs)) as ex:
+            gs = list(ex.map(one, zip(ctx.fs, grads)))
+        t = lambda a, shape: torch.from_numpy(np.ascontiguousarray(a)).reshape(shape)
+        P = gs[0]["means3D"].shape[0]
+        acc = None
+        for g in gs:
+            cur = [t(g["means3D"], (P, 3)), t(g["shs"], (P, -1, 3)), t(g["opacities"], (P, 1)), t(g["scales"], (P, 3)),
+                   t(g["rotations"], (P, 4))]
+            acc = cur if acc is None else [a + b for a, b in zip(acc, cur)]
+        return tuple(acc) + (None, None, None)
+
+
 def camera_dict(cam):
     """Host copy of what GaussianRasterizationSettings carries for one camera (gaussian_renderer/__init__.py:38-51)."""
     return dict(view=cam.world_view_transform.contiguous().cpu().numpy(), proj=cam.full_proj_transform.cpu().numpy(),
@@ -55,7 +95,8 @@ def expon_lr(step, lr_init, lr_final, lr_delay_mult, max_steps):
 class OracleTrainer:
     def __init__(self, params, spatial_lr_scale=1.0, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
                  position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05,
-                 scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, sh_degree=3):
+                 scaling_lr=5e-3, rotation_lr=1e-3, c_init=0.17, c_lr=0.1, sh_degree=3, parallel_views=False):
+        self.parallel_views = bool(parallel_views)          # the three renders of step() on three host threads
         P = lambda t: torch.nn.Parameter(t.detach().cpu().clone().float())
         self.p = {k: P(params[k]) for k in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")}
         self.sched = (position_lr_init * spatial_lr_scale, position_lr_final * spatial_lr_scale, position_lr_delay_mult,
@@ -88,7 +129,10 @@ class OracleTrainer:
             if g["name"] == "xyz":
                 g["lr"] = expon_lr(self.iteration, *self.sched)
         m, sh, o, s, r = self.activated()
-        imgs = [_OracleRasterize.apply(m, sh, o, s, r, cam, bg, self.sh_degree) for cam in (cam_int, cam_now, cam_next)]
+        if self.parallel_views:
+            imgs = _OracleRasterizeViews.apply(m, sh, o, s, r, (cam_int, cam_now, cam_next), bg, self.sh_degree)
+        else:
+            imgs = [_OracleRasterize.apply(m, sh, o, s, r, cam, bg, self.sh_degree) for cam in (cam_int, cam_now, cam_next)]
         loss = torch_oracle.event_iteration_loss(imgs[0], imgs[1], imgs[2], gt_int, gt_now, gt_next, self.c, gt_blur)
         self.opt_c.zero_grad()
         loss.backward()

@@ -46,7 +46,9 @@ def test_bench_gpus2_self_launches_and_prints_one_json_line(force_fallback, sche
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["comm_backend"] == "gloo"
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["comm_backend"] == "gloo"
+    # (the census over the backend's own all-gather: two ranks, ONE device, and no RCCL rank at all under gloo)
+    assert out["rccl_ranks"] == 0 and out["distinct_devices_in_the_communicator"] == 1
     assert out["scaling"] == "weak" and out["value"] > 0
     assert out["dp_fallback"] is force_fallback
     assert out["config"]["workload"] == "tiny"
@@ -72,9 +74,43 @@ def test_bench_gpus8_dry_run_on_one_gpu():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["comm_backend"] == "gloo"
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["comm_backend"] == "gloo"
+    assert out["rccl_ranks"] == 0 and out["distinct_devices_in_the_communicator"] == 1
     assert out["scaling"] == "weak" and out["value"] > 0 and out["dp_fallback"] is False
     assert out["comm"]["sh_exchange"] == "factorised"
+
+
+@pytest.mark.gpu
+def test_bench_strict_mode_refuses_anything_but_one_rccl_rank_per_gpu():
+    """E3DGS_BENCH_STRICT=1 (what a real multi-GPU run sets): ranks that share a device or talk over another backend, and a
+    failing first exchange, end the run with a message instead of a quieter, slower line."""
+    env = dict(os.environ, E3DGS_BENCH_BACKEND="gloo", E3DGS_BENCH_DEVICE="0", E3DGS_BENCH_STRICT="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode != 0
+    assert "E3DGS_BENCH_STRICT=1" in (r.stderr + r.stdout) and "one RCCL rank per GPU" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_bench_real_rccl_ranks_one_per_gpu_strict(n):
+    """The driver's multi-GPU command form with E3DGS_BENCH_STRICT=1 on a box that HAS n GPUs (skipped elsewhere): one RCCL
+    rank per GPU, no fallback, `rccl_ranks` == n from the communicator's own all-gather."""
+    import torch
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs {n} GPUs (this box has {torch.cuda.device_count()})")
+    env = dict(os.environ, E3DGS_BENCH_STRICT="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "E3DGS_BENCH_BACKEND", "E3DGS_BENCH_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "tiny", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["comm_backend"] == "nccl" and out["dp_fallback"] is False
+    assert out["distinct_devices_in_the_communicator"] == n and out["value"] > 0
 
 
 @pytest.mark.gpu
@@ -105,8 +141,12 @@ def test_bench_single_gpu_line_carries_the_contract():
     assert cb["value"] > 0 and cb["unit"] == "iters/s" and cb["cores"] >= 1 and cb["kind"] in ("port", "reference")
     assert isinstance(cb["sample"], str) and cb["sample"]
     assert out["device_allocs_in_timed_region"] == 0
-    for key in ("contrast_only_substep", "shared_pose_iteration", "dropin_autograd_step"):
+    for key in ("contrast_only_substep", "shared_pose_iteration", "dropin_autograd_step", "trained_random_camera"):
         assert key in out
+    trc = out["trained_random_camera"]
+    assert trc["trained_random_camera"]["ms_per_step"] > 0 and trc["trained_random_camera"]["count_retries"] >= 0
+    assert trc["walk_statistics"]["trained"]["intensity"]["walked_fraction"] > 0
+    assert len(trc["trace_markers"]) == 10
     assert out["shared_pose_iteration"]["taken"] is True and out["shared_pose_iteration"]["renders"] == 2
     # how to read the headline: a sustained window, a frozen workload, the literal reference binning
     assert out["sustained"]["steps"] >= 500 and out["sustained"]["ms_per_step"] > 0

@@ -84,3 +84,98 @@ def test_distributed_schedules_over_rccl_with_one_rank():
         assert c["finite"], name
         assert c["loss_equal"], (name, c)
         assert c["params_equal"] and c["exp_avg_equal"] and c["exp_avg_sq_equal"], (name, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Real RCCL ranks, one per GPU: collected everywhere, skipped where the box has fewer GPUs than ranks -- the first box with
+# two (four, eight) GPUs runs the schedules below without anybody having to remember to.  Same workload, same emulation and
+# the same tolerances as tests/test_hip_multirank.py::test_world_4_and_8_... (gloo, all ranks on one GPU), so "equal to the
+# emulation" here and there means RCCL and gloo agree with each other to the emulation's tolerance.
+N_RCCL, W_RCCL, H_RCCL = 20003, 208, 144
+
+
+def _rccl_inputs(rank, dev):
+    import torch
+    from event_3dgs_amd import synth
+    from event_3dgs_amd.cameras import orbit_camera
+    from event_3dgs_amd.train_step import EventTrainer
+    params = synth.make_scene(N_RCCL, "trained", seed=0, device=dev)
+    cams = [orbit_camera(3 * rank, 32 if rank >= 5 else 16, W_RCCL, H_RCCL, device=dev, daz=d) for d in (0.0, 0.004, 0.012)]
+    bg = torch.zeros(3, device=dev)
+    gp = dict(params)
+    gp["xyz"] = params["xyz"] + 0.01 * torch.randn(N_RCCL, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    gt = EventTrainer(gp, dev)
+    gts = [(torch.round(gt.render_raw(c, bg)["color"].clamp(0, 1) * 255.0) / 255.0).contiguous() for c in cams]
+    return params, cams, gts, bg
+
+
+def _rccl_worker(rank, world, port, out, schedule, overlap, factorize, steps):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["E3DGS_FACTORIZE_SH"] = "1" if factorize else "0"
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from event_3dgs_amd.train_step import EventTrainer
+    params, cams, gts, bg = _rccl_inputs(rank, dev)
+    tr = EventTrainer(params, dev, overlap_features=overlap, dp_schedule=schedule)
+    assert tr.world == world and tr.rank == rank and tr.multi and tr.dp_schedule == schedule
+    assert tr.factorize_sh == factorize and tr.overlap_features == overlap and dist.get_backend() == "nccl"
+    for _ in range(steps):
+        tr.step(*cams, *gts, bg)
+    tr.sync_features(); tr.sync_optimizer_state()
+    torch.cuda.synchronize()
+    torch.save({"flat": tr.flat.cpu(), "m": tr.exp_avg.cpu(), "v": tr.exp_avg_sq.cpu()}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:          # noqa: BLE001
+        return 0
+
+
+@pytest.mark.parametrize("schedule,overlap,factorize", [("allreduce", True, True), ("rs_ag", True, True),
+                                                         ("allreduce", False, False), ("rs_ag", False, False)])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_ranks_one_per_gpu_replicas_identical_and_equal_to_the_mean_of_the_ranks(tmp_path, world, schedule, overlap,
+                                                                                      factorize):
+    if _gpu_count() < world:
+        pytest.skip(f"needs {world} GPUs (this box has {_gpu_count()}); world 1 over RCCL and world 2 / 4 / 8 over gloo on one "
+                    "GPU run in test_distributed_schedules_over_rccl_with_one_rank / tests/test_hip_multirank.py")
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    steps = 2
+    out = str(tmp_path / "rank")
+    mp.spawn(_rccl_worker, args=(world, port, out, schedule, overlap, factorize, steps), nprocs=world, join=True)
+    rs = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in range(1, world):
+        for k in ("flat", "m", "v"):
+            assert torch.equal(rs[0][k], rs[r][k]), (r, k)                 # replicas bit-identical
+    # single-process emulation on GPU 0: the mean of the ranks' gradient buffers, one Adam
+    from event_3dgs_amd.train_step import EventTrainer
+    dev = torch.device("cuda", 0)
+    ins = [_rccl_inputs(r, dev) for r in range(world)]
+    bg = ins[0][3]
+    ts = [EventTrainer(i[0], dev, overlap_features=False) for i in ins]
+    for _ in range(steps):
+        for t, (_, cams, gts, _) in zip(ts, ins):
+            t.compute_gradients(*cams, *gts, bg)
+        mean = torch.stack([t.flat_grad for t in ts]).sum(0).div_(world)
+        for t in ts:
+            t.flat_grad.copy_(mean)
+            t.apply_update()
+    torch.cuda.synchronize()
+    m_ref, m_got = ts[0].exp_avg.cpu(), rs[0]["m"]
+    assert float((m_got - m_ref).norm() / m_ref.norm()) < 1e-4
+    v_ref, v_got = ts[0].exp_avg_sq.cpu(), rs[0]["v"]
+    assert float((v_got - v_ref).norm() / v_ref.norm()) < 1e-4
+    assert float((rs[0]["flat"] - ts[0].flat.cpu()).abs().max()) <= 0.05
