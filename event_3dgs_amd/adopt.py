@@ -82,14 +82,160 @@ class _SplitFeatures(torch.autograd.Function):
         return g[:, :ctx.n_dc], g[:, ctx.n_dc:], None
 
 
-def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+import os as _os
+
+DEFER_RENDERS = _os.environ.get("E3DGS_ADOPT_DEFER", "1") != "0"
+_META_GETTERS = None
+
+
+def _meta_getters():
+    """Tensor attributes a lazy result answers from its own metadata (shape, dtype, device ...) without rendering."""
+    global _META_GETTERS
+    if _META_GETTERS is None:
+        T = torch.Tensor
+        _META_GETTERS = {T.shape.__get__, T.dtype.__get__, T.device.__get__, T.is_cuda.__get__, T.ndim.__get__, T.size,
+                         T.dim, T.numel, T.element_size, T.is_floating_point, T.is_contiguous, T.stride, T.__len__,
+                         T.layout.__get__, T.is_sparse.__get__, T.is_quantized.__get__, T.is_meta.__get__}
+    return _META_GETTERS
+
+
+class _Lazy(torch.Tensor):
+    """One output of a deferred render(): a tensor whose VALUE exists from its first use on.  Any torch operation on it
+    (operators, methods, torch.* functions, indexing with it) is run on the real tensor -- which carries the autograd
+    history of the rasteriser node -- after the pending renders of its batch have gone through the rasteriser in one
+    pass.  Shape / dtype / device are answered without rendering."""
+
+    @staticmethod
+    def __new__(cls, batch, getter, shape, dtype, device):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device, requires_grad=False)
+        t._e3_batch, t._e3_get = batch, getter
+        return t
+
+    def _value(self):
+        self._e3_batch.flush()
+        return self._e3_get()
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _meta_getters():
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        from torch.utils._pytree import tree_map
+        real = lambda x: x._value() if isinstance(x, _Lazy) else x
+        return func(*tree_map(real, args), **tree_map(real, kwargs))
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # (reached only when something bypasses __torch_function__, e.g. a C++ extension that takes the tensor as it is)
+        from torch.utils._pytree import tree_map
+        real = lambda x: x._value() if isinstance(x, _Lazy) else x
+        return func(*tree_map(real, args), **tree_map(real, kwargs or {}))
+
+
+def materialize(x):
+    """The real tensor behind a deferred result (anything else is returned as it is).  adopt's own loss functions call it;
+    a caller who hands a deferred image to a torch.autograd.Function of their OWN must too -- Function.apply takes its
+    arguments without dispatching, so the function would see a tensor with no history and the gradient would be lost."""
+    return x._value() if isinstance(x, _Lazy) else x
+
+
+class _PendingRenders:
+    """The renders issued on one parameter version of one model that nothing has used yet."""
+    MAX_VIEWS = 4
+
+    def __init__(self, pc, key):
+        self.pc, self.key = pc, key
+        self.items = []                 # (settings, screenspace_points)
+        self.done = False
+        self.images = self.radii = None
+
+    @staticmethod
+    def key_of(pc, rs):
+        ts = (pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation)
+        return (tuple((id(t), t._version, t.data_ptr()) for t in ts), id(rs.bg), rs.bg._version, float(rs.scale_modifier),
+                int(rs.sh_degree), int(rs.image_height), int(rs.image_width))
+
+    def versions_now(self):
+        pc = self.pc
+        ts = (pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation)
+        return tuple((id(t), t._version, t.data_ptr()) for t in ts)
+
+    def flush(self):
+        if self.done:
+            return
+        pc = self.pc
+        if self.versions_now() != self.key[0]:
+            raise RuntimeError("the model's parameters were replaced or modified in place between render() and the first use "
+                               "of its result: a deferred render cannot reproduce the old values (use the image before the "
+                               "optimizer step, or set E3DGS_ADOPT_DEFER=0 / render(..., defer=False))")
+        if getattr(pc, "_e3dgs_pending", None) is self:
+            pc._e3dgs_pending = None
+        self.done = True
+        with torch.enable_grad():           # (first use may sit inside a no_grad block -- a logging line: the graph is still built)
+            shs = _features(pc)
+            if pc._features_dc.requires_grad or pc._features_rest.requires_grad:
+                shs = _SplitFeatures.apply(pc._features_dc, pc._features_rest, shs)
+            if len(self.items) == 1:
+                rs, ssp = self.items[0]
+                image, radii = rasterizer.rasterize_gaussians(pc._xyz, ssp, shs, None, pc._opacity, pc._scaling, pc._rotation,
+                                                              None, rs, flags=_lib.FLAG_PREACT)
+                self.images, self.radii = [image], [radii]
+            else:
+                settings = tuple(rs for rs, _ in self.items)
+                radii, *images = _RasterizeViews.apply(pc._xyz, shs, pc._opacity, pc._scaling, pc._rotation,
+                                                       self.items[0][1], settings)
+                self.images, self.radii = list(images), [radii[k] for k in range(len(self.items))]
+        self.items = [(rs, None) for rs, _ in self.items]
+
+
+def _deferred_render(pc, rs, screenspace_points):
+    """render() without running the rasteriser yet.  The renders pending on the SAME parameter version of `pc` (same
+    background tensor, scale modifier, SH degree and frame size; at most four) are rendered together by the first use of
+    any of their results: one multi-view pass, forward and backward, instead of one pass each.
+
+    What differs from three immediate renders, and nothing else:
+      * `viewspace_points.grad` is filled for the FIRST render of a batch only (the multi-view backward hands out render
+        #1's screen-space gradient: the densification statistics read no other, train.py:145,317-320); for the later ones
+        it stays None;
+      * results are `_Lazy` tensors until first use -- every torch operation sees the real tensor; a
+        torch.autograd.Function of the caller's own must be given adopt.materialize(image);
+      * an in-place parameter update between render() and the first use raises instead of rendering stale or new values."""
+    key = _PendingRenders.key_of(pc, rs)
+    batch = getattr(pc, "_e3dgs_pending", None)
+    if batch is None or batch.done or batch.key != key or len(batch.items) >= _PendingRenders.MAX_VIEWS:
+        batch = _PendingRenders(pc, key)
+        try:
+            pc._e3dgs_pending = batch
+        except AttributeError:                  # (a model object that takes no attributes: render now)
+            batch.items.append((rs, screenspace_points))
+            batch.flush()
+            return {"render": batch.images[0], "viewspace_points": screenspace_points,
+                    "visibility_filter": batch.radii[0] > 0, "radii": batch.radii[0]}
+    k = len(batch.items)
+    batch.items.append((rs, screenspace_points))
+    dev, P = pc._xyz.device, pc._xyz.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    return {"render": _Lazy(batch, lambda: batch.images[k], (3, H, W), torch.float32, dev),
+            "viewspace_points": screenspace_points,
+            "visibility_filter": _Lazy(batch, lambda: batch.radii[k] > 0, (P,), torch.bool, dev),
+            "radii": _Lazy(batch, lambda: batch.radii[k], (P,), torch.int32, dev)}
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, defer=None):
     """Rung 1: the reference's render() (gaussian_renderer/__init__.py:20-104) -- same arguments, same result dict
     {"render", "viewspace_points", "visibility_filter", "radii"} -- with everything between the model's raw parameters
     and the image inside the rasteriser: SH evaluation (the reference forces the torch branch at :71: ~40 elementwise
     launches per render), exp / sigmoid / normalize (E3DGS_FLAG_PREACT) and their chain rule, one autograd node in C++.
     Needs the reference model's raw tensors (`pc._xyz`, `_features_dc`, `_features_rest`, `_scaling`, `_rotation`,
     `_opacity`) and its activations; anything else (override_color, pipe.compute_cov3D_python, pipe.debug, a model with
-    other activations, no compiled extension) goes through renderer.render, i.e. the reference's own sequence."""
+    other activations, no compiled extension) goes through renderer.render, i.e. the reference's own sequence.
+
+    DEFERRED (defer=True; default: adopt.DEFER_RENDERS, environment E3DGS_ADOPT_DEFER, on): with gradients enabled the call
+    returns at once and the rasteriser runs when an image, `radii` or `visibility_filter` of the result is first USED --
+    train.py:144,159,161 issues the three renders of an event iteration before any loss operation reads them, so they go
+    through the rasteriser as ONE multi-view pass (what render_views does explicitly), forward and backward.  See
+    _deferred_render for what that changes (`viewspace_points.grad` of the second and third render stays None)."""
     from . import renderer
     fast = (override_color is None and not getattr(pipe, "compute_cov3D_python", False)
             and not getattr(pipe, "debug", False) and all(hasattr(pc, a) for a in _RAW_ATTRS)
@@ -105,6 +251,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    if defer is None:
+        defer = DEFER_RENDERS
+    if defer and torch.is_grad_enabled() and int(pc.max_sh_degree) <= 3:
+        return _deferred_render(pc, rs, screenspace_points)
     shs = _features(pc)
     if torch.is_grad_enabled() and (pc._features_dc.requires_grad or pc._features_rest.requires_grad):
         shs = _SplitFeatures.apply(pc._features_dc, pc._features_rest, shs)
@@ -207,19 +357,19 @@ def event_loss(image, image_now, image_next, c, gt_image_intensity, image_now_gt
                gt_c=0.17):
     """Rung 2: the loss block of train.py:165-203 as one autograd node (losses.event_iteration_loss: the fused event-loss
     kernels; value and gradients w.r.t. the three renders and the threshold c)."""
-    return losses.event_iteration_loss(image, image_now, image_next, c, gt_image_intensity, image_now_gt, image_next_gt,
-                                       gt_blur_image, gt_c)
+    return losses.event_iteration_loss(materialize(image), materialize(image_now), materialize(image_next), c,
+                                       gt_image_intensity, image_now_gt, image_next_gt, gt_blur_image, gt_c)
 
 
 def gray_loss(image, gt_image, lambda_dssim=0.2):
     """The `--gray` loss block train.py:213-223 ((1 - lambda) l1_loss_gray + lambda (1 - ssim_gray), utils/loss_utils.py:40-48,
     368-385) with the fused SSIM kernel behind autograd."""
-    return losses.gray_iteration_loss(image, gt_image, lambda_dssim)
+    return losses.gray_iteration_loss(materialize(image), gt_image, lambda_dssim)
 
 
 def rgb_loss(image, gt_image, lambda_dssim=0.2):
     """The RGB loss block train.py:292-296 ((1 - lambda) l1_loss + lambda (1 - ssim), utils/loss_utils.py:270-271,388-396)."""
-    return losses.rgb_iteration_loss(image, gt_image, lambda_dssim)
+    return losses.rgb_iteration_loss(materialize(image), gt_image, lambda_dssim)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -271,10 +421,9 @@ class FusedAdam(torch.optim.Optimizer):
                     g = g.float()
                 losses.adam_step_(p.view(-1), g.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
                                   float(group["lr"]), step, beta1=b1, beta2=b2, eps=float(group["eps"]))
-                # the kernel wrote through raw pointers: tell autograd's version counters, as an in-place torch op would
-                # (render()'s per-version cache of the concatenated SH coefficients, and any saved-tensor check, rely on it)
-                for t in (p, st["exp_avg"], st["exp_avg_sq"]):
-                    torch.autograd.graph.increment_version(t)
+                # (losses.adam_step_ bumps the version counters of the three tensors -- the views share them with their
+                # bases --, as an in-place torch op would: render()'s per-version cache of the concatenated SH coefficients,
+                # the deferred renders' staleness check and autograd's saved-tensor check rely on it)
         return loss
 
 

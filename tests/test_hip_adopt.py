@@ -165,3 +165,65 @@ def test_fused_adam_is_torch_adam():
         assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-6, atol=2e-7)
         assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-6, atol=1e-9)
         assert a._version == b._version                      # the kernel's writes are visible to autograd's version counters
+
+
+def test_deferred_renders_are_one_multi_view_pass_and_equal_three_immediate_renders():
+    """adopt.render(defer=True): the three renders of an iteration run when the first image is used, as ONE multi-view pass
+    (one launch of every rasteriser stage, counted with the library's profiler); images bit-identical to immediate renders,
+    parameter gradients equal to fp32 summation order, render #1's screen-space gradient equal; shape / dtype / device of a
+    pending result are answered without rendering; a first use under no_grad still builds the graph; a parameter update
+    between render() and the first use raises."""
+    import ctypes as C
+    from event_3dgs_amd import _lib, adopt, renderer
+    params, cams, gts, bg = _scene()
+    L = _lib.lib()
+    pipe = renderer.PipelineParams()
+    w = [torch.randn(3, 128, 176, generator=torch.Generator().manual_seed(k)).to(DEV) for k in range(3)]
+
+    def launches(slot):
+        ms, n = C.c_double(0), C.c_int(0)
+        L.e3dgs_profile_query(slot, C.byref(ms), C.byref(n))
+        return n.value
+
+    def run(defer):
+        P = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+        pc = renderer.GaussianView(P, 3, 3)
+        L.e3dgs_profile_enable(0xFF)
+        pk = [adopt.render(c, pc, pipe, bg, defer=defer) for c in cams]
+        if defer:
+            assert launches(0) == 0, "nothing may have been rendered yet"
+            assert tuple(pk[1]["render"].shape) == (3, 128, 176) and pk[1]["render"].dtype == torch.float32
+            assert pk[2]["radii"].shape[0] == params["xyz"].shape[0] and pk[0]["render"].is_cuda
+            assert launches(0) == 0, "metadata of a pending result is answered without rendering"
+            with torch.no_grad():
+                _ = float(pk[2]["render"].mean())               # first use inside no_grad (a logging line)
+        loss = sum((p["render"] * wk).sum() for p, wk in zip(pk, w))
+        loss.backward()
+        torch.cuda.synchronize()
+        n_pre, n_bwd = launches(0), launches(6)
+        L.e3dgs_profile_enable(0)
+        return pk, P, n_pre, n_bwd
+    pk_d, P_d, pre_d, bwd_d = run(True)
+    pk_i, P_i, pre_i, bwd_i = run(False)
+    assert (pre_d, bwd_d) == (1, 1) and (pre_i, bwd_i) == (3, 3)
+    for a, b in zip(pk_d, pk_i):
+        assert torch.equal(adopt.materialize(a["render"]), b["render"])
+        assert torch.equal(adopt.materialize(a["radii"]), b["radii"])
+        assert torch.equal(adopt.materialize(a["visibility_filter"]), b["visibility_filter"])
+    for k in P_d:
+        ga, gb = P_d[k].grad.cpu().numpy(), P_i[k].grad.cpu().numpy()
+        assert rel_l2(ga, gb) <= 2e-5, k
+    assert rel_l2(pk_d[0]["viewspace_points"].grad.cpu().numpy(), pk_i[0]["viewspace_points"].grad.cpu().numpy()) <= 2e-5
+    assert pk_d[1]["viewspace_points"].grad is None and pk_i[1]["viewspace_points"].grad is not None
+    # visibility_filter as an index (train.py:318-320) and an image used after the optimizer moved the parameters
+    P = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+    pc = renderer.GaussianView(P, 3, 3)
+    pkg = adopt.render(cams[0], pc, pipe, bg, defer=True)
+    acc = torch.zeros(params["xyz"].shape[0], device=DEV)
+    acc[pkg["visibility_filter"]] = torch.max(acc[pkg["visibility_filter"]], pkg["radii"][pkg["visibility_filter"]].float())
+    assert float(acc.max()) > 0
+    stale = adopt.render(cams[1], pc, pipe, bg, defer=True)
+    with torch.no_grad():
+        P["xyz"].add_(1e-3)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        stale["render"].sum()
