@@ -206,6 +206,7 @@ FLAG_CULL_RECT = 0x1000
 FLAG_CULL_NO_BOX = 0x2000
 FLAG_NO_SMALL_PATHS = 0x4000
 FLAG_FAST_EXP = 0x8000
+FLAG_MEAN2D_VIEWS = 0x10000
 OPTION_MASK = FLAG_OPTIONS | FLAG_CULL_RECT | FLAG_CULL_NO_BOX | FLAG_NO_SMALL_PATHS | FLAG_FAST_EXP
 ACC_STRIDE = 12
 

@@ -183,8 +183,8 @@ class _PendingRenders:
                 self.images, self.radii = [image], [radii]
             else:
                 settings = tuple(rs for rs, _ in self.items)
-                radii, *images = _RasterizeViews.apply(pc._xyz, shs, pc._opacity, pc._scaling, pc._rotation,
-                                                       self.items[0][1], settings)
+                radii, *images = _RasterizeViews.apply(pc._xyz, shs, pc._opacity, pc._scaling, pc._rotation, settings,
+                                                       *[ssp for _, ssp in self.items])
                 self.images, self.radii = list(images), [radii[k] for k in range(len(self.items))]
         self.items = [(rs, None) for rs, _ in self.items]
 
@@ -194,10 +194,8 @@ def _deferred_render(pc, rs, screenspace_points):
     background tensor, scale modifier, SH degree and frame size; at most four) are rendered together by the first use of
     any of their results: one multi-view pass, forward and backward, instead of one pass each.
 
-    What differs from three immediate renders, and nothing else:
-      * `viewspace_points.grad` is filled for the FIRST render of a batch only (the multi-view backward hands out render
-        #1's screen-space gradient: the densification statistics read no other, train.py:145,317-320); for the later ones
-        it stays None;
+    What differs from three immediate renders, and nothing else (every render's `viewspace_points.grad` is filled with its
+    own view's screen-space gradient, E3DGS_FLAG_MEAN2D_VIEWS):
       * results are `_Lazy` tensors until first use -- every torch operation sees the real tensor; a
         torch.autograd.Function of the caller's own must be given adopt.materialize(image);
       * an in-place parameter update between render() and the first use raises instead of rendering stale or new values."""
@@ -235,7 +233,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     returns at once and the rasteriser runs when an image, `radii` or `visibility_filter` of the result is first USED --
     train.py:144,159,161 issues the three renders of an event iteration before any loss operation reads them, so they go
     through the rasteriser as ONE multi-view pass (what render_views does explicitly), forward and backward.  See
-    _deferred_render for what that changes (`viewspace_points.grad` of the second and third render stays None)."""
+    _deferred_render for what that changes (results are lazy until first use; a parameter update in between raises)."""
     from . import renderer
     fast = (override_color is None and not getattr(pipe, "compute_cov3D_python", False)
             and not getattr(pipe, "debug", False) and all(hasattr(pc, a) for a in _RAW_ATTRS)
@@ -282,7 +280,9 @@ class _RasterizeViews(torch.autograd.Function):
     (e3dgs_rasterize_forward_multi / _backward_multi; raw parameters, E3DGS_FLAG_PREACT)."""
 
     @staticmethod
-    def forward(ctx, xyz, shs, opacity, scaling, rotation, means2D, settings):
+    def forward(ctx, xyz, shs, opacity, scaling, rotation, settings, *means2D):
+        # means2D: the viewspace_points leaves, one per view (each receives its view's screen-space gradient), or just the
+        # first view's
         pend = rasterizer.forward_multi_begin(xyz.detach(), shs.detach(), opacity.detach(), scaling.detach(),
                                               rotation.detach(), list(settings),
                                               flags=_lib.FLAG_PREACT | _lib.FLAG_COUNT_MAPPED, count_host=_count_word(xyz.device))
@@ -291,6 +291,7 @@ class _RasterizeViews(torch.autograd.Function):
         raw = rasterizer.forward_multi_finish(pend)
         ctx.raw = raw
         ctx.n = len(settings)
+        ctx.n_m2 = len(means2D)
         # (the kernels read the inputs again in backward: saved through autograd, so that an in-place update between forward
         # and backward is reported the way autograd reports it for any saved tensor, as the C++ node of single renders does)
         ctx.save_for_backward(xyz, shs, opacity, scaling, rotation)
@@ -310,10 +311,14 @@ class _RasterizeViews(torch.autograd.Function):
         H, W = raw["color"].shape[2], raw["color"].shape[3]
         g = torch.stack([gi if gi is not None else torch.zeros(3, H, W, device=xyz.device) for gi in g_imgs]).float()
         e = lambda t: torch.empty_like(t)
+        per_view = ctx.n_m2 == n and n > 1
         out = dict(means3D=e(xyz), sh=e(shs), opacities=e(raw["opacities"]), scales=e(scaling), rots=e(rotation),
-                   means2D=torch.empty_like(xyz))
+                   means2D=torch.empty((n,) + tuple(xyz.shape), dtype=xyz.dtype, device=xyz.device) if per_view
+                   else torch.empty_like(xyz))
         rasterizer.backward_multi(raw, g, out)
-        return out["means3D"], out["sh"], out["opacities"], out["scales"], out["rots"], out["means2D"], None
+        m2 = tuple(out["means2D"][k] for k in range(n)) if per_view else \
+            ((out["means2D"],) + (None,) * (ctx.n_m2 - 1) if ctx.n_m2 else ())
+        return (out["means3D"], out["sh"], out["opacities"], out["scales"], out["rots"], None) + m2
 
 
 def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0):
@@ -324,10 +329,9 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0):
             (viewpoint_cam, viewpoint_cam_now, viewpoint_cam_next), gaussians, pipe, bg)
 
     Every kernel of the pipeline runs once over all cameras and the per-Gaussian backward sums the views in registers
-    (what EventTrainer.step runs, here behind autograd).  The cameras must share one frame size; `viewspace_points`
-    carries the screen-space gradient of the FIRST camera only (the densification statistics read render #1,
-    train.py:145,317-320) -- the other dicts hold a zero tensor.  Falls back to one render() per camera when the fast path
-    of render() does not apply or the frame sizes differ."""
+    (what EventTrainer.step runs, here behind autograd).  The cameras must share one frame size; every dict carries its own
+    `viewspace_points` leaf, filled with its view's screen-space gradient (E3DGS_FLAG_MEAN2D_VIEWS).  Falls back to one
+    render() per camera when the fast path of render() does not apply or the frame sizes differ."""
     cams = list(viewpoint_cameras)
     sizes = {(int(c.image_height), int(c.image_width)) for c in cams}
     fast = (len(cams) >= 1 and len(cams) <= 4 and len(sizes) == 1 and not getattr(pipe, "compute_cov3D_python", False)
@@ -345,12 +349,10 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0):
     shs = _features(pc)
     if torch.is_grad_enabled() and (pc._features_dc.requires_grad or pc._features_rest.requires_grad):
         shs = _SplitFeatures.apply(pc._features_dc, pc._features_rest, shs)
-    radii, *images = _RasterizeViews.apply(xyz, shs, pc._opacity, pc._scaling, pc._rotation, screenspace_points, settings)
-    out = []
-    for k, img in enumerate(images):
-        vs = screenspace_points if k == 0 else torch.zeros_like(xyz)
-        out.append({"render": img, "viewspace_points": vs, "visibility_filter": radii[k] > 0, "radii": radii[k]})
-    return out
+    leaves = [screenspace_points] + [torch.zeros_like(xyz, requires_grad=True) for _ in cams[1:]]
+    radii, *images = _RasterizeViews.apply(xyz, shs, pc._opacity, pc._scaling, pc._rotation, settings, *leaves)
+    return [{"render": img, "viewspace_points": leaves[k], "visibility_filter": radii[k] > 0, "radii": radii[k]}
+            for k, img in enumerate(images)]
 
 
 def event_loss(image, image_now, image_next, c, gt_image_intensity, image_now_gt, image_next_gt, gt_blur_image=None,

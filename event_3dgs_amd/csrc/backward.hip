@@ -1045,8 +1045,16 @@ __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_m
     // the common path with zero sums and every store below is executed by the whole wave: each store instruction covers
     // whole, contiguous lines.  Only a wave without any seen Gaussian takes the shortcut (its stores are whole lines too).
     const bool seen = vis != 0u;
+    // E3_FLAG_MEAN2D_VIEWS: dL_dmean2D is (nviews, P, 3) and receives the screen-space gradient of EVERY view (the
+    // deferred renders of adopt.render: each render() call owns a viewspace_points leaf); otherwise view 0's only
+    const bool m2views = dL_dmean2D && (flags & E3_FLAG_MEAN2D_VIEWS) != 0;
     if (__builtin_amdgcn_ballot_w64(seen) == 0ull) {
         if (dL_dmean2D) { dL_dmean2D[3 * (size_t)i] = 0.0f; dL_dmean2D[3 * (size_t)i + 1] = 0.0f; dL_dmean2D[3 * (size_t)i + 2] = 0.0f; }
+        if (m2views)
+            for (int v = 1; v < nv; ++v) {
+                float* mp = dL_dmean2D + ((size_t)v * P + i) * 3;
+                mp[0] = 0.0f; mp[1] = 0.0f; mp[2] = 0.0f;
+            }
         dL_dopacity[i] = 0.0f;
         dL_dmean3D[3 * (size_t)i] = 0.0f; dL_dmean3D[3 * (size_t)i + 1] = 0.0f; dL_dmean3D[3 * (size_t)i + 2] = 0.0f;
         if (dsh) for (int k = 0; k < 3 * M; ++k) dsh[(size_t)k * st] = 0.0f;
@@ -1070,11 +1078,13 @@ __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_m
 #pragma unroll 1
     for (int v = 0; v < nv; ++v) {
         float o_dx = 0.0f, o_dy = 0.0f, o_dz = 0.0f, o_il = 0.0f, o_g0 = 0.0f, o_g1 = 0.0f, o_g2 = 0.0f;
+        float o_m2x = 0.0f, o_m2y = 0.0f;
         if ((vis >> v) & 1u) {
             const ViewParams& vp = mv.vs.v[v];
             const size_t q = (size_t)i * nv + v;
             float g12[9], gcv[6], gmv[3];
             load_sums(mv.gsum, q, g12);
+            o_m2x = g12[0]; o_m2y = g12[1];          // NDC-unit screen-space gradient of this view (E3_FLAG_MEAN2D_VIEWS)
             view_geom_backward(vp, mx, my, mz, cv.S, g12, gcv, gmv);
 #pragma unroll
             for (int k = 0; k < 6; ++k) gcov[k] += gcv[k];
@@ -1102,6 +1112,10 @@ __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_m
         if (gcol) {
             float* gp = gcol + ((size_t)v * P + i) * 3;
             gp[0] = o_g0; gp[1] = o_g1; gp[2] = o_g2;
+        }
+        if (m2views && v > 0) {      // (view 0's block is written below; unseen views: zeros, o_m2 = 0)
+            float* mp = dL_dmean2D + ((size_t)v * P + i) * 3;
+            mp[0] = o_m2x; mp[1] = o_m2y; mp[2] = 0.0f;
         }
     }
     if (dL_dmean2D) {   // densification statistics use render #1 only (train.py:145)

@@ -36,6 +36,7 @@
 #define E3_FLAG_CULL_NO_BOX 0x2000        // exact culling without the tight candidate box
 #define E3_FLAG_NO_SMALL_PATHS 0x4000     // large-scene work decomposition whatever the splat count
 #define E3_FLAG_FAST_EXP 0x8000           // tolerance mode: hardware exp2 in the compositing forward (and its backward twin)
+#define E3_FLAG_MEAN2D_VIEWS 0x10000     // backward_multi: dL_dmean2D is (nviews, P, 3): EVERY view's screen-space gradient, not view 0's only
 #define E3_MAX_VIEWS 4       // views per e3dgs_rasterize_backward_geom_multi call
 #define E3_ACC_STRIDE 12      // floats the CALLER provides per (tile, Gaussian) instance and per splat sum in grad_acc
 #define E3_REC_FLOATS 9       // floats of a per-instance gradient record as stored (packed, 36 B; the rest is slack)

@@ -683,8 +683,8 @@ GRAY_WEIGHTS = (0.299, 0.587, 0.114)        # rgb_to_grayscale, utils/loss_utils
 
 def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None, stats_grad_view0=None, rank1=None):
     """e3dgs_rasterize_backward_multi for a forward_multi result.  grad_out_color is (n,3,H,W); `out` maps
-    means2D (optional, view 0) / opacities / means3D / sh / scales / rots to tensors that are fully overwritten
-    with the gradient summed over the views.  Optional `colour_views` (n,P,3): the per-view clamp-masked colour
+    means2D (optional: (P,3) = view 0's screen-space gradient, (n,P,3) = every view's) / opacities / means3D / sh / scales /
+    rots to tensors that are fully overwritten with the gradient summed over the views.  Optional `colour_views` (n,P,3): the per-view clamp-masked colour
     gradients (then `sh` may be omitted; see sh_grad_from_colour).
     stats_grad_view0 (3,H,W): e3dgs_rasterize_backward_multi_stats -- out["means2D"] is the screen-space gradient view 0
     has under THAT pixel gradient, everything else follows grad_out_color (shared-pose iterations that collect
@@ -715,6 +715,12 @@ def backward_multi(raw, grad_out_color, out, flags=None, grad_acc=None, stats_gr
     elif grad_acc is None:
         grad_acc = torch.empty(int(raw["num_rendered"]) + len(sl) * P, _lib.ACC_STRIDE, dtype=torch.float32,
                                device=dev)
+    m2 = out.get("means2D")
+    if m2 is not None and m2.dim() == 3:
+        # (nviews, P, 3): every view's screen-space gradient (E3DGS_FLAG_MEAN2D_VIEWS); (P, 3): view 0's only
+        if tuple(m2.shape) != (len(sl), P, 3) or not m2.is_contiguous():
+            raise ValueError("a per-view means2D output must be a contiguous (nviews, P, 3) tensor")
+        flags = int(flags) | _lib.FLAG_MEAN2D_VIEWS
     arrays, keep = _view_arrays(sl)
     head = (len(sl), P, int(rs.sh_degree), raw["M"], raw["num_rendered"], _lib.ptr(raw["bg"]), W, H, _lib.ptr(means3D),
             _lib.ptr(sh), _lib.ptr(raw.get("opacities")), _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rots),

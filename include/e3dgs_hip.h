@@ -94,6 +94,9 @@ const char* e3dgs_last_error(void);
                                              unchanged, the image agrees to <= 1e-4 except at the handful of pixels where
                                              an alpha >= 1/255 or T < 1e-4 decision flips (<= 1/255 each), gradients to
                                              1e-3.  Give the same bit to the backward. */
+#define E3DGS_FLAG_MEAN2D_VIEWS 0x10000   /* backward_multi* (ABI 17): dL_dmean2D is (nviews, P, 3) and receives the NDC-unit
+                                             screen-space gradient of EVERY view (block v = view v); without it, (P, 3):
+                                             view 0's only -- what the densification statistics read, train.py:145 */
 #define E3DGS_FLAG_BWD_ONLY_RENDER 8   /* backward: only the compositing backward (pixels -> grad_acc) */
 #define E3DGS_FLAG_BWD_ONLY_GEOM 16    /* backward: only the per-Gaussian backward (grad_acc -> parameter gradients).
                                           Together these let a caller overlap the compositing backward of several

@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_hip_trained_and_oracle_trained_reach_the_same_psnr():
+@pytest.mark.parametrize("fast_exp", [False, True])
+def test_hip_trained_and_oracle_trained_reach_the_same_psnr(fast_exp):
+    """fast_exp=True: the same criterion for the tolerance mode (E3DGS_FLAG_FAST_EXP: hardware exp in the compositing
+    kernels) -- what lets bench.py report it as a second, labelled figure."""
     from event_3dgs_amd import fit, scene_io, synth
     from event_3dgs_amd.cameras import orbit_camera
     from event_3dgs_amd.train_step import EventTrainer
@@ -43,7 +46,7 @@ def test_hip_trained_and_oracle_trained_reach_the_same_psnr():
     init["xyz"] += 0.02 * torch.randn(N, 3, generator=g).to(DEV)
     init["features_dc"] += 0.5 * torch.randn(N, 1, 3, generator=g).to(DEV)
     init["opacity"] *= 0.7
-    hip = EventTrainer(init, DEV)
+    hip = EventTrainer(init, DEV, fast_exp=fast_exp)
     ora = OracleTrainer(init)
     cd_train = [camera_dict(c) for c in train]
     cd_event = [camera_dict(c) for c in events]
@@ -69,7 +72,7 @@ def test_hip_trained_and_oracle_trained_reach_the_same_psnr():
     print(f"gray PSNR on the held-out views: initial {p0_hip:.3f} dB; after {ITERS} iterations HIP-trained {p_hip:.3f} dB, "
           f"oracle-trained {p_ora:.3f} dB; first losses {lh[0]:.6f} / {lo[0]:.6f}, last {lh[-1]:.6f} / {lo[-1]:.6f}; "
           f"c {float(hip.c):.5f} / {float(ora.c):.5f}")
-    assert abs(lh[0] - lo[0]) <= 1e-5 * abs(lo[0])
+    assert abs(lh[0] - lo[0]) <= (1e-4 if fast_exp else 1e-5) * abs(lo[0])
     assert p_hip > p0_hip + 1.0 and p_ora > p0_ora + 1.0         # both actually trained
     assert abs(p_hip - p_ora) <= 0.1                             # north_star: PSNR within 0.1 dB of the reference
 

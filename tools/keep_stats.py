@@ -48,6 +48,13 @@ for t in tiles:
     cs = strips(contrib)
     S["entries"] += n; S["processed"] += processed
     S["eval_strips"] += int(ev.sum()); S["contrib_strips"] += int(cs.sum())
+    # alternative 64-pixel groupings of the tile (round 6: would 8 x 8 blocks be evaluated less often than 16 x 4 strips?)
+    blocks8 = lambda m: m.view(n, 2, 8, 2, 8).any(dim=4).any(dim=2).reshape(n, 4)
+    cols4 = lambda m: m.view(n, 16, 4, 4).any(dim=3).any(dim=1)          # 4 x 16 column strips
+    for name, part in (("b8", blocks8), ("c4", cols4)):
+        S.setdefault("eval_" + name, 0); S.setdefault("contrib_" + name, 0)
+        S["eval_" + name] += int((part(alive & reach) & tile_alive[:, None]).sum())
+        S["contrib_" + name] += int(part(contrib).sum())
     S["contrib_px"] += int(contrib.sum()); S["entries_any"] += int(cs.any(dim=1).sum())
     alive_strip = strips(alive)
     S["strip_tests"] += 4 * processed; S["dead_strip_tests"] += int((~alive_strip & tile_alive[:, None]).sum())
@@ -62,5 +69,9 @@ print("forward: processed %.2f of the list; evaluated strips per processed entry
       "contributing pixels per evaluated strip %.1f of 64; strip tests on strips with no live pixel %.3f" % (
           S["processed"] / S["entries"], S["eval_strips"] / S["processed"], S["contrib_strips"] / S["eval_strips"],
           S["contrib_px"] / S["eval_strips"], S["dead_strip_tests"] / S["strip_tests"]))
+print("groupings of 64 pixels, evaluated groups per processed entry (contributing groups): 16x4 strips %.3f (%.3f), 8x8 blocks "
+      "%.3f (%.3f), 4x16 columns %.3f (%.3f)" % (S["eval_strips"] / S["processed"], S["contrib_strips"] / S["processed"],
+                                                 S["eval_b8"] / S["processed"], S["contrib_b8"] / S["processed"],
+                                                 S["eval_c4"] / S["processed"], S["contrib_c4"] / S["processed"]))
 print("backward: visited entries %.2f of the list, live strips per visited entry %.2f, contributing pixels per live strip %.1f" % (
     S["bwd_entries"] / S["entries"], S["bwd_strips"] / max(S["bwd_entries"], 1), S["contrib_px"] / max(S["bwd_strips"], 1)))
