@@ -594,6 +594,9 @@ def main():
                                 "sclk_mhz_reported_mean": round(sum(sclk) / len(sclk), 1) if sclk else None,
                                 "rocm_smi_samples": len(samples), "last_sample": samples[-1] if samples else None,
                                 "stage_avg_ms_at_the_end": end_stages,
+                                # why this leg is slower than the headline: the SAME triplet for 500 more iterations -- the scene
+                                # overfits three views and the walks deepen (compare trained_random_camera.walk_statistics)
+                                "walk_statistics_at_the_end": _walk_statistics(trainer, (cam_int, cam_now, cam_next), bg, W, H),
                                 "stage_avg_ms_in_the_timed_region_s_table": {k: v["avg_ms"] for k, v in stages.items()},
                                 "in_kernel_clock_ghz": {k: (v.get("clock") or {}).get("ghz_median") for k, v in
                                                         ((roofline or {}).get("kernels") or {}).items()}}
