@@ -1,4 +1,4 @@
-"""The committed profile summary bench.py decorates its line with (profiles/traffic.json = profiles/r05_final/summary.json,
+"""The committed profile summary bench.py decorates its line with (profiles/traffic.json = profiles/r06_final/summary.json,
 written by profiles/collect.py on the GPU box) is complete: the per-iteration attribution found the iteration's kernels
 and the dominant kernel's HBM traffic is there under the name bench.py looks up.  (Whether it still describes the
 current sources is reported by bench.py itself: `traffic_stale`.)"""
