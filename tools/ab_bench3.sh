@@ -6,7 +6,7 @@ cp $LIVE /tmp/live.so
 for r in $(seq $R); do
   for src in "$@"; do
     cp $src $LIVE
-    python bench.py --no-cpu-baseline --no-substep 2>&1 | tail -1 | python -c "
+    python bench.py --no-cpu-baseline --no-substep $BENCH_ARGS 2>&1 | tail -1 | python -c "
 import json,sys;d=json.loads(sys.stdin.read());print('$src', d['value'],d['ms_per_step'], {k:v['avg_ms'] for k,v in d['stages'].items()})"
   done
 done
