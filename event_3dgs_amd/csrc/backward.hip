@@ -1015,6 +1015,9 @@ __device__ __forceinline__ void sh_basis(int k, float x, float y, float z, float
 // NK: coefficients per channel the SH loop is unrolled for -- 16 (degrees 0..3, the reference model's; the instantiation
 // every training path runs) or 25 (degree 4, utils/sh_utils.py:97-110: a caller of the multi-view entry points with
 // (P, 25, 3) coefficients)
+#ifndef E3_GEOM_PREFETCH
+#define E3_GEOM_PREFETCH 1
+#endif
 template <bool DEFER, int NK = 16>
 __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_multi_kernel(
     int P, int D, int M, const float* __restrict__ means, const float* __restrict__ shs,
@@ -1075,15 +1078,39 @@ __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_m
     build_cov3(sact, mv.vs.v[0].scale_modifier, qn[0], qn[1], qn[2], qn[3], cv);
     float gcov[6] = {0, 0, 0, 0, 0, 0}, gmean[3] = {0, 0, 0}, gopac = 0.0f;
     float m2x = 0.0f, m2y = 0.0f;
+#if E3_GEOM_PREFETCH
+    // the NEXT view's sums (and clamp bits) are requested before this view is computed: the view loop is rolled (one copy of
+    // a ~90-register body), so without this each view's round trip starts only when the previous view's arithmetic is done
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    uint32_t ncl = 0u;
+    auto fetch = [&](int v) __attribute__((always_inline)) {
+        if (v < nv && ((vis >> v) & 1u)) {
+            const size_t q = (size_t)i * nv + v;
+            n0 = mv.gsum[3 * q]; n1 = mv.gsum[3 * q + 1]; n2 = mv.gsum[3 * q + 2];
+            ncl = mv.clamped[q];
+        }
+    };
+    fetch(0);
+#endif
 #pragma unroll 1
     for (int v = 0; v < nv; ++v) {
         float o_dx = 0.0f, o_dy = 0.0f, o_dz = 0.0f, o_il = 0.0f, o_g0 = 0.0f, o_g1 = 0.0f, o_g2 = 0.0f;
         float o_m2x = 0.0f, o_m2y = 0.0f;
+#if E3_GEOM_PREFETCH
+        const float4 c0 = n0, c1 = n1, c2 = n2;
+        const uint32_t ccl = ncl;
+        fetch(v + 1);
+#endif
         if ((vis >> v) & 1u) {
             const ViewParams& vp = mv.vs.v[v];
             const size_t q = (size_t)i * nv + v;
             float g12[9], gcv[6], gmv[3];
+#if E3_GEOM_PREFETCH
+            g12[0] = c0.x; g12[1] = c0.y; g12[2] = c0.z; g12[3] = c0.w;
+            g12[4] = c1.x; g12[5] = c1.y; g12[6] = c1.z; g12[7] = c1.w; g12[8] = c2.x;
+#else
             load_sums(mv.gsum, q, g12);
+#endif
             o_m2x = g12[0]; o_m2y = g12[1];          // NDC-unit screen-space gradient of this view (E3_FLAG_MEAN2D_VIEWS)
             view_geom_backward(vp, mx, my, mz, cv.S, g12, gcv, gmv);
 #pragma unroll
@@ -1091,10 +1118,19 @@ __global__ __launch_bounds__(256, DEFER ? E3_GEOM_DEFER_OCC : 4) void geom_bwd_m
             gmean[0] += gmv[0]; gmean[1] += gmv[1]; gmean[2] += gmv[2];
             gopac += g12[5];
             if (v == 0) {
+#if E3_GEOM_PREFETCH
+                if (mv.stats) { m2x = c2.y; m2y = c2.z; }
+#else
                 if (mv.stats) { const float4 s2 = mv.gsum[3 * q + 2]; m2x = s2.y; m2y = s2.z; }
+#endif
                 else { m2x = g12[0]; m2y = g12[1]; }
             }
+#if E3_GEOM_PREFETCH
+            const uint32_t cl = ccl;
+            (void)q;
+#else
             const uint32_t cl = mv.clamped[q];
+#endif
             o_g0 = (cl & 1u) ? 0.0f : g12[6];
             o_g1 = (cl & 2u) ? 0.0f : g12[7];
             o_g2 = (cl & 4u) ? 0.0f : g12[8];
